@@ -1,0 +1,392 @@
+"""Capture golden vectors by running the UNMODIFIED reference in this container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/generate.py
+
+Imports `emphases` from /root/reference with the third-party stand-ins of
+`tests/golden/stubs/` (see its README) and, for every case below, records the
+inputs and what the reference's own modules produce in float32 with autocast
+disabled ("O-fp32", the parity oracle of SURVEY.md §8c) plus, for information,
+what the shipped API returns under its bf16 autocast ("O-shipped").
+
+Outputs (committed; data only, no reference source):
+  tests/golden/cases.npz       default conv model, bundled checkpoint
+  tests/golden/chunks.npz      chunk plans of `emphases.preprocess`
+  tests/golden/variants.npz    config-variant matrix with seeded weights
+  emphases_amd/assets/checkpoint.npz   the reference's trained weights
+The GPU box never runs this script; it only reads the .npz files.
+"""
+import hashlib
+import os
+import sys
+
+os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
+sys.dont_write_bytecode = True
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = '/root/reference'
+sys.path[:0] = [os.path.join(HERE, 'stubs'), REFERENCE, ROOT]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import emphases  # noqa: E402  (the reference)
+import pypar  # noqa: E402  (stand-in)
+
+from emphases_amd import config as acfg  # noqa: E402
+from emphases_amd import synth, weights  # noqa: E402
+from oracle import prominence as oracle  # noqa: E402
+
+torch.set_num_threads(1)
+CHECKPOINT = os.path.join(
+    REFERENCE, 'emphases', 'assets', 'checkpoints', 'checkpoint.pt')
+
+
+###############################################################################
+# Reference drivers
+###############################################################################
+
+
+def make_alignment(bounds_seconds, names=None):
+    names = names or synth.word_names(len(bounds_seconds))
+    return pypar.Alignment([
+        pypar.Word(name, start, end)
+        for name, (start, end) in zip(names, bounds_seconds)])
+
+
+def reference_model(state=None):
+    model = emphases.Model()
+    if state is None:
+        state = torch.load(
+            CHECKPOINT, map_location='cpu', weights_only=False)['model']
+        model.load_state_dict(state)
+    else:
+        result = model.load_state_dict(
+            {k: torch.from_numpy(v) for k, v in state.items()}, strict=False)
+        assert not result.unexpected_keys, result
+        assert all('position.encoding' in k for k in result.missing_keys), \
+            result
+    return model.eval()
+
+
+def run_fp32(model, alignment, audio, batch_size=None):
+    """O-fp32: the reference's `preprocess` and `Model`, autocast disabled."""
+    stages = []
+    captured = {}
+    hooks = [
+        model.input_layer.register_forward_hook(
+            lambda m, i, o: captured.__setitem__('input_layer', o)),
+        model.frame_encoder.register_forward_hook(
+            lambda m, i, o: captured.__setitem__('encoder', o))]
+    original = emphases.downsample
+
+    def downsample(*args):
+        result = original(*args)
+        captured['downsampled'] = result
+        return result
+    emphases.downsample = downsample
+    try:
+        with torch.no_grad():
+            for features, bounds in emphases.preprocess(
+                    alignment, audio, emphases.SAMPLE_RATE, batch_size, None):
+                captured.clear()
+                frame_lengths = torch.tensor([features.shape[-1]])
+                word_lengths = torch.tensor([bounds.shape[-1]])
+                logits = model(features, frame_lengths, bounds, word_lengths)
+                stages.append(dict(
+                    features=features[0].numpy(),
+                    bounds=bounds[0].numpy(),
+                    logits=logits[0, 0].numpy(),
+                    scores=emphases.postprocess(logits)[0, 0].numpy(),
+                    **{k: v[0].numpy() for k, v in captured.items()}))
+    finally:
+        emphases.downsample = original
+        for hook in hooks:
+            hook.remove()
+    return stages
+
+
+def run_shipped(alignment, audio, batch_size=None):
+    """O-shipped: the public API verbatim (bf16 autocast on CPU)."""
+    for name in ('model', 'checkpoint', 'device_type'):
+        if hasattr(emphases.infer, name):
+            delattr(emphases.infer, name)
+    return emphases.from_alignment_and_audio(
+        alignment, audio, emphases.SAMPLE_RATE, CHECKPOINT, batch_size,
+        None).float().numpy()
+
+
+###############################################################################
+# Cases
+###############################################################################
+
+
+def seconds(bounds_frames):
+    return [(int(s) / 100.0, int(e) / 100.0) for s, e in bounds_frames.T]
+
+
+def two_tone():
+    """SURVEY.md App. E known-answer input."""
+    n = np.arange(16000, dtype=np.float64)
+    x = 0.1 * np.sin(2 * np.pi * 220 * n / 16000) + \
+        0.05 * np.sin(2 * np.pi * 1000 * n / 16000)
+    bounds = np.array([[0, 25, 50, 75], [25, 50, 75, 100]])
+    return x.astype(np.float32)[None], bounds
+
+
+def default_cases():
+    cases = {}
+    audio, bounds = two_tone()
+    cases['two_tone_1s'] = (audio, bounds, None)
+    cases['utt_2p5s'] = (
+        synth.audio(3, 250), synth.word_frames(3, 250), None)
+    cases['utt_10s'] = (
+        synth.audio(0, 1000), synth.word_frames(0, 1000), None)
+    cases['utt_silence_6s'] = (
+        synth.audio(9, 600), synth.word_frames(9, 600), None)
+    # words of 1 and 2 frames, and a leading stretch of digital silence
+    audio = synth.audio(5, 300)
+    audio[:, :16000] = 0.
+    bounds = np.array([
+        [0, 100, 101, 103, 150, 151, 220],
+        [100, 101, 103, 150, 151, 220, 300]])
+    cases['short_words_3s'] = (audio, bounds, None)
+    # the float-floor quirk: 8.03 s -> frame 802 (convert.py:29-31)
+    ends = [57, 203, 411, 803, 811, 819, 1000, 1206, 1606, 1613, 1615, 1622,
+            1631, 1700]
+    bounds = np.array([[0] + ends[:-1], ends])
+    cases['float_floor_17s'] = (synth.audio(7, 1700), bounds, None)
+    frames = 4118
+    cases['chunked_41s_b500'] = (
+        synth.audio(11, frames), synth.word_frames(11, frames, 8, 60), 500)
+    cases['chunked_41s_b1000'] = (
+        synth.audio(11, frames), synth.word_frames(11, frames, 8, 60), 1000)
+    return cases
+
+
+def capture_default(out):
+    model = reference_model()
+    state = {k: v.numpy() for k, v in model.state_dict().items()}
+    worst = 0.
+    for name, (audio, bounds, batch_size) in default_cases().items():
+        audio_t = torch.from_numpy(audio)
+        words = seconds(bounds)
+        alignment = make_alignment(words)
+        stages = run_fp32(model, alignment, audio_t, batch_size)
+        shipped = run_shipped(alignment, audio_t, batch_size)
+        scores = np.concatenate([s['scores'] for s in stages])
+        pcm = np.rint(audio[0] * 32768.0)
+        if np.array_equal(pcm / 32768.0, audio[0].astype(np.float64)):
+            out[f'{name}/pcm'] = pcm.astype(np.int16)
+        else:
+            out[f'{name}/audio'] = audio[0]
+        out[f'{name}/bounds_frames'] = bounds.astype(np.int32)
+        out[f'{name}/batch_size'] = np.int64(
+            -1 if batch_size is None else batch_size)
+        out[f'{name}/scores'] = scores
+        out[f'{name}/scores_shipped_bf16'] = shipped[0]
+        out[f'{name}/chunk_frames'] = np.array(
+            [s['features'].shape[-1] for s in stages], dtype=np.int32)
+        out[f'{name}/chunk_words'] = np.array(
+            [s['bounds'].shape[-1] for s in stages], dtype=np.int32)
+        out[f'{name}/chunk_bounds'] = np.concatenate(
+            [s['bounds'] for s in stages], axis=1).astype(np.int32)
+        out[f'{name}/logits'] = np.concatenate(
+            [s['logits'] for s in stages])
+        out[f'{name}/downsampled'] = np.concatenate(
+            [s['downsampled'] for s in stages], axis=1)
+        mel = np.concatenate([s['features'] for s in stages], axis=1)
+        encoder = np.concatenate([s['encoder'] for s in stages], axis=1)
+        first = np.concatenate([s['input_layer'] for s in stages], axis=1)
+        if mel.shape[1] <= 1000:
+            out[f'{name}/mel'] = mel
+            out[f'{name}/encoder'] = encoder
+            out[f'{name}/input_layer'] = first
+        else:
+            # long cases: every 7th frame plus the chunk edges
+            out[f'{name}/mel_stride7'] = mel[:, ::7]
+            out[f'{name}/encoder_stride7'] = encoder[:, ::7]
+        # the oracle must agree with the reference it restates
+        mine = oracle.from_alignment_and_audio(
+            words, audio_t, {k: torch.from_numpy(v) for k, v in state.items()},
+            {}, batch_size)[0].numpy()
+        delta = float(np.abs(mine - scores).max())
+        worst = max(worst, delta)
+        print(f'{name:22s} F={mel.shape[1]:5d} W={scores.size:4d} '
+              f'chunks={len(stages):2d} |oracle-ref|={delta:.2e} '
+              f'|shipped-ref|={np.abs(shipped[0] - scores).max():.2e}')
+    assert worst < 2e-6, worst
+    return state
+
+
+###############################################################################
+# Chunk plans (host arithmetic of core.py:345-418)
+###############################################################################
+
+
+def capture_chunks(out):
+    plans = {
+        'gapfree_b500': (synth.word_frames(21, 2600), 500),
+        'gapfree_b1000': (synth.word_frames(21, 2600), 1000),
+        'gapfree_none': (synth.word_frames(21, 2600), None),
+        'gapfree_b64': (synth.word_frames(22, 700, 2, 40), 64),
+        'floor_b300': (np.array([
+            [0, 57, 203, 411, 803, 811, 819, 1000, 1206, 1606, 1613, 1615,
+             1622, 1631],
+            [57, 203, 411, 803, 811, 819, 1000, 1206, 1606, 1613, 1615, 1622,
+             1631, 1700]]), 300),
+        # a 2-frame chunk: shorter than the reflect pad -> dropped
+        'short_chunk_b10': (np.array(
+            [[0, 40, 42, 90], [40, 42, 90, 130]]), 10),
+        'dropped_chunk_b0': (np.array(
+            [[0, 40, 42, 90], [40, 42, 90, 130]]), 0),
+    }
+    for name, (bounds, batch_size) in plans.items():
+        frames = int(bounds[1, -1])
+        audio = torch.from_numpy(synth.audio(1, frames))
+        alignment = make_alignment(seconds(bounds))
+        produced = [
+            (features.shape[-1], word_bounds[0].numpy())
+            for features, word_bounds in emphases.preprocess(
+                alignment, audio, 16000, batch_size, None)]
+        out[f'{name}/bounds_frames'] = bounds.astype(np.int32)
+        out[f'{name}/batch_size'] = np.int64(
+            -1 if batch_size is None else batch_size)
+        out[f'{name}/chunk_frames'] = np.array(
+            [p[0] for p in produced], dtype=np.int32)
+        out[f'{name}/chunk_words'] = np.array(
+            [p[1].shape[-1] for p in produced], dtype=np.int32)
+        out[f'{name}/chunk_bounds'] = np.concatenate(
+            [p[1] for p in produced], axis=1).astype(np.int32)
+        print(f'chunks {name:18s}', [
+            (p[0], p[1].shape[-1]) for p in produced])
+
+
+###############################################################################
+# Variant matrix with seeded weights
+###############################################################################
+
+
+ACTIVATIONS = {
+    'relu': torch.nn.ReLU, 'gelu': torch.nn.GELU, 'silu': torch.nn.SiLU,
+    'leaky_relu': torch.nn.LeakyReLU}
+
+
+def variant_list():
+    variants = []
+    for location in acfg.DOWNSAMPLE_LOCATIONS:
+        for method in acfg.DOWNSAMPLE_METHODS:
+            variants.append(dict(
+                downsample_location=location, downsample_method=method))
+    variants += [dict(activation=a) for a in ('gelu', 'silu', 'leaky_relu')]
+    variants += [dict(encoder_kernel_size=k) for k in (5, 7)]
+    variants += [dict(decoder_kernel_size=k) for k in (1, 5)]
+    variants += [dict(channels=c) for c in (64, 128)]
+    variants += [dict(layers=n) for n in (5, 7)]
+    variants += [dict(loss='mse'), dict(normalize=True),
+                 dict(loudness_feature=True),
+                 dict(loudness_feature=True, normalize=True)]
+    variants += [dict(architecture='transformer'),
+                 dict(architecture='transformer',
+                      downsample_location='inference',
+                      downsample_method='average')]
+    return variants
+
+
+def variant_name(overrides):
+    return ','.join(f'{k}={v}' for k, v in sorted(overrides.items())) or \
+        'default'
+
+
+def configure_reference(config):
+    emphases.ARCHITECTURE = config.architecture
+    emphases.ACTIVATION_FUNCTION = ACTIVATIONS[config.activation]
+    emphases.CHANNELS = config.channels
+    emphases.LAYERS = config.layers
+    emphases.ENCODER_KERNEL_SIZE = config.encoder_kernel_size
+    emphases.DECODER_KERNEL_SIZE = config.decoder_kernel_size
+    emphases.DOWNSAMPLE_LOCATION = config.downsample_location
+    emphases.DOWNSAMPLE_METHOD = config.downsample_method
+    emphases.LOSS = config.loss
+    emphases.NORMALIZE = config.normalize
+    emphases.LOUDNESS_FEATURE = config.loudness_feature
+    emphases.NUM_FEATURES = config.num_features
+
+
+def capture_variants(out):
+    frames = 300
+    audio = synth.audio(4, frames)
+    bounds = synth.word_frames(4, frames, 3, 40)
+    audio_t = torch.from_numpy(audio)
+    alignment = make_alignment(seconds(bounds))
+    out['audio_pcm'] = np.rint(audio[0] * 32768.0).astype(np.int16)
+    out['bounds_frames'] = bounds.astype(np.int32)
+    names = []
+    for overrides in variant_list():
+        config = acfg.Config(**overrides)
+        name = variant_name(overrides)
+        configure_reference(config)
+        state = weights.random_state(config, seed=7)
+        model = reference_model(state)
+        expected = {
+            k: tuple(v.shape) for k, v in model.state_dict().items()
+            if 'position.encoding' not in k}
+        assert expected == {
+            k: tuple(v) for k, v in
+            weights.parameter_shapes(config).items()}, name
+        stages = run_fp32(model, alignment, audio_t)
+        assert len(stages) == 1
+        out[f'{name}/logits'] = stages[0]['logits']
+        out[f'{name}/scores'] = stages[0]['scores']
+        if config.loudness_feature:
+            out[f'{name}/features'] = stages[0]['features']
+        cfg_dict = {k: getattr(config, k) for k in overrides}
+        if config.architecture == 'transformer' and \
+                config.downsample_location == 'input':
+            delta = float('nan')
+        else:
+            mine = oracle.forward(
+                torch.from_numpy(stages[0]['features']), stages[0]['bounds'],
+                {k: torch.from_numpy(v) for k, v in state.items()},
+                dict(cfg_dict)).numpy()
+            delta = float(np.abs(mine - stages[0]['logits']).max())
+            scale = float(np.abs(stages[0]['logits']).max())
+            assert delta < 5e-5 + 2e-6 * scale, (name, delta, scale)
+        names.append(name)
+        print(f'variant {name:60s} |oracle-ref|logit={delta:.2e} '
+              f'range=[{stages[0]["logits"].min():.3f}, '
+              f'{stages[0]["logits"].max():.3f}]')
+    configure_reference(acfg.DEFAULT)
+    out['names'] = np.array(names)
+
+
+###############################################################################
+# Entry point
+###############################################################################
+
+
+def main():
+    default, chunk_plans, variants = {}, {}, {}
+    state = capture_default(default)
+    capture_chunks(chunk_plans)
+    capture_variants(variants)
+
+    flat = np.concatenate([v.ravel() for v in state.values()])
+    digest = hashlib.sha256(flat.astype('<f4').tobytes()).hexdigest()
+    print('weights sha256', digest)
+    assert digest == \
+        'be2fb6555ba5fab57a4abb3c4e55a6cefc9dbd03c3ccbdcc2c735784aa277e69'
+    os.makedirs(os.path.join(ROOT, 'emphases_amd', 'assets'), exist_ok=True)
+    np.savez(
+        os.path.join(ROOT, 'emphases_amd', 'assets', 'checkpoint.npz'),
+        **state)
+    np.savez_compressed(os.path.join(HERE, 'cases.npz'), **default)
+    np.savez_compressed(os.path.join(HERE, 'chunks.npz'), **chunk_plans)
+    np.savez_compressed(os.path.join(HERE, 'variants.npz'), **variants)
+    leaked = [
+        root for root, dirs, _ in os.walk(REFERENCE) if '__pycache__' in dirs]
+    assert not leaked, leaked
+
+
+if __name__ == '__main__':
+    main()
