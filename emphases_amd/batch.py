@@ -1,0 +1,189 @@
+"""Ragged batch planning: utterances -> word-boundary chunks -> packed layout.
+
+`chunk_utterance` is the host arithmetic of the reference's `preprocess`
+generator (`emphases/core.py:345-418`): greedy accumulation of words up to
+`batch_size` frames in float64 with floor division (`convert.py:19-31`), chunk
+audio cut at frame-quantised word times out of the 432-zero-padded signal, and
+chunk-relative word bounds.  Chunks that the reference silently drops (its
+feature extraction raises inside `except RuntimeError: pass`, `core.py:403-415`,
+when the chunk is no longer than the 432-sample reflect pad) are dropped here by
+an explicit length test.
+
+`Plan` lays a list of chunks ("segments") out for the HIP kernels: every
+segment gets its own column range on a packed frame axis and a packed word
+axis (offsets aligned to 16 columns so MFMA tiles and 16-byte loads line up),
+and all integer metadata is packed into ONE buffer so that a batch costs a
+single small host-to-device copy.
+"""
+import dataclasses
+
+import numpy as np
+
+from . import config as cfg
+from . import convert
+from . import runtime
+
+ALIGN = 16     # column alignment of every segment on the packed axes
+LEAD = 16      # unused columns before the first segment (halo reads stay inside)
+TAIL = 64      # unused columns after the last segment
+
+
+@dataclasses.dataclass
+class Segment:
+    """One independently processed chunk of one utterance."""
+    utterance: int          # index of the utterance in the batch
+    start_word: int         # first word (index into the utterance's alignment)
+    end_word: int           # one past the last word
+    start_sample: int       # chunk start in the 432-zero-padded signal
+    length: int             # chunk length in samples
+    frames: int
+    bounds: np.ndarray      # int64 [2, words], chunk-relative frames
+
+
+def _word_times(alignment):
+    return [(word.start(), word.end()) for word in
+            (alignment[i] for i in range(len(alignment)))]
+
+
+def chunk_utterance(alignment, num_samples, batch_size=None, utterance=0):
+    """Chunk plan of one utterance; `alignment` follows the pypar protocol."""
+    times = alignment if isinstance(alignment, list) else \
+        _word_times(alignment)
+    padded = num_samples + 2 * cfg.PADDING
+    total_frames = int(padded / cfg.HOPSIZE)                     # core.py:359
+    limit = total_frames if batch_size is None else batch_size
+    segments = []
+    start = 0
+    count = len(times)
+    while start < count:
+        frames = 0.
+        end = start + 1
+        while end < count:
+            frames += convert.seconds_to_frames(
+                times[end - 1][1] - times[end - 1][0])           # core.py:373
+            if int(frames) > limit:
+                break
+            end += 1
+        first, last = times[start], times[end - 1]
+        origin = int(first[0] * cfg.SAMPLE_RATE / cfg.HOPSIZE)
+        bounds = np.array(
+            [[int(s * cfg.SAMPLE_RATE / cfg.HOPSIZE) - origin
+              for s, _ in times[start:end]],
+             [int(e * cfg.SAMPLE_RATE / cfg.HOPSIZE) - origin
+              for _, e in times[start:end]]], dtype=np.int64)
+        start_sample = int(convert.frames_to_samples(
+            int(convert.seconds_to_frames(first[0]))))           # core.py:395
+        end_sample = int(convert.frames_to_samples(
+            int(convert.seconds_to_frames(last[1]))))            # core.py:398
+        start_sample = max(0, min(start_sample, padded))
+        end_sample = max(0, min(end_sample, padded))   # slice clamps
+        length = max(0, end_sample - start_sample)
+        # reflect padding needs more than PADDING samples (mels.py:31-36)
+        if length > cfg.PADDING:
+            segments.append(Segment(
+                utterance, start, end, start_sample, length,
+                1 + (length + 2 * cfg.PADDING - cfg.NUM_FFT) // cfg.HOPSIZE,
+                bounds))
+        start = end
+    return segments
+
+
+def _round_up(value, multiple):
+    return (value + multiple - 1) // multiple * multiple
+
+
+def _tiles(counts, block):
+    """(segment, first position) of every `block`-wide tile, int32 [n, 2]."""
+    per_segment = (np.asarray(counts, dtype=np.int64) + block - 1) // block
+    total = int(per_segment.sum())
+    segment = np.repeat(np.arange(len(counts), dtype=np.int64), per_segment)
+    first = np.arange(total, dtype=np.int64) - np.repeat(
+        np.cumsum(per_segment) - per_segment, per_segment)
+    return np.stack([segment, first * block], axis=1).astype(np.int32)
+
+
+class Plan:
+    """Packed layout of a batch of segments."""
+
+    def __init__(self, segments, audio_offsets, audio_lengths):
+        """`audio_offsets[u]`, `audio_lengths[u]`: where utterance `u` sits in
+        the packed audio buffer."""
+        self.segments = segments
+        count = len(segments)
+        frames = np.array([s.frames for s in segments], dtype=np.int64)
+        words = np.array([s.bounds.shape[1] for s in segments], dtype=np.int64)
+        frame_off = LEAD + np.concatenate(
+            [[0], np.cumsum(_round_up(frames, ALIGN))[:-1]]) \
+            if count else np.zeros(0, dtype=np.int64)
+        word_off = LEAD + np.concatenate(
+            [[0], np.cumsum(_round_up(words, ALIGN))[:-1]]) \
+            if count else np.zeros(0, dtype=np.int64)
+        self.frames = frames
+        self.words = words
+        self.frame_off = frame_off.astype(np.int64)
+        self.word_off = word_off.astype(np.int64)
+        self.ld_frames = int(
+            LEAD + _round_up(frames, ALIGN).sum() + TAIL) if count else TAIL
+        self.ld_words = int(
+            LEAD + _round_up(words, ALIGN).sum() + TAIL) if count else TAIL
+        self.total_frames = int(frames.sum())
+        self.total_words = int(words.sum())
+
+        table = np.zeros((count, runtime.SEG_FIELDS), dtype=np.int64)
+        for i, segment in enumerate(segments):
+            table[i, runtime.SEG_AUDIO_OFF] = audio_offsets[segment.utterance]
+            table[i, runtime.SEG_AUDIO_LEN] = audio_lengths[segment.utterance]
+            table[i, runtime.SEG_START] = segment.start_sample
+            table[i, runtime.SEG_LENGTH] = segment.length
+        table[:, runtime.SEG_FRAME_OFF] = self.frame_off
+        table[:, runtime.SEG_FRAMES] = frames
+        table[:, runtime.SEG_WORD_OFF] = self.word_off
+        table[:, runtime.SEG_WORDS] = words
+        self.table = table
+
+        bounds = np.zeros((2, self.ld_words), dtype=np.int32)
+        word_segment = np.full(self.ld_words, -1, dtype=np.int32)
+        for i, segment in enumerate(segments):
+            lo = int(self.word_off[i])
+            hi = lo + int(words[i])
+            bounds[:, lo:hi] = segment.bounds
+            word_segment[lo:hi] = i
+        self.bounds = bounds
+        self.word_segment = word_segment
+        self._tiles = {}
+
+    def tiles(self, axis, block):
+        key = (axis, block)
+        if key not in self._tiles:
+            counts = self.frames if axis == runtime.AXIS_FRAMES else self.words
+            self._tiles[key] = _tiles(counts, block)
+        return self._tiles[key]
+
+    def word_columns(self):
+        """Packed word-axis column of every word, in segment order."""
+        if not len(self.segments):
+            return np.zeros(0, dtype=np.int64)
+        return np.concatenate([
+            np.arange(off, off + n) for off, n in
+            zip(self.word_off, self.words)])
+
+    def pack_metadata(self, tile_requests):
+        """All integer metadata as one int32 array plus the element offset of
+        every piece (the int64 table first, so it stays 8-byte aligned)."""
+        pieces = [('table', self.table.view(np.int32).ravel()),
+                  ('bounds', self.bounds.ravel()),
+                  ('word_segment', self.word_segment)]
+        for axis, block in tile_requests:
+            pieces.append(
+                (('tiles', axis, block), self.tiles(axis, block).ravel()))
+        offsets = {}
+        cursor = 0
+        chunks = []
+        for name, array in pieces:
+            offsets[name] = (cursor, array.size)
+            padded = _round_up(max(array.size, 1), 4)
+            chunk = np.zeros(padded, dtype=np.int32)
+            chunk[:array.size] = array
+            chunks.append(chunk)
+            cursor += padded
+        return np.concatenate(chunks), offsets

@@ -1,0 +1,332 @@
+"""Drop-in API surface of the prominence-inference path.
+
+Same names, argument meaning and error behaviour as the reference's
+`emphases/core.py` (signatures at `core.py:23-29, 76-83, 115-122, 182-189,
+223-230`; step functions `preprocess` 345-418, `infer` 295-332, `postprocess`
+335-342, `downsample` 426-469), with the hot path executed by the HIP library
+instead of ATen.  Deliberate, documented deviations:
+
+* scores are float32 (the reference returns bf16/fp16 because it runs under
+  `torch.autocast`, `core.py:594-607`);
+* `checkpoint=None` loads the bundled copy of the reference's trained weights
+  instead of downloading from HuggingFace (`core.py:307-310`);
+* there is no CPU execution path: `gpu=None` means "the current HIP device"
+  and the result is returned on the CPU (as the reference would for
+  `gpu=None`); with no device visible the call raises;
+* `from_alignments_and_audios` is an addition: many utterances in one ragged
+  batch (the reference loops one file at a time, `core.py:169-179`).
+"""
+import contextlib
+import functools
+import os
+
+import numpy as np
+import torch
+
+from . import alignment as alignment_module
+from . import batch
+from . import config as cfg
+from . import engine as engine_module
+from . import load
+from . import runtime
+
+_ACTIVE = [cfg.DEFAULT]
+
+
+def configure(config=None, **overrides):
+    """Select the active configuration (the reference mutates module globals
+    through `yapecs --config file.py`; see `emphases/__init__.py:7-15`)."""
+    if config is None:
+        config = cfg.Config(**overrides)
+    _ACTIVE[0] = config
+    return config
+
+
+def active_config():
+    return _ACTIVE[0]
+
+
+@functools.lru_cache(maxsize=8)
+def _engine(checkpoint, device_index, config):
+    return engine_module.Engine(config, checkpoint, device_index)
+
+
+def get_engine(checkpoint=None, gpu=None, config=None):
+    """Cached `Engine` per (checkpoint, device, config) — the explicit form of
+    the reference's function-attribute cache (`core.py:298-315`)."""
+    device = runtime.require_gpu(gpu)
+    index = device.index if device.index is not None else \
+        torch.cuda.current_device()
+    checkpoint = None if checkpoint is None else os.fspath(checkpoint)
+    return _engine(checkpoint, index, config or active_config())
+
+
+###############################################################################
+# Emphasis annotation API
+###############################################################################
+
+
+def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
+                               checkpoint=None, batch_size=None, gpu=None,
+                               config=None):
+    """Scores for many utterances in one ragged batch.
+
+    Returns a list of float32 tensors [1, W_i] (CPU if `gpu is None`)."""
+    engine = get_engine(checkpoint, gpu, config)
+    device = engine.device
+    audios = [resample(audio, sample_rate)[:1].reshape(-1) for audio in audios]
+    lengths = [int(audio.shape[0]) for audio in audios]
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64) \
+        if lengths else np.zeros(0, dtype=np.int64)
+    segments = []
+    for index, (item, length) in enumerate(zip(alignments, lengths)):
+        segments.extend(
+            batch.chunk_utterance(item, length, batch_size, index))
+    results = [torch.zeros((1, 0)) for _ in audios]
+    if segments:
+        plan = batch.Plan(segments, offsets, lengths)
+        packed = torch.cat([
+            audio.to(torch.float32) for audio in audios]).contiguous()
+        packed = packed.to(device, non_blocking=True)
+        with torch.cuda.device(device):
+            scores, _ = engine.forward(packed, plan)
+        scores = scores if gpu is not None else scores.cpu()
+        pieces = [[] for _ in audios]
+        for segment, off, count in zip(
+                plan.segments, plan.word_off, plan.words):
+            pieces[segment.utterance].append(scores[off:off + count])
+        results = [
+            torch.cat(piece)[None] if piece else result
+            for piece, result in zip(pieces, results)]
+    return results
+
+
+def from_alignment_and_audio(alignment, audio, sample_rate, checkpoint=None,
+                             batch_size=None, gpu=None):
+    """Produce emphasis scores for each word (`core.py:223-265`).
+
+    alignment: object with `len()`, `[i]` -> word with `.start()/.end()/
+        .duration()` in seconds (the subset of `pypar.Alignment` the reference
+        uses, `core.py:366-400`)
+    audio: float tensor [1, S] (only channel 0 is featurised, `mels.py:48`)
+    sample_rate, checkpoint, batch_size (max frames per chunk), gpu: as in
+        the reference.
+    Returns float32 scores [1, W]; words of chunks the reference drops
+    (`core.py:414-415`) have no score, as there."""
+    return from_alignments_and_audios(
+        [alignment], [audio], sample_rate, checkpoint, batch_size, gpu)[0]
+
+
+def from_text_and_audio(text, audio, sample_rate, checkpoint=None,
+                        batch_size=None, gpu=None):
+    """`core.py:182-220` force-aligns the transcript with `pyfoal` (P2FA /
+    HTK subprocesses, third-party) before inference; forced alignment is
+    outside the accelerated path."""
+    raise NotImplementedError(
+        'forced alignment (pyfoal/P2FA) is not part of the HIP hot path; '
+        'align the transcript first and call from_alignment_and_audio')
+
+
+def from_file(text_file, audio_file, checkpoint=None, batch_size=None,
+              gpu=None):
+    """`core.py:23-73`: scores for an alignment file (.TextGrid / .json) and
+    an audio file."""
+    if not str(text_file).endswith(('.TextGrid', '.json')):
+        with open(text_file, encoding='utf-8') as file:
+            return from_text_and_audio(
+                file.read(), load.audio(audio_file), cfg.SAMPLE_RATE,
+                checkpoint, batch_size, gpu)
+    return from_alignment_and_audio(
+        alignment_module.Alignment(text_file), load.audio(audio_file),
+        cfg.SAMPLE_RATE, checkpoint, batch_size, gpu)
+
+
+def _save(alignment, scores, output_prefix):
+    """`core.py:111-112`: the alignment as .TextGrid, the scores as .pt"""
+    alignment.save(f'{output_prefix}.TextGrid')
+    torch.save(scores.cpu(), f'{output_prefix}.pt')
+
+
+def from_file_to_file(text_file, audio_file, output_prefix=None,
+                      checkpoint=None, batch_size=None, gpu=None):
+    """`core.py:76-112`"""
+    from pathlib import Path
+    if output_prefix is None:
+        output_prefix = Path(text_file).stem
+    scores = from_file(text_file, audio_file, checkpoint, batch_size, gpu)
+    _save(alignment_module.Alignment(text_file), scores, output_prefix)
+
+
+def from_files_to_files(text_files, audio_files, output_prefixes=None,
+                        checkpoint=None, batch_size=None, gpu=None,
+                        utterances_per_batch=64):
+    """`core.py:115-179`, but the files are processed in ragged batches of
+    `utterances_per_batch` instead of one at a time."""
+    from pathlib import Path
+    text_files, audio_files = list(text_files), list(audio_files)
+    if output_prefixes is None:
+        output_prefixes = [Path(file).stem for file in text_files]
+    for file in text_files:
+        if not str(file).endswith(('.TextGrid', '.json')):
+            from_text_and_audio(None, None, None)
+    for first in range(0, len(text_files), utterances_per_batch):
+        last = first + utterances_per_batch
+        alignments = [
+            alignment_module.Alignment(file)
+            for file in text_files[first:last]]
+        audios = [load.audio(file) for file in audio_files[first:last]]
+        results = from_alignments_and_audios(
+            alignments, audios, cfg.SAMPLE_RATE, checkpoint, batch_size, gpu)
+        for item, scores, prefix in zip(
+                alignments, results, output_prefixes[first:last]):
+            _save(item, scores, prefix)
+
+
+###############################################################################
+# Inference steps
+###############################################################################
+
+
+def preprocess(alignment, audio, sample_rate=cfg.SAMPLE_RATE, batch_size=None,
+               gpu=None):
+    """Convert audio to model input (`core.py:345-418`): yields
+    `(features [1, NUM_FEATURES, Fc] on the device, word_bounds int64
+    [1, 2, Wc] on the CPU)` per chunk."""
+    engine = get_engine(None, gpu)
+    audio = resample(audio, sample_rate)[:1].reshape(-1).to(torch.float32)
+    segments = batch.chunk_utterance(alignment, int(audio.shape[0]), batch_size)
+    if not segments:
+        return
+    plan = batch.Plan(segments, [0], [int(audio.shape[0])])
+    with torch.cuda.device(engine.device):
+        meta = engine.upload(plan)
+        features = engine.features(
+            audio.to(engine.device).contiguous(), plan, meta)
+    for segment, off, count in zip(segments, plan.frame_off, plan.frames):
+        yield (features[None, :, off:off + count],
+               torch.from_numpy(segment.bounds)[None])
+
+
+def infer(features, word_bounds, checkpoint=None):
+    """Model inference on one chunk (`core.py:295-332`): features
+    [1, C_in, F] on the device, word_bounds [1, 2, W] -> logits [1, 1, W]."""
+    model = Model(checkpoint=checkpoint, gpu=features.device.index)
+    frame_lengths = torch.tensor([features.shape[-1]])
+    word_lengths = torch.tensor([word_bounds.shape[-1]])
+    return model(features, frame_lengths, word_bounds, word_lengths)
+
+
+def postprocess(logits, config=None):
+    """`core.py:335-342`"""
+    config = config or active_config()
+    if config.loss == 'bce':
+        return torch.sigmoid(logits)
+    return torch.clamp(logits, 0., 1.)
+
+
+def _packed_plan(frame_lengths, word_bounds, word_lengths):
+    """Plan for already-featurised, padded `[B, C, T]` inputs."""
+    segments = []
+    for index, (frames, words) in enumerate(zip(frame_lengths, word_lengths)):
+        bounds = np.asarray(
+            word_bounds[index].cpu(), dtype=np.int64)[:, :int(words)]
+        segments.append(batch.Segment(
+            index, 0, int(words), 0, 0, int(frames), bounds))
+    return batch.Plan(
+        segments, [0] * len(segments), [0] * len(segments))
+
+
+def _pack(xs, plan, axis_offsets, counts, ld, device):
+    packed = torch.zeros(
+        (xs.shape[1], ld), dtype=torch.float32, device=device)
+    for index, (off, count) in enumerate(zip(axis_offsets, counts)):
+        packed[:, off:off + count] = xs[index, :, :count]
+    return packed
+
+
+def downsample(xs, word_bounds, word_lengths, config=None):
+    """Interpolate from frame to word resolution (`core.py:426-469`):
+    xs [B, C, T], word_bounds [B, 2, W], word_lengths [B] -> [B, C, Wmax]."""
+    config = config or active_config()
+    device = runtime.require_gpu(xs.device if xs.is_cuda else None)
+    lib = runtime.library()
+    lengths = [int(n) for n in word_lengths]
+    plan = _packed_plan([xs.shape[2]] * xs.shape[0], word_bounds, lengths)
+    engine_module.check_bounds(plan, config.downsample_method)
+    with torch.cuda.device(device):
+        host, offsets = plan.pack_metadata([])
+        meta = torch.from_numpy(host).to(device)
+        view = lambda name: meta[  # noqa: E731
+            offsets[name][0]:offsets[name][0] + offsets[name][1]]
+        packed = _pack(
+            xs.to(device, torch.float32), plan, plan.frame_off, plan.frames,
+            plan.ld_frames, device)
+        out = torch.zeros(
+            (xs.shape[1], plan.ld_words), dtype=torch.float32, device=device)
+        runtime.check(lib.emph_segment_reduce(
+            packed.data_ptr(), plan.ld_frames, view('bounds').data_ptr(),
+            out.data_ptr(), plan.ld_words, xs.shape[1],
+            view('table').data_ptr(), view('word_segment').data_ptr(),
+            plan.ld_words, runtime.REDUCTIONS[config.downsample_method],
+            runtime.stream()), 'emph_segment_reduce')
+    result = torch.zeros(
+        (xs.shape[0], xs.shape[1], max(lengths) if lengths else 0),
+        dtype=torch.float32, device=device)
+    for index, (off, count) in enumerate(zip(plan.word_off, plan.words)):
+        result[index, :, :count] = out[:, off:off + count]
+    return result if xs.is_cuda else result.cpu()
+
+
+class Model:
+    """Callable with the reference's `Model.forward` signature
+    (`emphases/model/core.py:39`): `(features [B, C_in, T], frame_lengths [B],
+    word_bounds [B, 2, W], word_lengths [B]) -> logits [B, 1, Wmax]`.
+
+    Every batch item is computed with its own zero halo (B=1 semantics); the
+    reference's padded-batch conv leaks padding into shorter items
+    (`convolution.py:35-37`), which is not reproduced."""
+
+    def __init__(self, checkpoint=None, gpu=None, config=None):
+        self.config = config or active_config()
+        self.engine = get_engine(checkpoint, gpu, self.config)
+
+    def __call__(self, features, frame_lengths, word_bounds, word_lengths):
+        return self.forward(features, frame_lengths, word_bounds, word_lengths)
+
+    def forward(self, features, frame_lengths, word_bounds, word_lengths):
+        engine = self.engine
+        device = engine.device
+        plan = _packed_plan(
+            [int(n) for n in frame_lengths], word_bounds,
+            [int(n) for n in word_lengths])
+        with torch.cuda.device(device):
+            packed = _pack(
+                features.to(device, torch.float32), plan, plan.frame_off,
+                plan.frames, plan.ld_frames, device)
+            _, logits = engine.forward(None, plan, features=packed)
+        width = int(max(int(n) for n in word_lengths))
+        result = torch.zeros(
+            (features.shape[0], 1, width), dtype=torch.float32, device=device)
+        for index, (off, count) in enumerate(zip(plan.word_off, plan.words)):
+            result[index, 0, :count] = logits[off:off + count]
+        return result if features.is_cuda else result.cpu()
+
+
+###############################################################################
+# Utilities
+###############################################################################
+
+
+@contextlib.contextmanager
+def inference_context(model=None):
+    """`core.py:594-610` sets eval mode, no_grad and autocast; the HIP path is
+    inference-only and float32, so only no_grad remains."""
+    with torch.no_grad():
+        yield
+
+
+def resample(audio, sample_rate, target_rate=cfg.SAMPLE_RATE):
+    """`core.py:613-619` (torchaudio sinc resampler, third-party)."""
+    if sample_rate == target_rate:
+        return audio
+    return load.resample(audio, sample_rate, target_rate)

@@ -1,0 +1,66 @@
+// Shared helpers of libemphases_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/emphases_hip.h"
+
+namespace emph {
+
+constexpr int kWave = 64;          // CDNA wavefront width
+constexpr int kHop = 160;          // emphases/config/defaults.py:53
+constexpr int kFft = 1024;         // defaults.py:59
+constexpr int kBins = 513;
+constexpr int kMels = 80;          // defaults.py:62
+constexpr int kPad = 432;          // (1024 - 160) / 2, core.py:357, mels.py:31
+
+void set_error(const char* format, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t status = hipGetLastError();
+    if (status != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(status));
+        return static_cast<int>(status);
+    }
+    return EMPH_OK;
+}
+
+#define EMPH_REQUIRE(cond, code, ...)            \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::emph::set_error(__VA_ARGS__);      \
+            return (code);                       \
+        }                                        \
+    } while (0)
+
+// Per-axis view of one row of the segment table.
+struct Span {
+    int64_t offset;   // first column on the packed axis
+    int32_t count;    // valid positions
+};
+
+__device__ __forceinline__ Span load_span(const int64_t* seg, int segment,
+                                          int axis) {
+    const int64_t* row = seg + static_cast<int64_t>(segment) * EMPH_SEG_FIELDS;
+    Span span;
+    if (axis == EMPH_AXIS_FRAMES) {
+        span.offset = row[EMPH_SEG_FRAME_OFF];
+        span.count = static_cast<int32_t>(row[EMPH_SEG_FRAMES]);
+    } else {
+        span.offset = row[EMPH_SEG_WORD_OFF];
+        span.count = static_cast<int32_t>(row[EMPH_SEG_WORDS]);
+    }
+    return span;
+}
+
+// LDS traffic between lanes of ONE wave: DS operations of a wave execute in
+// program order, so only the compiler has to be kept from reordering.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+}  // namespace emph

@@ -1,0 +1,450 @@
+// Front-end of the prominence path: framed log-mel (and the optional
+// A-weighted loudness row) straight from packed utterance audio.
+//
+// Replaces, per chunk (paths relative to the reference repository):
+//   F.pad(audio, (432, 432)) + word-boundary slice    emphases/core.py:357-401
+//   reflect pad 432                                   data/preprocess/mels.py:31-36
+//   torch.stft(1024, hop 160, periodic Hann)          mels.py:39-48
+//   sqrt(re^2 + im^2 + 1e-6)                          mels.py:51
+//   mel basis matmul, log(clamp(., 1e-5))             mels.py:94-109
+//   librosa loudness (always on CPU in the reference) data/preprocess/loudness.py:59-107
+//
+// Design (gfx950): one 256-thread workgroup owns a block of 32 frames of one
+// chunk.  The 5984 contiguous samples those frames cover are staged ONCE into
+// LDS with the zero-pad / slice / reflect index arithmetic applied per sample,
+// so HBM sees each audio sample about once (adjacent blocks share 864).  Each
+// wave then transforms one frame at a time: a 1024-point real FFT as a
+// 512-point complex FFT held 8 points per lane — three radix-8 passes in
+// registers with two wave-private LDS transposes — followed by the real-FFT
+// split, magnitudes, the 1001-non-zero sparse mel projection and the log.
+// The [80 x 32] result tile is staged in LDS and written as 128-byte row
+// segments.  Nothing of the 513 x F complex spectrogram ever reaches HBM.
+#include <math.h>
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace emph {
+
+namespace {
+thread_local char g_error[512] = "";
+}
+
+void set_error(const char* format, ...) {
+    va_list args;
+    va_start(args, format);
+    vsnprintf(g_error, sizeof(g_error), format, args);
+    va_end(args);
+}
+
+constexpr int kBlockFrames = 32;                               // frames per workgroup
+constexpr int kStage = kHop * (kBlockFrames - 1) + kFft;       // 5984 samples
+constexpr int kExRow = 72;                                     // complex per exchange row
+constexpr int kExFloats = 2 * 8 * kExRow;                      // 1152 floats per wave
+constexpr int kOutStride = kBlockFrames + 1;
+
+// Table layout (floats)
+constexpr int kTabWindow = 0;                  // [1024]
+constexpr int kTabTw1 = 1024;                  // [8][64] complex  W512^(p r)
+constexpr int kTabTw2 = kTabTw1 + 2 * 512;     // [8][8] complex   W64^(p0 t)
+constexpr int kTabTw3 = kTabTw2 + 2 * 64;      // [513] complex    W1024^k
+constexpr int kTabSize = kTabTw3 + 2 * 514;
+
+struct cf {
+    float x, y;
+};
+
+__device__ __forceinline__ cf cmul(cf a, cf b) {
+    return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
+// multiply by -i
+__device__ __forceinline__ cf mul_neg_i(cf a) { return {a.y, -a.x}; }
+
+// In-place forward DFT of 8 points, natural order in and out:
+// v[r] <- sum_q v[q] exp(-2 pi i q r / 8)
+__device__ __forceinline__ void dft8(cf v[8]) {
+    constexpr float kH = 0.70710678118654752440f;
+    cf a0 = cadd(v[0], v[4]), b0 = csub(v[0], v[4]);
+    cf a1 = cadd(v[1], v[5]), b1 = csub(v[1], v[5]);
+    cf a2 = cadd(v[2], v[6]), b2 = csub(v[2], v[6]);
+    cf a3 = cadd(v[3], v[7]), b3 = csub(v[3], v[7]);
+    // b_j *= W8^j
+    b1 = {kH * (b1.x + b1.y), kH * (b1.y - b1.x)};
+    b2 = mul_neg_i(b2);
+    b3 = {kH * (b3.y - b3.x), -kH * (b3.x + b3.y)};
+    // DFT-4 of a -> even outputs
+    cf e0 = cadd(a0, a2), e1 = csub(a0, a2);
+    cf o0 = cadd(a1, a3), o1 = mul_neg_i(csub(a1, a3));
+    v[0] = cadd(e0, o0);
+    v[2] = cadd(e1, o1);
+    v[4] = csub(e0, o0);
+    v[6] = csub(e1, o1);
+    // DFT-4 of b -> odd outputs
+    e0 = cadd(b0, b2);
+    e1 = csub(b0, b2);
+    o0 = cadd(b1, b3);
+    o1 = mul_neg_i(csub(b1, b3));
+    v[1] = cadd(e0, o0);
+    v[3] = cadd(e1, o1);
+    v[5] = csub(e0, o0);
+    v[7] = csub(e1, o1);
+}
+
+__device__ __forceinline__ float wave_max(float value) {
+#pragma unroll
+    for (int offset = 32; offset > 0; offset >>= 1)
+        value = fmaxf(value, __shfl_xor(value, offset));
+    return value;
+}
+
+// MODE 0: mel rows.  MODE 1: per-chunk peak power only.  MODE 2: mel rows and
+// loudness row.  MODE 3: loudness row only.
+template <int MODE>
+__global__ __launch_bounds__(256) void frontend_kernel(
+    const float* __restrict__ audio, const int64_t* __restrict__ seg,
+    const int32_t* __restrict__ tiles, const float* __restrict__ table,
+    const int32_t* __restrict__ mel_start, const int32_t* __restrict__ mel_count,
+    const int32_t* __restrict__ mel_offset, const float* __restrict__ mel_values,
+    int mel_nnz, float* __restrict__ out, int64_t ld, int mel_row, int loud_row,
+    float* __restrict__ seg_peak, const float* __restrict__ a_weights,
+    int normalize) {
+    constexpr bool kMel = MODE == 0 || MODE == 2;
+    constexpr bool kLoud = MODE == 2 || MODE == 3;
+    constexpr bool kPeak = MODE == 1;
+
+    extern __shared__ __align__(16) float lds[];
+    float* stage = lds;                                  // [kStage]
+    float* exchange = stage + kStage;                    // [4][kExFloats]
+    float* tile = exchange + 4 * kExFloats;              // [80][kOutStride]
+    float* loud_tile = tile + kMels * kOutStride;        // [kBlockFrames]
+    float* basis = loud_tile + kBlockFrames;             // [mel_nnz]
+    float* weights = basis + (kMel ? ((mel_nnz + 3) & ~3) : 0);  // [513+]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    const int segment = tiles[2 * blockIdx.x];
+    const int frame0 = tiles[2 * blockIdx.x + 1];
+    const int64_t* row = seg + static_cast<int64_t>(segment) * EMPH_SEG_FIELDS;
+    const int64_t audio_off = row[EMPH_SEG_AUDIO_OFF];
+    const int64_t audio_len = row[EMPH_SEG_AUDIO_LEN];
+    const int64_t start = row[EMPH_SEG_START];
+    const int64_t length = row[EMPH_SEG_LENGTH];
+    const int64_t frame_off = row[EMPH_SEG_FRAME_OFF];
+    const int frames = static_cast<int>(row[EMPH_SEG_FRAMES]);
+
+    // ---- stage the block's samples: zero pad + slice + reflect in one pass
+    const int64_t first = static_cast<int64_t>(frame0) * kHop - kPad;
+    for (int index = tid; index < kStage; index += 256) {
+        int64_t r = first + index;             // position in the chunk
+        if (r < 0) r = -r;                     // reflect (no edge repeat)
+        if (r >= length) r = 2 * (length - 1) - r;
+        float value = 0.f;
+        if (r >= 0 && r < length) {
+            const int64_t a = start + r - kPad;   // undo the 432 zero pad
+            if (a >= 0 && a < audio_len) value = audio[audio_off + a];
+        }
+        stage[index] = value;
+    }
+    if (kMel)
+        for (int index = tid; index < mel_nnz; index += 256)
+            basis[index] = mel_values[index];
+    if (kLoud)
+        for (int index = tid; index < kBins; index += 256)
+            weights[index] = a_weights[index];
+
+    // ---- per-lane constants
+    const int p = lane;              // pass-1 position
+    const int r1 = lane >> 3;        // pass-2/3 residue r
+    const int p0 = lane & 7;         // pass-2 position / pass-3 output t
+    float window[16];
+    cf tw1[8], tw2[8], tw3[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        window[2 * q] = table[kTabWindow + 2 * (p + 64 * q)];
+        window[2 * q + 1] = table[kTabWindow + 2 * (p + 64 * q) + 1];
+        tw1[q] = {table[kTabTw1 + 2 * (q * 64 + p)],
+                  table[kTabTw1 + 2 * (q * 64 + p) + 1]};
+        tw2[q] = {table[kTabTw2 + 2 * (q * 8 + p0)],
+                  table[kTabTw2 + 2 * (q * 8 + p0) + 1]};
+        tw3[q] = {table[kTabTw3 + 2 * (lane + 64 * q)],
+                  table[kTabTw3 + 2 * (lane + 64 * q) + 1]};
+    }
+    const cf tw_nyquist = {table[kTabTw3 + 2 * 512], table[kTabTw3 + 2 * 512 + 1]};
+
+    // mel rows owned by this lane: row `lane`, and a quarter of row 64+lane/4
+    int row_a_start = 0, row_a_count = 0, row_a_off = 0;
+    int row_b_start = 0, row_b_count = 0, row_b_off = 0;
+    if (kMel) {
+        row_a_start = mel_start[lane];
+        row_a_count = mel_count[lane];
+        row_a_off = mel_offset[lane];
+        const int rb = 64 + (lane >> 2);
+        row_b_start = mel_start[rb];
+        row_b_count = mel_count[rb];
+        row_b_off = mel_offset[rb];
+    }
+
+    __syncthreads();
+
+    cf* ex = reinterpret_cast<cf*>(exchange + wave * kExFloats);
+    // magnitudes reuse the wave's exchange buffer once the spectrum is consumed
+    float* mag = exchange + wave * kExFloats;
+    float peak = 0.f;
+    float floor_db = 0.f;
+    if (kLoud) {
+        // librosa.amplitude_to_db: max(D) - top_db with D = 10 log10(max(amin^2, S^2))
+        const float top = 10.f * log10f(fmaxf(1e-10f, seg_peak[segment]));
+        floor_db = top - 80.f;
+    }
+
+    for (int local = wave; local < kBlockFrames; local += 4) {
+        if (frame0 + local >= frames) break;   // wave-uniform
+        const float* samples = stage + local * kHop;
+
+        // pass 1: radix-8 over q of z[p + 64 q], z[n] = y[2n] + i y[2n+1]
+        cf v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float2 pair =
+                *reinterpret_cast<const float2*>(samples + 2 * (p + 64 * q));
+            v[q] = {pair.x * window[2 * q], pair.y * window[2 * q + 1]};
+        }
+        dft8(v);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (r) v[r] = cmul(v[r], tw1[r]);
+            ex[r * kExRow + p] = v[r];
+        }
+        wave_lds_fence();
+
+        // pass 2: lane (r, p0) takes A[p0 + 8 p1][r], radix-8 over p1
+#pragma unroll
+        for (int p1 = 0; p1 < 8; ++p1) v[p1] = ex[r1 * kExRow + p0 + 8 * p1];
+        wave_lds_fence();
+        dft8(v);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            if (t) v[t] = cmul(v[t], tw2[t]);
+            ex[r1 * kExRow + t * 8 + p0] = v[t];     // [r][t][p0]
+        }
+        wave_lds_fence();
+
+        // pass 3: lane (r, t) takes C[r][p0][t], radix-8 over p0
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = ex[r1 * kExRow + p0 * 8 + q];
+        wave_lds_fence();
+        dft8(v);
+        // Z[r + 8 t + 64 u] = v[u]; natural-order spectrum into LDS
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ex[r1 + 8 * p0 + 64 * u] = v[u];
+        wave_lds_fence();
+
+        // real-FFT split for bins k = lane + 64 j (and k = 512 on lane 0)
+        float power[9];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = lane + 64 * j;
+            const cf zk = ex[k];
+            const cf zm = ex[(512 - k) & 511];
+            const cf even = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
+            const cf odd = {0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};
+            const cf rot = cmul(tw3[j], odd);
+            const float re = even.x + rot.x, im = even.y + rot.y;
+            power[j] = re * re + im * im;
+        }
+        {
+            const cf z0 = ex[0];
+            const cf rot = cmul(tw_nyquist, cf{z0.y, 0.f});
+            const float re = z0.x + rot.x, im = rot.y;
+            power[8] = re * re + im * im;
+        }
+        wave_lds_fence();
+
+        if (kPeak) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) peak = fmaxf(peak, power[j]);
+            if (lane == 0) peak = fmaxf(peak, power[8]);
+            continue;
+        }
+
+        if (kLoud) {
+            // 10 log10(max(1e-10, |X|^2)) floored at peak - 80, + A-weight,
+            // clamped at MIN_DB = -100, mean over the 513 bins
+            double total = 0.;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                if (j == 8 && lane != 0) break;
+                const int k = j == 8 ? 512 : lane + 64 * j;
+                float db = 10.f * log10f(fmaxf(1e-10f, power[j]));
+                db = fmaxf(db, floor_db) + weights[k];
+                total += static_cast<double>(fmaxf(db, -100.f));
+            }
+#pragma unroll
+            for (int offset = 32; offset > 0; offset >>= 1)
+                total += __shfl_xor(total, offset);
+            if (lane == 0) {
+                float value = static_cast<float>(total / 513.);
+                if (normalize) value = (value + 100.f) / 100.f;
+                loud_tile[local] = value;
+            }
+        }
+
+        if (kMel) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) mag[lane + 64 * j] = sqrtf(power[j] + 1e-6f);
+            if (lane == 0) mag[512] = sqrtf(power[8] + 1e-6f);
+            wave_lds_fence();
+
+            // rows 0..63: one lane per row (runs of 4..20 bins)
+            float acc = 0.f;
+            for (int j = 0; j < row_a_count; ++j)
+                acc = fmaf(basis[row_a_off + j], mag[row_a_start + j], acc);
+            float value = logf(fmaxf(acc, 1e-5f));
+            if (normalize) value = (value + 10.f) / 10.f;
+            tile[lane * kOutStride + local] = value;
+
+            // rows 64..79: four lanes per row (runs of 21..37 bins)
+            acc = 0.f;
+            for (int j = lane & 3; j < row_b_count; j += 4)
+                acc = fmaf(basis[row_b_off + j], mag[row_b_start + j], acc);
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            if ((lane & 3) == 0) {
+                value = logf(fmaxf(acc, 1e-5f));
+                if (normalize) value = (value + 10.f) / 10.f;
+                tile[(64 + (lane >> 2)) * kOutStride + local] = value;
+            }
+            wave_lds_fence();
+        }
+    }
+
+    if (kPeak) {
+        peak = wave_max(peak);
+        // non-negative floats order like their bit patterns
+        if (lane == 0)
+            atomicMax(reinterpret_cast<unsigned int*>(seg_peak + segment),
+                      __float_as_uint(peak));
+        return;
+    }
+
+    __syncthreads();
+    const int valid = min(kBlockFrames, frames - frame0);
+    if (kMel) {
+        // 80 rows x 32 frames: 8 rows per pass, 128-byte segments
+        const int column = tid & 31;
+        for (int m = tid >> 5; m < kMels; m += 8)
+            if (column < valid)
+                out[static_cast<int64_t>(mel_row + m) * ld + frame_off + frame0 +
+                    column] = tile[m * kOutStride + column];
+    }
+    if (kLoud && tid < valid)
+        out[static_cast<int64_t>(loud_row) * ld + frame_off + frame0 + tid] =
+            loud_tile[tid];
+}
+
+size_t frontend_lds_bytes(bool mel, bool loud, int mel_nnz) {
+    size_t floats = kStage + 4 * kExFloats + kMels * kOutStride + kBlockFrames;
+    if (mel) floats += (mel_nnz + 3) & ~3;
+    if (loud) floats += 516;
+    return floats * sizeof(float);
+}
+
+}  // namespace emph
+
+using namespace emph;
+
+extern "C" {
+
+int emph_abi_version(void) { return EMPH_ABI_VERSION; }
+
+const char* emph_last_error(void) { return g_error; }
+
+int64_t emph_frontend_table_size(void) { return kTabSize; }
+
+int emph_frontend_table_fill(float* host_table) {
+    EMPH_REQUIRE(host_table != nullptr, EMPH_EINVAL, "table is null");
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int n = 0; n < kFft; ++n)   // periodic Hann, torch.hann_window default
+        host_table[kTabWindow + n] =
+            static_cast<float>(0.5 - 0.5 * cos(two_pi * n / kFft));
+    for (int r = 0; r < 8; ++r)
+        for (int p = 0; p < 64; ++p) {
+            const double angle = -two_pi * (p * r) / 512.;
+            host_table[kTabTw1 + 2 * (r * 64 + p)] = static_cast<float>(cos(angle));
+            host_table[kTabTw1 + 2 * (r * 64 + p) + 1] =
+                static_cast<float>(sin(angle));
+        }
+    for (int t = 0; t < 8; ++t)
+        for (int p0 = 0; p0 < 8; ++p0) {
+            const double angle = -two_pi * (p0 * t) / 64.;
+            host_table[kTabTw2 + 2 * (t * 8 + p0)] = static_cast<float>(cos(angle));
+            host_table[kTabTw2 + 2 * (t * 8 + p0) + 1] =
+                static_cast<float>(sin(angle));
+        }
+    for (int k = 0; k < 514; ++k) {
+        const double angle = -two_pi * k / 1024.;
+        host_table[kTabTw3 + 2 * k] = static_cast<float>(cos(angle));
+        host_table[kTabTw3 + 2 * k + 1] = static_cast<float>(sin(angle));
+    }
+    return EMPH_OK;
+}
+
+int emph_logmel(const float* audio, const int64_t* seg, const int32_t* tiles,
+                int32_t n_tiles, const float* table, const int32_t* mel_start,
+                const int32_t* mel_count, const int32_t* mel_offset,
+                const float* mel_values, int32_t mel_nnz, float* out,
+                int64_t ld, int32_t mel_row, int32_t loud_row,
+                const float* seg_peak, const float* a_weights,
+                int32_t normalize, void* stream) {
+    if (n_tiles == 0) return EMPH_OK;
+    const bool mel = mel_row >= 0, loud = loud_row >= 0;
+    EMPH_REQUIRE(audio && seg && tiles && table && out, EMPH_EINVAL,
+                 "emph_logmel: null pointer");
+    EMPH_REQUIRE(mel || loud, EMPH_EINVAL, "emph_logmel: no output row selected");
+    EMPH_REQUIRE(!mel || (mel_start && mel_count && mel_offset && mel_values),
+                 EMPH_EINVAL, "emph_logmel: mel basis is null");
+    EMPH_REQUIRE(!mel || (mel_nnz > 0 && mel_nnz <= 8192), EMPH_ERANGE,
+                 "emph_logmel: mel_nnz %d out of range", mel_nnz);
+    EMPH_REQUIRE(!loud || (seg_peak && a_weights), EMPH_EINVAL,
+                 "emph_logmel: loudness needs seg_peak and a_weights");
+    const size_t lds = frontend_lds_bytes(mel, loud, mel_nnz);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* peak = const_cast<float*>(seg_peak);
+#define EMPH_LAUNCH(MODE)                                                      \
+    hipLaunchKernelGGL(frontend_kernel<MODE>, dim3(n_tiles), dim3(256), lds, s, \
+                       audio, seg, tiles, table, mel_start, mel_count,         \
+                       mel_offset, mel_values, mel_nnz, out, ld, mel_row,      \
+                       loud_row, peak, a_weights, normalize)
+    if (mel && loud) {
+        EMPH_LAUNCH(2);
+    } else if (mel) {
+        EMPH_LAUNCH(0);
+    } else {
+        EMPH_LAUNCH(3);
+    }
+    return check_launch("emph_logmel");
+}
+
+int emph_frontend_peak(const float* audio, const int64_t* seg,
+                       const int32_t* tiles, int32_t n_tiles,
+                       const float* table, float* seg_peak, void* stream) {
+    if (n_tiles == 0) return EMPH_OK;
+    EMPH_REQUIRE(audio && seg && tiles && table && seg_peak, EMPH_EINVAL,
+                 "emph_frontend_peak: null pointer");
+    const size_t lds = frontend_lds_bytes(false, false, 0);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int32_t* none_i = nullptr;
+    const float* none_f = nullptr;
+    float* none_o = nullptr;
+    hipLaunchKernelGGL(frontend_kernel<1>, dim3(n_tiles), dim3(256), lds, s,
+                       audio, seg, tiles, table, none_i, none_i, none_i, none_f,
+                       0, none_o, int64_t{0}, -1, -1, seg_peak, none_f, 0);
+    return check_launch("emph_frontend_peak");
+}
+#undef EMPH_LAUNCH
+
+}  // extern "C"

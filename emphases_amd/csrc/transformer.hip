@@ -1,0 +1,270 @@
+// Transformer encoder pieces (emphases/model/layers/transformer.py:13-52):
+// positional encoding, the attention core and the post-LN residual.  The
+// linear layers (in_proj, out_proj, linear1, linear2) are kernel_size-1 calls
+// of emph_conv1d, so activations stay in the packed [channels, positions]
+// layout end to end (the reference permutes to [T, B, C] and back).
+//
+// Attention (fp32 MFMA, scores never materialised; the reference's bmm writes a
+// 2 x T x T fp32 matrix per utterance and layer):
+//   S^T = K Q^T   A = K[key][d]  (keys on the lane's low bits -> coalesced
+//                 reads of the d-major K rows), B = Q^T pre-scaled by 1/sqrt(d)
+//   O^T = V^T P^T A = V^T[d][key] read from the position-major V buffer,
+//                 B = P^T = the S^T accumulator registers as they stand: with
+//                 k-step r taking keys {4g + r}, the MFMA D-layout (row =
+//                 4*(lane>>4) + r) IS the B-operand layout, so probabilities
+//                 never move between lanes or through LDS.
+//   Online softmax statistics live per lane because the query is the MFMA
+//   column (lane & 15) in both products.
+#include <math.h>
+
+#include "common.h"
+
+namespace emph {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// grid = n_tiles (blocks of `tile_n` positions); block = 256
+__global__ __launch_bounds__(256) void add_position_kernel(
+    float* __restrict__ x, int64_t ldx, const float* __restrict__ table,
+    int channels, int max_positions, const int64_t* __restrict__ seg, int axis,
+    const int32_t* __restrict__ tiles, int tile_n) {
+    const int segment = tiles[2 * blockIdx.x];
+    const int t0 = tiles[2 * blockIdx.x + 1];
+    const Span span = load_span(seg, segment, axis);
+    const int count = min(tile_n, span.count - t0);
+    for (int index = threadIdx.x; index < channels * tile_n; index += 256) {
+        const int c = index / tile_n;
+        const int i = index - c * tile_n;
+        if (i < count && t0 + i < max_positions)
+            x[static_cast<int64_t>(c) * ldx + span.offset + t0 + i] +=
+                table[static_cast<int64_t>(t0 + i) * channels + c];
+    }
+}
+
+// one thread per column; y = LayerNorm(x + r) over channels
+template <int CMAX>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(
+    const float* x, const float* __restrict__ r, float* y,
+    int64_t ld, int channels, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, int64_t first, int64_t count) {
+    const int64_t index = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (index >= count) return;
+    const int64_t column = first + index;
+    float v[CMAX];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+        if (c < channels) {
+            v[c] = x[static_cast<int64_t>(c) * ld + column] +
+                   r[static_cast<int64_t>(c) * ld + column];
+            sum += v[c];
+        }
+    }
+    const float mean = sum / static_cast<float>(channels);
+    float square = 0.f;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < channels) square = fmaf(v[c] - mean, v[c] - mean, square);
+    const float rstd = 1.f / sqrtf(square / static_cast<float>(channels) + eps);
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < channels)
+            y[static_cast<int64_t>(c) * ld + column] =
+                (v[c] - mean) * rstd * gamma[c] + beta[c];
+}
+
+// grid = (n_tiles, heads); block = 64 (one wave = 64 queries of one head)
+template <int D>
+__global__ __launch_bounds__(64) void attention_kernel(
+    const float* __restrict__ qk, const float* __restrict__ v,
+    float* __restrict__ out, int64_t ld, int channels,
+    const int64_t* __restrict__ seg, int axis, const int32_t* __restrict__ tiles) {
+    constexpr int QT = 4;                 // 16-query tiles per wave
+    constexpr int KSTEPS = D / 4;         // k-steps of the QK^T product
+    constexpr int MT = (D + 15) / 16;     // 16-row tiles of O^T
+    const int lane = threadIdx.x;
+    const int col = lane & 15;
+    const int kk = lane >> 4;
+    const int head = blockIdx.y;
+    const int segment = tiles[2 * blockIdx.x];
+    const int q0 = tiles[2 * blockIdx.x + 1];
+    const Span span = load_span(seg, segment, axis);
+    const int length = span.count;
+    const float scale = 1.f / sqrtf(static_cast<float>(D));
+
+    const float* q_rows = qk + static_cast<int64_t>(head * D) * ld + span.offset;
+    const float* k_rows =
+        qk + static_cast<int64_t>(channels + head * D) * ld + span.offset;
+    const float* v_rows = v + span.offset * channels + head * D;
+
+    float bq[QT][KSTEPS];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int query = q0 + 16 * t + col;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+            bq[t][s] = query < length
+                           ? q_rows[static_cast<int64_t>(4 * s + kk) * ld + query] * scale
+                           : 0.f;
+    }
+
+    f32x4 o[QT][MT];
+    float row_max[QT], row_sum[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        row_max[t] = -INFINITY;
+        row_sum[t] = 0.f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) o[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int key0 = 0; key0 < length; key0 += 16) {
+        // K fragment: A[i = key][k = d]
+        float ak[KSTEPS];
+        const int key = key0 + col;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+            ak[s] = key < length ? k_rows[static_cast<int64_t>(4 * s + kk) * ld + key]
+                                 : 0.f;
+        // V fragment for k-step r: A[i = d][k] = V[key0 + 4*kk + r][d]
+        float av[4][MT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int vkey = key0 + 4 * kk + r;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                av[r][m] = (vkey < length && 16 * m + col < D)
+                               ? v_rows[static_cast<int64_t>(vkey) * channels + 16 * m + col]
+                               : 0.f;
+        }
+
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s)
+                s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[s], bq[t][s], s4, 0, 0, 0);
+            // s4[r] = score(key0 + 4*kk + r, query col)
+            float local = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (key0 + 4 * kk + r >= length) s4[r] = -INFINITY;
+                local = fmaxf(local, s4[r]);
+            }
+            local = fmaxf(local, __shfl_xor(local, 16));
+            local = fmaxf(local, __shfl_xor(local, 32));
+            const float new_max = fmaxf(row_max[t], local);
+            const float alpha = expf(row_max[t] - new_max);
+            float partial = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s4[r] = expf(s4[r] - new_max);
+                partial += s4[r];
+            }
+            partial += __shfl_xor(partial, 16);
+            partial += __shfl_xor(partial, 32);
+            row_sum[t] = row_sum[t] * alpha + partial;
+            row_max[t] = new_max;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                o[t][m] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    o[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        av[r][m], s4[r], o[t][m], 0, 0, 0);
+            }
+        }
+    }
+
+    // O^T[d = 16 m + 4 kk + r][query col]
+    float* o_rows = out + static_cast<int64_t>(head * D) * ld + span.offset;
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int query = q0 + 16 * t + col;
+        if (query >= length) continue;
+        const float inverse = 1.f / row_sum[t];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = 16 * m + 4 * kk + r;
+                if (d < D)
+                    o_rows[static_cast<int64_t>(d) * ld + query] = o[t][m][r] * inverse;
+            }
+    }
+}
+
+}  // namespace emph
+
+using namespace emph;
+
+extern "C" {
+
+int emph_add_position(float* x, int64_t ldx, const float* table, int32_t channels,
+                      int32_t max_positions, const int64_t* seg, int32_t axis,
+                      const int32_t* tiles, int32_t n_tiles, int32_t tile_n,
+                      void* stream) {
+    if (n_tiles == 0) return EMPH_OK;
+    EMPH_REQUIRE(x && table && seg && tiles, EMPH_EINVAL,
+                 "emph_add_position: null pointer");
+    EMPH_REQUIRE(tile_n > 0 && channels > 0, EMPH_EINVAL, "emph_add_position: bad shape");
+    hipLaunchKernelGGL(add_position_kernel, dim3(n_tiles), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, ldx, table, channels,
+                       max_positions, seg, axis, tiles, tile_n);
+    return check_launch("emph_add_position");
+}
+
+int emph_add_layernorm(const float* x, const float* r, float* y, int64_t ld,
+                       int32_t channels, const float* gamma, const float* beta,
+                       float eps, int64_t first_column, int64_t columns,
+                       void* stream) {
+    if (columns == 0) return EMPH_OK;
+    EMPH_REQUIRE(x && r && y && gamma && beta, EMPH_EINVAL,
+                 "emph_add_layernorm: null pointer");
+    EMPH_REQUIRE(channels > 0 && channels <= 128, EMPH_ERANGE,
+                 "emph_add_layernorm: channels %d not in 1..128", channels);
+    const unsigned blocks = static_cast<unsigned>((columns + 255) / 256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (channels <= 80)
+        hipLaunchKernelGGL(add_layernorm_kernel<80>, dim3(blocks), dim3(256), 0, s, x,
+                           r, y, ld, channels, gamma, beta, eps, first_column, columns);
+    else
+        hipLaunchKernelGGL(add_layernorm_kernel<128>, dim3(blocks), dim3(256), 0, s, x,
+                           r, y, ld, channels, gamma, beta, eps, first_column, columns);
+    return check_launch("emph_add_layernorm");
+}
+
+int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
+                   int32_t channels, int32_t heads, const int64_t* seg,
+                   int32_t axis, const int32_t* tiles, int32_t n_tiles,
+                   void* stream) {
+    if (n_tiles == 0) return EMPH_OK;
+    EMPH_REQUIRE(qk && v && out && seg && tiles, EMPH_EINVAL,
+                 "emph_attention: null pointer");
+    EMPH_REQUIRE(heads > 0 && channels % heads == 0, EMPH_EINVAL,
+                 "emph_attention: channels %d not divisible by heads %d", channels,
+                 heads);
+    const int d = channels / heads;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dim3 grid(n_tiles, heads);
+    switch (d) {
+        case 32:
+            hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64), 0, s, qk, v, out, ld,
+                               channels, seg, axis, tiles);
+            break;
+        case 40:
+            hipLaunchKernelGGL(attention_kernel<40>, grid, dim3(64), 0, s, qk, v, out, ld,
+                               channels, seg, axis, tiles);
+            break;
+        case 64:
+            hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64), 0, s, qk, v, out, ld,
+                               channels, seg, axis, tiles);
+            break;
+        default:
+            set_error("emph_attention: head dimension %d not in {32, 40, 64}", d);
+            return EMPH_ERANGE;
+    }
+    return check_launch("emph_attention");
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+// Frame -> word resampling and the scalar output projection.
+//
+// emph_segment_reduce replaces the Python double loop of emphases.downsample
+// (emphases/core.py:426-469: one slice + reduce + copy, i.e. >= 3 kernel
+// launches and a host sync, per word).  It is HBM-bound: every frame embedding
+// is read exactly once (320 B per frame for 80 channels) in 64-byte row
+// segments; one wave owns one word, lanes are 16 frames x 4 channels, and the
+// frame axis is folded with a 16-lane butterfly.
+//
+// emph_output_layer replaces Conv1d(channels, 1, k, 'same')
+// (emphases/model/core.py:33-37,138) fused with emphases.postprocess
+// (emphases/core.py:335-342).
+#include <math.h>
+
+#include "common.h"
+
+namespace emph {
+
+// grid.x = blocks of 4 words over the packed word axis; block = 256
+__global__ __launch_bounds__(256) void segment_reduce_kernel(
+    const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ bounds,
+    float* __restrict__ out, int64_t ldw, int channels,
+    const int64_t* __restrict__ seg, const int32_t* __restrict__ word_segment,
+    int64_t total_words, int mode) {
+    const int lane = threadIdx.x & 63;
+    const int64_t word = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (word >= total_words) return;
+    const int segment = word_segment[word];
+    if (segment < 0) return;                      // alignment padding column
+    const int64_t* row = seg + static_cast<int64_t>(segment) * EMPH_SEG_FIELDS;
+    const int64_t frame_off = row[EMPH_SEG_FRAME_OFF];
+    const int frames = static_cast<int>(row[EMPH_SEG_FRAMES]);
+    // Python slice semantics: clamp to the chunk (core.py:446-454)
+    int start = bounds[word];
+    int end = bounds[ldw + word];
+    const int raw_count = end - start;
+    start = max(0, min(start, frames));
+    end = max(start, min(end, frames));
+
+    const int fr = lane & 15;
+    const int cg = lane >> 4;
+    if (mode == EMPH_REDUCE_CENTER) {
+        // gather at (start + end) // 2 of the UNclamped bounds (core.py:459-466)
+        const int center = (bounds[word] + bounds[ldw + word]) >> 1;
+        for (int c = lane; c < channels; c += 64)
+            out[static_cast<int64_t>(c) * ldw + word] =
+                (center >= 0 && center < frames)
+                    ? x[static_cast<int64_t>(c) * ldx + frame_off + center]
+                    : 0.f;
+        return;
+    }
+    const float* base = x + frame_off;
+    for (int c = cg; c < channels; c += 4) {
+        const float* src = base + static_cast<int64_t>(c) * ldx;
+        float value = mode == EMPH_REDUCE_MAX ? -INFINITY : 0.f;
+        if (mode == EMPH_REDUCE_MAX) {
+            for (int t = start + fr; t < end; t += 16) value = fmaxf(value, src[t]);
+#pragma unroll
+            for (int offset = 8; offset > 0; offset >>= 1)
+                value = fmaxf(value, __shfl_xor(value, offset));
+        } else {
+            for (int t = start + fr; t < end; t += 16) value += src[t];
+#pragma unroll
+            for (int offset = 8; offset > 0; offset >>= 1)
+                value += __shfl_xor(value, offset);
+            if (mode == EMPH_REDUCE_AVERAGE)
+                value = value / static_cast<float>(raw_count > 0 ? end - start : 0);
+        }
+        if (fr == 0) out[static_cast<int64_t>(c) * ldw + word] = value;
+    }
+}
+
+// one thread per position of the packed axis
+__global__ __launch_bounds__(256) void output_layer_kernel(
+    const float* __restrict__ x, int64_t ldx, const float* __restrict__ weight,
+    const float* __restrict__ bias, int channels, int kernel_size,
+    const int64_t* __restrict__ seg, const int32_t* __restrict__ position_segment,
+    int64_t total, int axis, int post, float* __restrict__ logits,
+    float* __restrict__ scores) {
+    extern __shared__ float w[];
+    for (int index = threadIdx.x; index < channels * kernel_size; index += 256)
+        w[index] = weight[index];
+    __syncthreads();
+    const int64_t position =
+        static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (position >= total) return;
+    const int segment = position_segment[position];
+    if (segment < 0) return;
+    const Span span = load_span(seg, segment, axis);
+    const int t = static_cast<int>(position - span.offset);
+    const int halo = (kernel_size - 1) / 2;
+    float acc = 0.f;
+    for (int c = 0; c < channels; ++c) {
+        const float* src = x + static_cast<int64_t>(c) * ldx + position;
+        for (int tap = 0; tap < kernel_size; ++tap) {
+            const int u = t + tap - halo;
+            if (u >= 0 && u < span.count)
+                acc = fmaf(w[c * kernel_size + tap], src[tap - halo], acc);
+        }
+    }
+    acc += bias[0];
+    if (logits != nullptr) logits[position] = acc;
+    if (scores != nullptr) {
+        float value = acc;
+        if (post == EMPH_POST_SIGMOID) value = 1.f / (1.f + expf(-acc));
+        if (post == EMPH_POST_CLAMP01) value = fminf(fmaxf(acc, 0.f), 1.f);
+        scores[position] = value;
+    }
+}
+
+}  // namespace emph
+
+using namespace emph;
+
+extern "C" {
+
+int emph_segment_reduce(const float* x, int64_t ldx, const int32_t* bounds,
+                        float* out, int64_t ldw, int32_t channels,
+                        const int64_t* seg, const int32_t* word_segment,
+                        int64_t total_words, int32_t mode, void* stream) {
+    if (total_words == 0) return EMPH_OK;
+    EMPH_REQUIRE(x && bounds && out && seg && word_segment, EMPH_EINVAL,
+                 "emph_segment_reduce: null pointer");
+    EMPH_REQUIRE(mode >= EMPH_REDUCE_SUM && mode <= EMPH_REDUCE_CENTER, EMPH_EINVAL,
+                 "emph_segment_reduce: unknown mode %d", mode);
+    EMPH_REQUIRE(channels > 0 && total_words <= ldw, EMPH_EINVAL,
+                 "emph_segment_reduce: bad shape");
+    const unsigned blocks = static_cast<unsigned>((total_words + 3) / 4);
+    hipLaunchKernelGGL(segment_reduce_kernel, dim3(blocks), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, ldx, bounds, out, ldw,
+                       channels, seg, word_segment, total_words, mode);
+    return check_launch("emph_segment_reduce");
+}
+
+int emph_output_layer(const float* x, int64_t ldx, const float* weight,
+                      const float* bias, int32_t channels, int32_t kernel_size,
+                      const int64_t* seg, const int32_t* position_segment,
+                      int64_t total, int32_t axis, int32_t post, float* logits,
+                      float* scores, void* stream) {
+    if (total == 0) return EMPH_OK;
+    EMPH_REQUIRE(x && weight && bias && seg && position_segment, EMPH_EINVAL,
+                 "emph_output_layer: null pointer");
+    EMPH_REQUIRE(kernel_size >= 1 && kernel_size <= 7 && (kernel_size & 1),
+                 EMPH_ERANGE, "emph_output_layer: kernel_size %d", kernel_size);
+    EMPH_REQUIRE(channels > 0 && channels * kernel_size <= 8192, EMPH_ERANGE,
+                 "emph_output_layer: channels %d", channels);
+    const unsigned blocks = static_cast<unsigned>((total + 255) / 256);
+    hipLaunchKernelGGL(output_layer_kernel, dim3(blocks), dim3(256),
+                       channels * kernel_size * sizeof(float),
+                       static_cast<hipStream_t>(stream), x, ldx, weight, bias,
+                       channels, kernel_size, seg, position_segment, total, axis,
+                       post, logits, scores);
+    return check_launch("emph_output_layer");
+}
+
+}  // extern "C"

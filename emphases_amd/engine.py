@@ -1,0 +1,360 @@
+"""Device-side execution of the prominence path on one MI355X.
+
+`Engine` owns the immutable per-(checkpoint, device) state — MFMA-ordered
+weight packs, biases, the front-end tables, the sparse mel basis — and runs a
+`batch.Plan` through the HIP kernels of libemphases_hip.so:
+
+    audio -> log-mel (+loudness) -> input conv -> frame encoder (conv stack or
+    transformer) -> word-boundary reduce -> word decoder -> output conv ->
+    sigmoid/clamp
+
+which is `Model.forward` + `postprocess` of the reference
+(`emphases/model/core.py:39-138`, `emphases/core.py:335-342`) for every chunk
+of the batch at once, with per-chunk (B=1) edge semantics.  The reference
+keeps its model on function attributes of `infer` (`core.py:298-315`); here the
+cache is an explicit object.
+"""
+import numpy as np
+import torch
+
+from . import config as cfg
+from . import melbasis
+from . import runtime
+from . import weights as weights_module
+
+FRONTEND_BLOCK = 32     # frames per front-end workgroup (csrc/frontend.hip)
+ATTENTION_BLOCK = 64    # queries per attention wave (csrc/transformer.hip)
+WORD_TILE = 16
+
+
+def a_weighting():
+    """A-weighting minus REF_DB on the 8 kHz / 1024-bin grid the reference
+    evaluates it on (`loudness.py:110-120`; librosa.A_weighting restated from
+    its published formula — third-party, parity-unpinned)."""
+    frequencies = np.fft.rfftfreq(n=1024, d=1.0 / 8000)
+    f_sq = frequencies ** 2.0
+    const = np.array([12194.217, 20.598997, 107.65265, 737.86223]) ** 2.0
+    with np.errstate(divide='ignore'):
+        weights = 2.0 + 20.0 * (
+            np.log10(const[0]) + 2 * np.log10(f_sq)
+            - np.log10(f_sq + const[0]) - np.log10(f_sq + const[1])
+            - 0.5 * np.log10(f_sq + const[2])
+            - 0.5 * np.log10(f_sq + const[3]))
+    return (np.maximum(-80.0, weights) - cfg.REF_DB).astype(np.float32)
+
+
+class _Conv:
+    """Device copy of one Conv1d / Linear in MFMA fragment order."""
+
+    def __init__(self, weight, bias, device):
+        weight = np.asarray(weight, dtype=np.float32)
+        if weight.ndim == 2:
+            weight = weight[:, :, None]
+        self.c_out, self.c_in, self.kernel_size = weight.shape
+        self.pack = torch.from_numpy(runtime.conv_pack(weight)).to(device)
+        self.bias = None if bias is None else torch.from_numpy(
+            np.ascontiguousarray(bias, dtype=np.float32)).to(device)
+
+
+class Engine:
+    """Weights + constants on one device, and the kernel sequence."""
+
+    def __init__(self, config=cfg.DEFAULT, state=None, device=None,
+                 conv_tile=None):
+        self.config = config
+        self.device = runtime.require_gpu(device)
+        self.lib = runtime.library()
+        self.conv_tile = conv_tile
+        state = weights_module.load(state, config)
+        self.state = state
+        dev = self.device
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+
+        # Front-end constants
+        self.table = to(runtime.frontend_table())
+        basis = melbasis.default()
+        self.mel_start = to(basis.row_start)
+        self.mel_count = to(basis.row_count)
+        self.mel_offset = to(basis.row_offset)
+        self.mel_values = to(basis.values)
+        self.mel_nnz = int(basis.values.size)
+        self.a_weights = to(a_weighting())
+
+        # Model
+        self.input_layer = _Conv(
+            state['input_layer.weight'], state['input_layer.bias'], dev)
+        self.frame_encoder = self._stack('frame_encoder')
+        self.word_decoder = self._stack('word_decoder') \
+            if config.has_decoder else None
+        self.output_weight = to(state['output_layer.weight'])
+        self.output_bias = to(state['output_layer.bias'])
+        if config.architecture == 'transformer':
+            self.position = to(weights_module.positional_encoding(
+                cfg.MAX_POSITIONS, config.channels))
+
+    def _stack(self, prefix):
+        config, state, dev = self.config, self.state, self.device
+        layers = []
+        if config.architecture == 'convolution':
+            for i in range(config.layers):
+                layers.append(_Conv(
+                    state[f'{prefix}.{2 * i}.weight'],
+                    state[f'{prefix}.{2 * i}.bias'], dev))
+            return layers
+        channels = config.channels
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        for i in range(config.layers):
+            p = f'{prefix}.model.layers.{i}.'
+            in_w = state[p + 'self_attn.in_proj_weight']
+            in_b = state[p + 'self_attn.in_proj_bias']
+            layers.append(dict(
+                qk=_Conv(in_w[:2 * channels], in_b[:2 * channels], dev),
+                v=_Conv(in_w[2 * channels:], in_b[2 * channels:], dev),
+                out=_Conv(state[p + 'self_attn.out_proj.weight'],
+                          state[p + 'self_attn.out_proj.bias'], dev),
+                linear1=_Conv(state[p + 'linear1.weight'],
+                              state[p + 'linear1.bias'], dev),
+                linear2=_Conv(state[p + 'linear2.weight'],
+                              state[p + 'linear2.bias'], dev),
+                norm1=(to(state[p + 'norm1.weight']),
+                       to(state[p + 'norm1.bias'])),
+                norm2=(to(state[p + 'norm2.weight']),
+                       to(state[p + 'norm2.bias']))))
+        return layers
+
+    ###########################################################################
+    # Plan upload
+    ###########################################################################
+
+    def frame_tile(self, plan):
+        """Positions per conv wave on the frame axis: the widest tile that
+        still leaves about two waves per SIMD on the 256 CUs."""
+        if self.conv_tile is not None:
+            return self.conv_tile
+        for tile in (64, 32):
+            if plan.total_frames / tile >= 2048:
+                return tile
+        return 32 if plan.total_frames / 32 >= 512 else 16
+
+    def upload(self, plan, tile=None):
+        """One H2D copy of all integer metadata; returns device views."""
+        tile = tile or self.frame_tile(plan)
+        requests = [
+            (runtime.AXIS_FRAMES, FRONTEND_BLOCK),
+            (runtime.AXIS_FRAMES, tile),
+            (runtime.AXIS_WORDS, WORD_TILE)]
+        if self.config.architecture == 'transformer':
+            requests += [(runtime.AXIS_FRAMES, ATTENTION_BLOCK),
+                         (runtime.AXIS_WORDS, ATTENTION_BLOCK)]
+        requests = list(dict.fromkeys(requests))
+        host, offsets = plan.pack_metadata(requests)
+        pinned = torch.from_numpy(host)
+        if self.device.type == 'cuda':
+            pinned = pinned.pin_memory()
+        device_buffer = pinned.to(self.device, non_blocking=True)
+        views = {'_buffer': device_buffer, '_pinned': pinned, 'tile': tile}
+        for name, (start, size) in offsets.items():
+            views[name] = (device_buffer[start:start + size], size)
+        return views
+
+    ###########################################################################
+    # Kernel wrappers
+    ###########################################################################
+
+    def _conv(self, layer, x, ldx, y, ldy, meta, axis, block, activation,
+              transpose_out=False):
+        tiles, size = meta[('tiles', axis, block)]
+        runtime.check(self.lib.emph_conv1d(
+            x.data_ptr(), ldx, y.data_ptr(), ldy, layer.pack.data_ptr(),
+            None if layer.bias is None else layer.bias.data_ptr(),
+            layer.c_in, layer.c_out, layer.kernel_size,
+            runtime.ACTIVATIONS[activation], meta['table'][0].data_ptr(), axis,
+            tiles.data_ptr(), size // 2, block, int(transpose_out),
+            runtime.stream()), 'emph_conv1d')
+
+    def features(self, audio, plan, meta, out=None, extra_rows=None):
+        """Feature matrix [num_features, ld_frames] of every segment
+        (`data/preprocess/core.py:71-125`).  Pitch/periodicity rows come from
+        a third-party neural tracker (`penn`) and are accepted only as
+        precomputed packed rows in `extra_rows`."""
+        config = self.config
+        rows = config.num_features
+        if out is None:
+            out = torch.empty(
+                (rows, plan.ld_frames), dtype=torch.float32,
+                device=self.device)
+        mel_row = 0 if config.mel_feature else -1
+        loud_row = rows - 1 if config.loudness_feature else -1
+        extra = int(config.pitch_feature) + int(config.periodicity_feature)
+        if extra:
+            if extra_rows is None or extra_rows.shape[0] != extra:
+                raise NotImplementedError(
+                    'pitch/periodicity features come from the third-party '
+                    '`penn` tracker; pass them precomputed as extra_rows')
+            first = cfg.NUM_MELS if config.mel_feature else 0
+            out[first:first + extra] = extra_rows
+        tiles, size = meta[('tiles', runtime.AXIS_FRAMES, FRONTEND_BLOCK)]
+        table = meta['table'][0]
+        peak = None
+        if config.loudness_feature:
+            peak = torch.zeros(
+                len(plan.segments), dtype=torch.float32, device=self.device)
+            runtime.check(self.lib.emph_frontend_peak(
+                audio.data_ptr(), table.data_ptr(), tiles.data_ptr(),
+                size // 2, self.table.data_ptr(), peak.data_ptr(),
+                runtime.stream()), 'emph_frontend_peak')
+        if mel_row >= 0 or loud_row >= 0:
+            runtime.check(self.lib.emph_logmel(
+                audio.data_ptr(), table.data_ptr(), tiles.data_ptr(),
+                size // 2, self.table.data_ptr(), self.mel_start.data_ptr(),
+                self.mel_count.data_ptr(), self.mel_offset.data_ptr(),
+                self.mel_values.data_ptr(), self.mel_nnz, out.data_ptr(),
+                plan.ld_frames, mel_row, loud_row,
+                None if peak is None else peak.data_ptr(),
+                self.a_weights.data_ptr(), int(config.normalize),
+                runtime.stream()), 'emph_logmel')
+        return out
+
+    def _transformer(self, layers, x, ld, plan, meta, axis, block, scratch):
+        """`Transformer.forward` (transformer.py:25-30) in place on x."""
+        config = self.config
+        channels = config.channels
+        table = meta['table'][0]
+        att_tiles, att_size = meta[('tiles', axis, ATTENTION_BLOCK)]
+        counts = plan.frames if axis == runtime.AXIS_FRAMES else plan.words
+        if len(counts) and int(counts.max()) > cfg.MAX_POSITIONS:
+            # transformer.py:40,51-52: the encoding table has 5000 rows
+            raise RuntimeError(
+                f'a chunk of {int(counts.max())} positions exceeds the '
+                f'{cfg.MAX_POSITIONS}-entry positional encoding; pass a '
+                'smaller batch_size')
+        runtime.check(self.lib.emph_add_position(
+            x.data_ptr(), ld, self.position.data_ptr(), channels,
+            cfg.MAX_POSITIONS, table.data_ptr(), axis, att_tiles.data_ptr(),
+            att_size // 2, ATTENTION_BLOCK, runtime.stream()),
+            'emph_add_position')
+        qk, v, attended, projected = scratch
+        for layer in layers:
+            self._conv(layer['qk'], x, ld, qk, ld, meta, axis, block, None)
+            self._conv(layer['v'], x, ld, v, channels, meta, axis, block, None,
+                       transpose_out=True)
+            runtime.check(self.lib.emph_attention(
+                qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld, channels,
+                config.heads, table.data_ptr(), axis, att_tiles.data_ptr(),
+                att_size // 2, runtime.stream()), 'emph_attention')
+            self._conv(layer['out'], attended, ld, projected, ld, meta, axis,
+                       block, None)
+            runtime.check(self.lib.emph_add_layernorm(
+                x.data_ptr(), projected.data_ptr(), x.data_ptr(), ld, channels,
+                layer['norm1'][0].data_ptr(), layer['norm1'][1].data_ptr(),
+                config.layer_norm_eps, 0, ld, runtime.stream()),
+                'emph_add_layernorm')
+            self._conv(layer['linear1'], x, ld, attended, ld, meta, axis,
+                       block, 'relu')
+            self._conv(layer['linear2'], attended, ld, projected, ld, meta,
+                       axis, block, None)
+            runtime.check(self.lib.emph_add_layernorm(
+                x.data_ptr(), projected.data_ptr(), x.data_ptr(), ld, channels,
+                layer['norm2'][0].data_ptr(), layer['norm2'][1].data_ptr(),
+                config.layer_norm_eps, 0, ld, runtime.stream()),
+                'emph_add_layernorm')
+        return x
+
+    def _stack_forward(self, layers, x, other, ld, plan, meta, axis, block):
+        """Frame encoder / word decoder; returns the tensor holding the
+        result (one of x / other)."""
+        config = self.config
+        if config.architecture == 'convolution':
+            for layer in layers:
+                self._conv(layer, x, ld, other, ld, meta, axis, block,
+                           config.activation)
+                x, other = other, x
+            return x, other
+        channels = config.channels
+        empty = lambda *shape: torch.zeros(  # noqa: E731
+            shape, dtype=torch.float32, device=self.device)
+        scratch = (empty(2 * channels, ld), empty(ld, channels),
+                   empty(channels, ld), other)
+        return self._transformer(
+            layers, x, ld, plan, meta, axis, block, scratch), other
+
+    ###########################################################################
+    # Forward
+    ###########################################################################
+
+    def forward(self, audio, plan, meta=None, stages=None, features=None,
+                extra_rows=None):
+        """Scores of every word of every segment.
+
+        audio: float32 device tensor, all utterances back to back.
+        Returns (scores, logits): float32 [ld_words] on the packed word axis
+        (`plan.word_columns()` picks the valid entries)."""
+        config = self.config
+        if config.downsample_location == 'input':
+            raise NotImplementedError(
+                "DOWNSAMPLE_LOCATION='input' (model/core.py:41-87) is not "
+                'built yet')
+        meta = meta or self.upload(plan)
+        block = meta['tile']
+        channels = config.channels
+        ld_f, ld_w = plan.ld_frames, plan.ld_words
+        zeros = lambda *shape: torch.zeros(  # noqa: E731
+            shape, dtype=torch.float32, device=self.device)
+        if features is None:
+            features = self.features(audio, plan, meta, extra_rows=extra_rows)
+        a, b = zeros(channels, ld_f), zeros(channels, ld_f)
+        self._conv(self.input_layer, features, ld_f, a, ld_f, meta,
+                   runtime.AXIS_FRAMES, block, None)
+        if stages is not None:
+            stages['features'] = features
+            stages['input_layer'] = a.clone()
+        encoded, _ = self._stack_forward(
+            self.frame_encoder, a, b, ld_f, plan, meta, runtime.AXIS_FRAMES,
+            block)
+        if stages is not None:
+            stages['encoder'] = encoded
+
+        check_bounds(plan, config.downsample_method)
+        wa, wb = zeros(channels, ld_w), zeros(channels, ld_w)
+        table = meta['table'][0]
+        runtime.check(self.lib.emph_segment_reduce(
+            encoded.data_ptr(), ld_f, meta['bounds'][0].data_ptr(),
+            wa.data_ptr(), ld_w, channels, table.data_ptr(),
+            meta['word_segment'][0].data_ptr(), ld_w,
+            runtime.REDUCTIONS[config.downsample_method], runtime.stream()),
+            'emph_segment_reduce')
+        if stages is not None:
+            stages['downsampled'] = wa.clone()
+        decoded = wa
+        if config.downsample_location == 'intermediate':
+            decoded, _ = self._stack_forward(
+                self.word_decoder, wa, wb, ld_w, plan, meta,
+                runtime.AXIS_WORDS, WORD_TILE)
+        logits = zeros(ld_w)
+        scores = zeros(ld_w)
+        runtime.check(self.lib.emph_output_layer(
+            decoded.data_ptr(), ld_w, self.output_weight.data_ptr(),
+            self.output_bias.data_ptr(), channels, config.decoder_kernel_size,
+            table.data_ptr(), meta['word_segment'][0].data_ptr(), ld_w,
+            runtime.AXIS_WORDS, runtime.POSTPROCESS[config.loss],
+            logits.data_ptr(), scores.data_ptr(), runtime.stream()),
+            'emph_output_layer')
+        return scores, logits
+
+
+def check_bounds(plan, method):
+    """Host-side replicas of the two cases where the reference raises
+    (`core.py:449-452,459-466`)."""
+    if method not in ('max', 'center'):
+        return
+    for segment in plan.segments:
+        starts, ends = segment.bounds
+        if method == 'max' and np.any(
+                np.minimum(ends, segment.frames) <=
+                np.minimum(starts, segment.frames)):
+            raise IndexError(
+                'max(): Expected reduction dim 1 to have non-zero size '
+                '(empty word)')
+        if method == 'center' and np.any(
+                (starts + ends) // 2 >= segment.frames):
+            raise IndexError('word center lies beyond the last frame')

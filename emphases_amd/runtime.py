@@ -1,0 +1,155 @@
+"""ctypes binding of libemphases_hip.so (the C ABI of `include/emphases_hip.h`).
+
+PyTorch is used here only for device memory and streams: tensors are handed to
+the library as raw device pointers plus the current HIP stream.  There is NO
+CPU fallback — if the library is missing, or no GPU is visible when a kernel
+is requested, the call fails loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
+ABI_VERSION = 1
+
+# include/emphases_hip.h
+SEG_FIELDS = 8
+(SEG_AUDIO_OFF, SEG_AUDIO_LEN, SEG_START, SEG_LENGTH, SEG_FRAME_OFF,
+ SEG_FRAMES, SEG_WORD_OFF, SEG_WORDS) = range(8)
+AXIS_FRAMES, AXIS_WORDS = 0, 1
+ACTIVATIONS = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2, 'silu': 3,
+               'leaky_relu': 4}
+REDUCTIONS = {'sum': 0, 'average': 1, 'max': 2, 'center': 3}
+POSTPROCESS = {None: 0, 'bce': 1, 'mse': 2}
+
+_c = ctypes
+_ptr, _i32, _i64, _f32 = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_float
+
+# name -> (restype, argtypes); every symbol include/emphases_hip.h declares
+SIGNATURES = {
+    'emph_abi_version': (_c.c_int, []),
+    'emph_last_error': (_c.c_char_p, []),
+    'emph_frontend_table_size': (_i64, []),
+    'emph_frontend_table_fill': (_c.c_int, [_ptr]),
+    'emph_logmel': (_c.c_int, [
+        _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _i64,
+        _i32, _i32, _ptr, _ptr, _i32, _ptr]),
+    'emph_frontend_peak': (_c.c_int, [
+        _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr]),
+    'emph_conv_pack_size': (_i64, [_i32, _i32, _i32]),
+    'emph_conv_pack': (_c.c_int, [_ptr, _i32, _i32, _i32, _ptr]),
+    'emph_conv1d': (_c.c_int, [
+        _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr, _i32,
+        _ptr, _i32, _i32, _i32, _ptr]),
+    'emph_segment_reduce': (_c.c_int, [
+        _ptr, _i64, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _i64, _i32, _ptr]),
+    'emph_output_layer': (_c.c_int, [
+        _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _i64, _i32, _i32,
+        _ptr, _ptr, _ptr]),
+    'emph_add_position': (_c.c_int, [
+        _ptr, _i64, _ptr, _i32, _i32, _ptr, _i32, _ptr, _i32, _i32, _ptr]),
+    'emph_attention': (_c.c_int, [
+        _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i32, _ptr, _i32, _ptr]),
+    'emph_add_layernorm': (_c.c_int, [
+        _ptr, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _f32, _i64, _i64, _ptr]),
+}
+
+_library = None
+
+
+class LibraryError(RuntimeError):
+    """The HIP library is missing, stale, or reported an error."""
+
+
+def library():
+    """Load (once) and return the shared library; raise if it is absent."""
+    global _library
+    if _library is None:
+        if not os.path.exists(LIBRARY_PATH):
+            raise LibraryError(
+                f'{LIBRARY_PATH} not found: build it with '
+                '`make -C emphases_amd/csrc` (or `__graft_entry__.build()`). '
+                'There is no CPU fallback for the HIP path.')
+        lib = ctypes.CDLL(LIBRARY_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            try:
+                function = getattr(lib, name)
+            except AttributeError as error:
+                raise LibraryError(
+                    f'{LIBRARY_PATH} does not export {name}') from error
+            function.restype = restype
+            function.argtypes = argtypes
+        if lib.emph_abi_version() != ABI_VERSION:
+            raise LibraryError(
+                f'ABI version {lib.emph_abi_version()} != {ABI_VERSION}; '
+                'rebuild the library')
+        _library = lib
+    return _library
+
+
+def require_gpu(device=None):
+    """Resolve the torch device of the HIP path or fail loudly."""
+    if not torch.cuda.is_available():
+        raise LibraryError(
+            'no MI355X/HIP device is visible; the prominence hot path has no '
+            'CPU fallback (the CPU restatement lives in oracle/ and is test '
+            'infrastructure only)')
+    if device is None:
+        return torch.device('cuda', torch.cuda.current_device())
+    if isinstance(device, int):
+        return torch.device('cuda', device)
+    return torch.device(device)
+
+
+def check(status, name):
+    if status != 0:
+        message = library().emph_last_error().decode('utf-8', 'replace')
+        raise LibraryError(f'{name} failed with status {status}: {message}')
+
+
+def pointer(tensor):
+    """Device (or host) address of a contiguous tensor / numpy array."""
+    if tensor is None:
+        return None
+    if isinstance(tensor, np.ndarray):
+        assert tensor.flags['C_CONTIGUOUS']
+        return tensor.ctypes.data
+    assert tensor.is_contiguous()
+    return tensor.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+###############################################################################
+# Host helpers (no GPU needed)
+###############################################################################
+
+
+def frontend_table():
+    """float32 table of Hann window + FFT twiddles (host, numpy)."""
+    lib = library()
+    table = np.zeros(lib.emph_frontend_table_size(), dtype=np.float32)
+    check(lib.emph_frontend_table_fill(table.ctypes.data),
+          'emph_frontend_table_fill')
+    return table
+
+
+def conv_pack(weight):
+    """Reorder a [c_out, c_in, k] (or [c_out, c_in]) weight into the MFMA
+    fragment order of emph_conv1d (host, numpy)."""
+    lib = library()
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    if weight.ndim == 2:
+        weight = weight[:, :, None]
+    c_out, c_in, kernel_size = weight.shape
+    pack = np.zeros(
+        lib.emph_conv_pack_size(c_out, c_in, kernel_size), dtype=np.float32)
+    check(lib.emph_conv_pack(
+        weight.ctypes.data, c_out, c_in, kernel_size, pack.ctypes.data),
+        'emph_conv_pack')
+    return pack

@@ -1,0 +1,250 @@
+/*
+ * emphases_hip.h — C ABI of the MI355X (gfx950) prominence-inference hot path.
+ *
+ * libemphases_hip.so replaces the ATen calls that interactiveaudiolab/emphases
+ * issues on its inference path (emphases/core.py:223-265 and below).  Every
+ * entry point is a plain `extern "C"` function over raw device pointers and
+ * sizes: no torch types cross this boundary.  The reference interface each one
+ * replaces is cited as file:line relative to the reference repository.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers on the current HIP device unless the
+ *     parameter name starts with `host_`.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *     work is enqueued asynchronously; nothing here synchronises the device
+ *     or allocates memory, so every call is hipGraph-capturable.
+ *   - Return value: 0 on success, a negative EMPH_E* code on a contract
+ *     violation, or a positive hipError_t if a launch failed.
+ *     `emph_last_error()` returns a message for the calling thread.
+ *   - Activations live in "packed ragged" form: a [channels, ld] row-major
+ *     float32 matrix whose column axis is the concatenation of all segments
+ *     (utterances or word-boundary chunks, emphases/core.py:361-418).  Each
+ *     segment keeps its OWN zero 'same' halo — results equal the reference's
+ *     one-utterance-at-a-time (B=1) semantics, not its padded-batch semantics
+ *     (model/layers/convolution.py:35-37 ignores lengths).
+ *
+ * Segment table: int64 [num_segments][EMPH_SEG_FIELDS], one row per segment.
+ */
+#ifndef EMPHASES_HIP_H
+#define EMPHASES_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMPH_ABI_VERSION 1
+
+/* Segment-table fields */
+enum {
+    EMPH_SEG_AUDIO_OFF = 0, /* first sample of the utterance in `audio`        */
+    EMPH_SEG_AUDIO_LEN = 1, /* samples in the utterance                        */
+    EMPH_SEG_START = 2,     /* chunk start, in the 432-zero-padded signal
+                               (emphases/core.py:357-358,395-401)              */
+    EMPH_SEG_LENGTH = 3,    /* chunk length in samples                         */
+    EMPH_SEG_FRAME_OFF = 4, /* first column of the chunk on the frame axis     */
+    EMPH_SEG_FRAMES = 5,    /* frames in the chunk                             */
+    EMPH_SEG_WORD_OFF = 6,  /* first column of the chunk on the word axis      */
+    EMPH_SEG_WORDS = 7,     /* words in the chunk                              */
+    EMPH_SEG_FIELDS = 8
+};
+
+/* Which axis of the segment table a ragged op walks */
+enum { EMPH_AXIS_FRAMES = 0, EMPH_AXIS_WORDS = 1 };
+
+/* Activations (emphases/config/defaults.py:181 and config/hparam-search/) */
+enum {
+    EMPH_ACT_NONE = 0,
+    EMPH_ACT_RELU = 1,
+    EMPH_ACT_GELU = 2,      /* exact erf form, torch.nn.GELU default          */
+    EMPH_ACT_SILU = 3,
+    EMPH_ACT_LEAKY_RELU = 4 /* slope 0.01, torch.nn.LeakyReLU default         */
+};
+
+/* Word-boundary reductions (emphases/core.py:426-469) */
+enum {
+    EMPH_REDUCE_SUM = 0,
+    EMPH_REDUCE_AVERAGE = 1,
+    EMPH_REDUCE_MAX = 2,
+    EMPH_REDUCE_CENTER = 3
+};
+
+/* Postprocess (emphases/core.py:335-342) */
+enum { EMPH_POST_NONE = 0, EMPH_POST_SIGMOID = 1, EMPH_POST_CLAMP01 = 2 };
+
+/* Error codes */
+enum {
+    EMPH_OK = 0,
+    EMPH_EINVAL = -1,   /* bad argument (null pointer, unsupported size)       */
+    EMPH_ERANGE = -2    /* size outside what the kernels are built for         */
+};
+
+int emph_abi_version(void);
+const char* emph_last_error(void);
+
+/* ------------------------------------------------------------------------ */
+/* Front-end: framed log-mel (+ optional A-weighted loudness row)            */
+/* ------------------------------------------------------------------------ */
+
+/* Number of floats in the constant table consumed by emph_logmel():
+ * periodic Hann window [1024], FFT twiddles.  Layout is private to the
+ * library; fill it on the host once and upload it. */
+int64_t emph_frontend_table_size(void);
+
+/* Fill `host_table` (emph_frontend_table_size() floats), computed in double
+ * precision.  Replaces torch.hann_window (emphases/data/preprocess/mels.py:
+ * 19-29) and the FFT plan inside torch.stft (mels.py:39-47). */
+int emph_frontend_table_fill(float* host_table);
+
+/* Log-mel features of every segment.
+ *
+ * Replaces, per chunk: F.pad(audio,(432,432)) + slice (emphases/core.py:
+ * 357-358,401), reflect pad (mels.py:31-36), torch.stft(1024, hop 160,
+ * periodic Hann, center=False) (mels.py:39-48), sqrt(re^2+im^2+1e-6)
+ * (mels.py:51), mel projection + log(clamp(.,1e-5)) (mels.py:94-109) and the
+ * optional (x+10)/10 (mels.py:57-58) — none of it materialised.
+ *
+ *   audio        float32 [*]        all utterances back to back
+ *   seg          int64 [n_seg][8]   segment table
+ *   tiles        int32 [n_tiles][2] (segment, first frame) per 32-frame block
+ *   table        float32            from emph_frontend_table_fill
+ *   mel_start/mel_count/mel_offset  int32 [80] run of each filterbank row
+ *   mel_values   float32 [nnz]      run values (librosa.filters.mel restated)
+ *   out          float32 [rows, ld] rows 0..79 receive the mel rows when
+ *                                   `mel_row >= 0` (row index of the first)
+ *   loud_row     row that receives A-weighted loudness, or -1
+ *   seg_peak     float32 [n_seg]    per-chunk max |X|^2 from
+ *                                   emph_frontend_peak (loudness only)
+ *   a_weights    float32 [513]      A-weighting minus REF_DB (loudness only)
+ *   normalize    0/1                emphases NORMALIZE switch
+ */
+int emph_logmel(const float* audio, const int64_t* seg, const int32_t* tiles,
+                int32_t n_tiles, const float* table, const int32_t* mel_start,
+                const int32_t* mel_count, const int32_t* mel_offset,
+                const float* mel_values, int32_t mel_nnz, float* out,
+                int64_t ld, int32_t mel_row, int32_t loud_row,
+                const float* seg_peak, const float* a_weights,
+                int32_t normalize, void* stream);
+
+/* Per-chunk max power spectrum value, needed by librosa.amplitude_to_db's
+ * top_db=80 floor, which is relative to the max over the WHOLE chunk
+ * (emphases/data/preprocess/loudness.py:84-93).  `seg_peak` float32 [n_seg]
+ * must be zeroed by the caller before the launch. */
+int emph_frontend_peak(const float* audio, const int64_t* seg,
+                       const int32_t* tiles, int32_t n_tiles,
+                       const float* table, float* seg_peak, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Conv1d 'same' (+ bias + activation) over ragged segments, fp32 MFMA       */
+/* ------------------------------------------------------------------------ */
+
+/* Number of floats of the MFMA-fragment-ordered weight pack for a Conv1d /
+ * Linear weight [c_out, c_in, k]. */
+int64_t emph_conv_pack_size(int32_t c_out, int32_t c_in, int32_t kernel_size);
+
+/* Reorder a torch-layout weight [c_out][c_in][k] (host) into the pack. */
+int emph_conv_pack(const float* host_weight, int32_t c_out, int32_t c_in,
+                   int32_t kernel_size, float* host_pack);
+
+/* y = act(conv1d(x, w, padding='same') + b) independently per segment.
+ *
+ * Replaces torch.nn.Conv1d(padding='same') + activation (emphases/model/
+ * core.py:17-21,93; model/layers/convolution.py:25-30) and, with
+ * kernel_size 1, torch.nn.Linear inside nn.TransformerEncoderLayer
+ * (model/layers/transformer.py:18-23).
+ *
+ *   x     float32 [c_in, ldx]   y  float32 [c_out, ldy]
+ *   axis  EMPH_AXIS_FRAMES or EMPH_AXIS_WORDS (which columns of `seg`)
+ *   tiles int32 [n_tiles][2]    (segment, first position), block = tile_n
+ *   tile_n 16, 32 or 64 positions per tile
+ *   transpose_out  0: y is [c_out, ldy];  1: y is [ldy, c_out] (position-major)
+ */
+int emph_conv1d(const float* x, int64_t ldx, float* y, int64_t ldy,
+                const float* pack, const float* bias, int32_t c_in,
+                int32_t c_out, int32_t kernel_size, int32_t activation,
+                const int64_t* seg, int32_t axis, const int32_t* tiles,
+                int32_t n_tiles, int32_t tile_n, int32_t transpose_out,
+                void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Frame -> word resampling                                                  */
+/* ------------------------------------------------------------------------ */
+
+/* out[:, word] = reduce(x[:, start:end]) for every word of every segment.
+ *
+ * Replaces the per-word Python loop of emphases.downsample (emphases/core.py:
+ * 426-469): one slice + reduce + copy per word, plus a host sync.
+ *
+ *   x            float32 [channels, ldx]  frame axis
+ *   bounds       int32 [2][ldw]           chunk-relative (start, end) frames on
+ *                                         the word axis (row 0 starts, row 1 ends)
+ *   out          float32 [channels, ldw]  word axis
+ *   word_segment int32 [total_words]      segment of each word column, -1 for
+ *                                         alignment padding columns
+ * Empty words give 0 (sum) or NaN (average) like the reference; `end` beyond
+ * the chunk is truncated like a Python slice.  The reference raises for an
+ * empty word under 'max' and an out-of-range 'center'; callers check that on
+ * the host (the kernel writes -inf / 0 there).
+ */
+int emph_segment_reduce(const float* x, int64_t ldx, const int32_t* bounds,
+                        float* out, int64_t ldw, int32_t channels,
+                        const int64_t* seg, const int32_t* word_segment,
+                        int64_t total_words, int32_t mode, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Output projection + postprocess                                           */
+/* ------------------------------------------------------------------------ */
+
+/* logits = conv1d(x, w[1, c, k], 'same') + b; scores = post(logits), per
+ * column of the packed axis.  Replaces output_layer (emphases/model/core.py:
+ * 33-37,138) and emphases.postprocess (emphases/core.py:335-342).  `weight`
+ * is the plain torch layout [1][c][k] on the device; `logits` / `scores` may
+ * be NULL; `position_segment` as `word_segment` above. */
+int emph_output_layer(const float* x, int64_t ldx, const float* weight,
+                      const float* bias, int32_t channels,
+                      int32_t kernel_size, const int64_t* seg,
+                      const int32_t* position_segment, int64_t total,
+                      int32_t axis, int32_t post, float* logits,
+                      float* scores, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Transformer blocks (emphases/model/layers/transformer.py:13-52)           */
+/* ------------------------------------------------------------------------ */
+
+/* x[c, pos] += table[pos_in_segment][c]  (PositionalEncoding.forward,
+ * transformer.py:51-52; dropout is the identity at inference).  `table` is
+ * float32 [max_positions][channels]; tiles are blocks of `tile_n` positions. */
+int emph_add_position(float* x, int64_t ldx, const float* table,
+                      int32_t channels, int32_t max_positions,
+                      const int64_t* seg, int32_t axis, const int32_t* tiles,
+                      int32_t n_tiles, int32_t tile_n, void* stream);
+
+/* Multi-head self-attention core: softmax(Q K^T / sqrt(d)) V per segment and
+ * head, never materialising the score matrix.  Replaces the attention inside
+ * nn.MultiheadAttention (transformer.py:18-23; key-padding mask all-false at
+ * inference, core.py:321-328).
+ *
+ *   qk   float32 [2*channels, ld]   rows 0..c-1 = Q, c..2c-1 = K
+ *   v    float32 [ld, channels]     position-major V
+ *   out  float32 [channels, ld]
+ *   tiles int32 [n_tiles][2]        (segment, first query), block = 64 queries
+ * Head dimension (channels / heads) must be 32, 40 or 64.
+ */
+int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
+                   int32_t channels, int32_t heads, const int64_t* seg,
+                   int32_t axis, const int32_t* tiles, int32_t n_tiles,
+                   void* stream);
+
+/* y = LayerNorm(x + r) over channels for columns [first_column,
+ * first_column + columns) (post-LN residual of nn.TransformerEncoderLayer,
+ * transformer.py:18-23; eps 1e-5).  channels <= 128. */
+int emph_add_layernorm(const float* x, const float* r, float* y, int64_t ld,
+                       int32_t channels, const float* gamma,
+                       const float* beta, float eps, int64_t first_column,
+                       int64_t columns, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMPHASES_HIP_H */
