@@ -1,0 +1,214 @@
+"""Benchmark of the prominence-inference hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path — packed audio already resident in HBM ->
+log-mel -> conv frame encoder -> word-boundary reduce -> word decoder ->
+scores — over one ragged batch of BASELINE.json's configs[1]: 64 synthetic
+10 s / 16 kHz utterances with random alignments, conv config, bundled
+checkpoint, per GPU (weak scaling: every rank owns its own 64 utterances and
+the only exchange is an RCCL all_gather of the per-word scores).
+
+Prints ONE JSON line on rank 0 with BASELINE.json's metric (utterances/s,
+whole job), the roofline of the dominant kernel (fp32-MFMA conv1d, measured
+live with HIP events on the launch stream) and the CPU oracle timed on the
+host cores beside it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import emphases_amd  # noqa: E402
+from emphases_amd import batch, config as cfg, runtime, synth  # noqa: E402
+
+UTTERANCES = 64
+FRAMES = 1000                 # 10 s at 100 frames/s
+PEAK_FP32_MFMA = 157.3        # TFLOP/s, MI355X_MICROARCH.md (dense, f32 in)
+
+
+def parse_args():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--gpus', type=int, default=1)
+    parser.add_argument('--steps', type=int, default=50)
+    parser.add_argument('--warmup', type=int, default=10)
+    parser.add_argument('--config', default='conv',
+                        choices=['conv', 'transformer'])
+    parser.add_argument('--tile', type=int, default=None)
+    parser.add_argument('--no-cpu-baseline', action='store_true')
+    return parser.parse_args()
+
+
+def workload(rank, count=UTTERANCES, frames=FRAMES):
+    """Synthetic utterances `rank*count ..`."""
+    first = rank * count
+    audios = [synth.audio(first + i, frames) for i in range(count)]
+    bounds = [synth.word_frames(first + i, frames) for i in range(count)]
+    alignments = [
+        emphases_amd.Alignment.from_frames(b, synth.word_names(b.shape[1]))
+        for b in bounds]
+    return audios, alignments, bounds
+
+
+def build_plan(audios, alignments):
+    lengths = [a.shape[1] for a in audios]
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+    segments = []
+    for index, (alignment, length) in enumerate(zip(alignments, lengths)):
+        segments.extend(batch.chunk_utterance(alignment, length, None, index))
+    return batch.Plan(segments, offsets, lengths)
+
+
+def cpu_baseline(audios, bounds, seconds=12.0):
+    """The CPU oracle (port of the reference's op sequence, B=1 loop exactly
+    like `emphases/core.py:169-179`) on this box's host cores."""
+    from oracle import prominence as oracle
+    from emphases_amd import weights
+    state = {k: torch.from_numpy(v) for k, v in weights.load().items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    words = [[(int(s) / 100., int(e) / 100.) for s, e in b.T] for b in bounds]
+    tensors = [torch.from_numpy(a) for a in audios]
+    oracle.from_alignment_and_audio(words[0], tensors[0], state)   # warm up
+    done = 0
+    start = time.perf_counter()
+    while time.perf_counter() - start < seconds:
+        index = done % len(tensors)
+        oracle.from_alignment_and_audio(words[index], tensors[index], state)
+        done += 1
+    elapsed = time.perf_counter() - start
+    return {
+        'value': done / elapsed, 'unit': 'utterances/s', 'cores': cores,
+        'kind': 'port',
+        'sample': f'{done} x 10 s utterances in {elapsed:.1f} s, one at a '
+                  f'time (B=1) through oracle/prominence.py, torch CPU fp32, '
+                  f'{cores} threads'}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        torch.distributed.init_process_group(
+            'nccl', rank=rank, world_size=world, device_id=device)
+
+    config = cfg.DEFAULT if args.config == 'conv' else \
+        cfg.Config(architecture='transformer')
+    state = None if args.config == 'conv' else \
+        emphases_amd.weights.random_state(config, seed=0)
+    engine = emphases_amd.engine.Engine(
+        config, state, device, conv_tile=args.tile)
+
+    audios, alignments, bounds = workload(rank)
+    plan = build_plan(audios, alignments)
+    packed = torch.cat(
+        [torch.from_numpy(a).reshape(-1) for a in audios]).to(device)
+    meta = engine.upload(plan)
+    columns = torch.from_numpy(plan.word_columns()).to(device)
+    gathered = [
+        torch.empty(plan.total_words, dtype=torch.float32, device=device)
+        for _ in range(world)] if world > 1 else None
+
+    def step():
+        scores, _ = engine.forward(packed, plan, meta)
+        if world > 1:
+            # every rank's utterances have the same word counts only by
+            # construction of this synthetic workload; pad to the max otherwise
+            torch.distributed.all_gather(gathered, scores[columns])
+        return scores
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    start = time.perf_counter()
+    for _ in range(args.steps):
+        scores = step()
+    barrier()
+    elapsed = time.perf_counter() - start
+    if world > 1:
+        slowest = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(
+            slowest, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(slowest.item())
+
+    # Dominant kernel, timed live with HIP events on the launch stream
+    engine.timers = []
+    for _ in range(min(args.steps, 10)):
+        engine.forward(packed, plan, meta)
+    torch.cuda.synchronize()
+    kernels = {}
+    for name, flops, begin, end in engine.timers:
+        entry = kernels.setdefault(name, [0, 0., 0.])
+        entry[0] += 1
+        entry[1] += begin.elapsed_time(end) * 1e-3
+        entry[2] += flops
+    engine.timers = None
+    dominant = max(kernels, key=lambda name: kernels[name][1])
+    launches, seconds, flops = kernels[dominant]
+    achieved = flops / seconds / 1e12
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        total_utterances = UTTERANCES * world
+        result = {
+            'metric': 'utterances/s (10 s @16 kHz) whole-node',
+            'value': total_utterances * args.steps / elapsed,
+            'unit': 'utterances/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': (
+                    f'{UTTERANCES} synthetic 10 s 16 kHz utterances per GPU, '
+                    f'{args.config} config, random word alignments, ragged '
+                    'batch with per-utterance (B=1) semantics '
+                    '(BASELINE.json configs[1])'),
+                'utterances_per_gpu': UTTERANCES, 'frames_per_gpu':
+                    plan.total_frames, 'words_per_gpu': plan.total_words,
+                'conv_tile': meta['tile'],
+                'parallelism': f'utterance-sharded x{world}'},
+            'frames_per_s_per_gpu': plan.total_frames * args.steps / elapsed,
+            'roofline': {
+                'bound': 'mfma', 'kernel': dominant,
+                'achieved': achieved, 'peak': PEAK_FP32_MFMA,
+                'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA,
+                'avg_launch_us': seconds / launches * 1e6,
+                'share_of_step': seconds / min(args.steps, 10) /
+                    (elapsed / args.steps),
+                'traffic': None},
+            'kernels_us_per_step': {
+                name: value[1] / min(args.steps, 10) * 1e6
+                for name, value in kernels.items()},
+        }
+        check = float(scores[columns].sum().item())
+        result['checksum'] = check
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(audios, bounds)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

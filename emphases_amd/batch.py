@@ -25,7 +25,8 @@ from . import runtime
 
 ALIGN = 16     # column alignment of every segment on the packed axes
 LEAD = 16      # unused columns before the first segment (halo reads stay inside)
-TAIL = 64      # unused columns after the last segment
+TAIL = 128     # unused columns after the last segment (a 64-wide tile of the
+               # last segment may read its halo past the end)
 
 
 @dataclasses.dataclass
@@ -92,14 +93,18 @@ def _round_up(value, multiple):
     return (value + multiple - 1) // multiple * multiple
 
 
-def _tiles(counts, block):
-    """(segment, first position) of every `block`-wide tile, int32 [n, 2]."""
-    per_segment = (np.asarray(counts, dtype=np.int64) + block - 1) // block
+def _tiles(counts, offsets, block):
+    """Tile table int32 [n, 4]: (segment, first position, segment's first
+    column, segment's positions) of every `block`-wide tile."""
+    counts = np.asarray(counts, dtype=np.int64)
+    per_segment = (counts + block - 1) // block
     total = int(per_segment.sum())
     segment = np.repeat(np.arange(len(counts), dtype=np.int64), per_segment)
     first = np.arange(total, dtype=np.int64) - np.repeat(
         np.cumsum(per_segment) - per_segment, per_segment)
-    return np.stack([segment, first * block], axis=1).astype(np.int32)
+    return np.stack(
+        [segment, first * block, np.asarray(offsets, dtype=np.int64)[segment],
+         counts[segment]], axis=1).astype(np.int32)
 
 
 class Plan:
@@ -155,8 +160,10 @@ class Plan:
     def tiles(self, axis, block):
         key = (axis, block)
         if key not in self._tiles:
-            counts = self.frames if axis == runtime.AXIS_FRAMES else self.words
-            self._tiles[key] = _tiles(counts, block)
+            if axis == runtime.AXIS_FRAMES:
+                self._tiles[key] = _tiles(self.frames, self.frame_off, block)
+            else:
+                self._tiles[key] = _tiles(self.words, self.word_off, block)
         return self._tiles[key]
 
     def word_columns(self):

@@ -55,12 +55,28 @@ __device__ __forceinline__ Span load_span(const int64_t* seg, int segment,
     return span;
 }
 
+// One row of a tile table: int32 {segment, first position, first column of the
+// segment on the walked axis, positions in the segment}.
+struct Tile {
+    int segment;
+    int first;
+    int offset;
+    int count;
+};
+
+__device__ __forceinline__ Tile load_tile(const int32_t* tiles, int index) {
+    const int4 row = reinterpret_cast<const int4*>(tiles)[index];
+    return Tile{row.x, row.y, row.z, row.w};
+}
+
 // LDS traffic between lanes of ONE wave: DS operations of a wave execute in
-// program order, so only the compiler has to be kept from reordering.
+// program order, so only the compiler has to be kept from reordering them.
+// (A wavefront-scope release/acquire fence would also do that, but hipcc lowers
+// it to s_waitcnt vmcnt(0): every pending global store would have to retire
+// first — 2 us per use in a store epilogue.)
 __device__ __forceinline__ void wave_lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 }  // namespace emph

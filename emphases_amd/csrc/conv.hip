@@ -6,38 +6,84 @@
 // kernel_size 1, the nn.Linear layers inside nn.TransformerEncoderLayer
 // (model/layers/transformer.py:18-23).
 //
-// Formulation: implicit GEMM  Y[c_out, n] = W[c_out, (tap, c_in)] X[(tap, c_in), n]
-// with M = c_out (16-row MFMA tiles), N = positions, K = taps * c_in.
-//   * One wave owns an [MB*16 x NB*16] output tile: MB*NB independent fp32
-//     accumulators keep the 32-cycle MFMA issue slot full (40-cycle dependent
-//     latency) from a single wave per SIMD.
-//   * The input tile (all c_in rows, NB*16 positions + halo) is staged once in
-//     LDS with 16-byte loads; each segment's own zero halo is applied there, so
-//     ragged batches keep the reference's B=1 edge semantics.  Row stride is
-//     16 (mod 32) floats, which makes the four k-rows of a B fragment hit
-//     disjoint banks (conflict-free ds_read_b32).
-//   * Weights are pre-packed on the host in A-fragment order
-//     [k-step][m-tile][lane]; a fragment load is one coalesced 256-byte
-//     global_load_dword that every wave on the chip shares through L2/L1.
+// Formulation: implicit GEMM  Y[c_out, n] = W[c_out, (c_in, tap)] X[(c_in, tap), n]
+// with M = c_out (16-row MFMA tiles), N = positions, K = c_in * taps.
+//   * A workgroup is four waves, one per SIMD; each wave owns an
+//     [MB*16 x NB*16] output tile: MB*NB independent fp32 accumulators keep the
+//     32-cycle MFMA issue slot full (40-cycle dependent latency).
+//   * The layer's weights, pre-packed on the host in A-fragment order
+//     [k-step][m-tile][lane], are staged ONCE per workgroup into LDS (76.8 KB
+//     for 80x80x3) and shared by the four waves; workgroups are persistent
+//     (grid-stride over groups of four tiles), so weight traffic out of L2 is
+//     per CU, not per tile.  An A fragment is one conflict-free ds_read_b32.
+//     Layers whose pack exceeds the LDS budget are staged in K chunks.
+//   * Activations go straight from L2/HBM to registers, no LDS stage: a B
+//     fragment (4 input rows x 16 positions) is one global_load_dword per lane,
+//     four 64-byte segments.  The K loop is software-pipelined through a
+//     ping-pong pair of register sets so that every load has one full
+//     iteration (U*MB*NB MFMAs, ~2000 cycles) to land.  Each segment's own
+//     zero halo is applied by loop-invariant per-lane masks, so ragged batches
+//     keep the reference's B=1 edge semantics.
 #include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
 
 #include "common.h"
+
+#ifndef EMPH_STAMP
+#define EMPH_STAMP(slot)   // in-kernel timeline stamps: tools/micro only
+#endif
 
 namespace emph {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x3u __attribute__((ext_vector_type(3), aligned(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-constexpr int kLead = 4;   // positions kept left of the tile (16-byte aligned halo)
+// N consecutive floats of one input row, loaded with the widest instructions.
+// The pieces are carried through the K loop AS vectors: when hipcc merges scalar
+// loads into a dwordx3 on its own, the loop-carried registers stay scalars and
+// it copies the tuple apart right after the load — a wait on a load that was
+// just issued, in every iteration.
+template <int N>
+struct Run;
+template <>
+struct Run<1> {
+    float a;
+    __device__ __forceinline__ void load(const float* p) { a = p[0]; }
+    __device__ __forceinline__ float get(int) const { return a; }
+};
+template <>
+struct Run<3> {
+    f32x3u a;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const f32x3u*>(p);
+    }
+    __device__ __forceinline__ float get(int i) const { return a[i]; }
+};
+template <>
+struct Run<5> {
+    f32x4u a;
+    float b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const f32x4u*>(p);
+        b = p[4];
+    }
+    __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b; }
+};
+template <>
+struct Run<7> {
+    f32x4u a;
+    f32x3u b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const f32x4u*>(p);
+        b = *reinterpret_cast<const f32x3u*>(p + 4);
+    }
+    __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
+};
 
 __host__ __device__ inline int round_up(int value, int multiple) {
     return (value + multiple - 1) / multiple * multiple;
-}
-
-// floats per staged row: tile + 2*kLead, rounded to 16 (mod 32)
-__host__ __device__ inline int stage_stride(int tile_n) {
-    int stride = tile_n + 2 * kLead;
-    while (stride % 32 != 16) ++stride;
-    return stride;
 }
 
 template <int ACT>
@@ -68,174 +114,402 @@ __host__ __device__ inline int padded_rows(int c_in, int ks) {
     return round_up(c_in, ks == 1 ? 16 : 8);
 }
 
-// grid = (n_tiles, m_tiles_padded / MB); block = 64 threads (one wave)
-template <int KS, int MB, int NB>
-__global__ __launch_bounds__(64) void conv1d_kernel(
-    const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
-    const float* __restrict__ pack, const float* __restrict__ bias, int c_in,
-    int c_out, int act, const int64_t* __restrict__ seg, int axis,
-    const int32_t* __restrict__ tiles, int transpose_out) {
-    constexpr int TN = NB * 16;
-    constexpr int HALO = (KS - 1) / 2;
-    constexpr int U = steps_per_iteration(KS);
-    extern __shared__ __align__(16) float xs[];
-    const int stride = stage_stride(TN);
-    const int lane = threadIdx.x;
-    const int rows = padded_rows(c_in, KS);
-    const int m_tiles = (c_out + 15) >> 4;
-    const int m_padded = gridDim.y * MB;
-    const int m_first = blockIdx.y * MB;
+constexpr int kConvLdsBudget = 136 * 1024;            // weights only
+// Waves per workgroup: two per SIMD for the narrow tiles (one wave's load
+// latency and epilogue hide under the other's MFMAs), one for the wide tile.
+__host__ __device__ constexpr int conv_waves(int nb) { return nb == 4 ? 4 : 8; }
+// floats per row of the epilogue patch; 16-byte aligned rows, and the two
+// 16-lane k-groups of a 32-lane ds_write phase land on disjoint banks
+__host__ __device__ constexpr int patch_stride(int nb) { return 16 * nb + 4; }
 
-    const int segment = tiles[2 * blockIdx.x];
-    const int t0 = tiles[2 * blockIdx.x + 1];
-    const Span span = load_span(seg, segment, axis);
-
-    // ---- stage x[:, t0 - kLead : t0 + TN + kLead) with the segment's zero halo
-    {
-        constexpr int quads = (TN + 2 * kLead) / 4;
-        const int total = rows * quads;
-        const float* base = x + span.offset + t0 - kLead;
-        for (int index = lane; index < total; index += 64) {
-            const int row = index / quads;
-            const int quad = index - row * quads;
-            const int t = t0 - kLead + 4 * quad;       // segment-relative
-            float4 value = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < c_in && t + 3 >= 0 && t < span.count) {
-                value = *reinterpret_cast<const float4*>(
-                    base + static_cast<int64_t>(row) * ldx + 4 * quad);
-                if (t < 0 || t + 3 >= span.count) {
-                    if (t < 0 || t >= span.count) value.x = 0.f;
-                    if (t + 1 < 0 || t + 1 >= span.count) value.y = 0.f;
-                    if (t + 2 < 0 || t + 2 >= span.count) value.z = 0.f;
-                    if (t + 3 < 0 || t + 3 >= span.count) value.w = 0.f;
-                }
+// Bias + activation + store of one [16 channels x NB*16 positions] patch held
+// in LDS (row stride patch_stride(NB) floats), by one wave.  Channel-major
+// output: a lane owns four consecutive positions of one channel (16-byte
+// store, 256-byte runs per row).  Position-major output (transpose): a lane
+// owns one position and writes its 16 channels as four 16-byte stores.
+template <int NB>
+__device__ __forceinline__ void store_patch(const float* patch, float* __restrict__ y,
+                                         int64_t ldy, const float* bias /* LDS, 16 */,
+                                         int channel0, int c_out, int act, Tile span,
+                                         int transpose) {
+    constexpr int stride = patch_stride(NB);
+    const int lane = threadIdx.x & 63;
+    const int t0 = span.first;
+    if (transpose) {
+        const int t = t0 + lane;
+        if (lane >= NB * 16 || t >= span.count) return;
+        float* out = y + (static_cast<int64_t>(span.offset) + t) * ldy + channel0;
+        const bool vector_ok = (ldy & 3) == 0 &&
+                               (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+#pragma unroll 1
+        for (int quad = 0; quad < 4; ++quad) {
+            float value[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                value[e] = activate(
+                    patch[(4 * quad + e) * stride + lane] + bias[4 * quad + e], act);
             }
-            *reinterpret_cast<float4*>(xs + row * stride + 4 * quad) = value;
-        }
-    }
-    __syncthreads();
-
-    f32x4 acc[MB][NB];
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int kk = lane >> 4;      // k index inside the k-step
-    const int col = lane & 15;     // A: row inside the m-tile, B: position
-    const int iterations = KS == 1 ? rows >> 3 : rows >> 2;
-    const int64_t step_stride = static_cast<int64_t>(m_padded) << 6;
-    const int64_t iteration_stride = step_stride * U;
-    const float* fragment = pack + (static_cast<int64_t>(m_first) << 6) + lane;
-    const float* b_base = xs + kk * stride + kLead + col - HALO;
-
-    // A fragments are prefetched one iteration (U*MB*NB MFMAs) ahead into the
-    // other register set of a ping-pong pair; sched_barrier pins the issue point
-    float a0[U][MB], a1[U][MB];
-    auto load_a = [&](float (&a)[U][MB]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int m = 0; m < MB; ++m) a[u][m] = fragment[u * step_stride + (m << 6)];
-    };
-    auto compute = [&](const float (&a)[U][MB]) {
-        float b[U][NB];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int n = 0; n < NB; ++n)
-                b[u][n] = KS == 1 ? b_base[4 * u * stride + n * 16]
-                                  : b_base[n * 16 + u];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int n = 0; n < NB; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                        a[u][m], b[u][n], acc[m][n], 0, 0, 0);
-        b_base += 4 * (KS == 1 ? U : 1) * stride;
-    };
-    load_a(a0);
-    for (int iteration = 0; iteration < iterations; iteration += 2) {
-        fragment += iteration_stride;
-        load_a(a1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a0);
-        __builtin_amdgcn_sched_barrier(0);
-        // the final pair re-reads its own fragments instead of branching
-        if (iteration + 2 < iterations) fragment += iteration_stride;
-        load_a(a0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- epilogue: bias + activation; D[row = 4*(lane>>4) + r][col = lane&15]
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {
-        if (m_first + m >= m_tiles) break;
-        const int channel = (m_first + m) * 16 + 4 * kk;
-        float b4[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            b4[r] = (bias != nullptr && channel + r < c_out) ? bias[channel + r] : 0.f;
-#pragma unroll
-        for (int n = 0; n < NB; ++n) {
-            const int t = t0 + n * 16 + col;
-            if (t >= span.count) continue;
-            const int64_t position = span.offset + t;
-            if (transpose_out) {
-                // y[position][channel .. channel+3]
-                float4 value;
-                value.x = activate(acc[m][n][0] + b4[0], act);
-                value.y = activate(acc[m][n][1] + b4[1], act);
-                value.z = activate(acc[m][n][2] + b4[2], act);
-                value.w = activate(acc[m][n][3] + b4[3], act);
-                float* out = y + position * ldy + channel;
-                if (channel + 3 < c_out) {
-                    *reinterpret_cast<float4*>(out) = value;
-                } else {
-                    if (channel < c_out) out[0] = value.x;
-                    if (channel + 1 < c_out) out[1] = value.y;
-                    if (channel + 2 < c_out) out[2] = value.z;
-                }
+            if (vector_ok && channel0 + 4 * quad + 3 < c_out) {
+                *reinterpret_cast<float4*>(out + 4 * quad) =
+                    make_float4(value[0], value[1], value[2], value[3]);
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (channel + r < c_out)
-                        y[static_cast<int64_t>(channel + r) * ldy + position] =
-                            activate(acc[m][n][r] + b4[r], act);
+                for (int e = 0; e < 4; ++e)
+                    if (channel0 + 4 * quad + e < c_out) out[4 * quad + e] = value[e];
+            }
+        }
+        return;
+    }
+    const int kk = lane >> 4;
+    const int col = lane & 15;
+    const bool vector_ok = (ldy & 3) == 0 && (span.offset & 3) == 0 &&
+                           (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+#pragma unroll 1
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = 4 * pass + kk;
+        const int channel = channel0 + row;
+        if (channel >= c_out) continue;
+        const float b = bias[row];
+#pragma unroll 1
+        for (int quad = col; quad < NB * 4; quad += 16) {
+            const int t = t0 + 4 * quad;
+            if (t >= span.count) continue;
+            float4 value = *reinterpret_cast<const float4*>(patch + row * stride + 4 * quad);
+            value.x = activate(value.x + b, act);
+            value.y = activate(value.y + b, act);
+            value.z = activate(value.z + b, act);
+            value.w = activate(value.w + b, act);
+            float* out = y + static_cast<int64_t>(channel) * ldy + span.offset + t;
+            if (vector_ok && t + 3 < span.count) {
+                *reinterpret_cast<float4*>(out) = value;
+            } else {
+                out[0] = value.x;
+                if (t + 1 < span.count) out[1] = value.y;
+                if (t + 2 < span.count) out[2] = value.z;
+                if (t + 3 < span.count) out[3] = value.w;
             }
         }
     }
 }
 
+// grid = (persistent workgroups, m_tiles_padded / MB); block = 64*WAVES threads
+//
+// Timeline of a workgroup (measured: a dependent global access costs 1-2 us on
+// a busy chip, so nothing that can be requested early waits for anything):
+//   tile descriptor -> request the weight pack (registers) and the first B
+//   fragments -> commit pack + bias to LDS -> barrier -> K loop -> epilogue out
+//   of LDS (no global reads).
+template <int KS, int MB, int NB>
+__global__ __launch_bounds__(64 * conv_waves(NB)) void conv1d_kernel(
+    const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+    const float* __restrict__ pack, const float* __restrict__ bias, int c_in,
+    int c_out, int act, const int32_t* __restrict__ tiles, int n_tiles,
+    int chunk_iterations, int patch_offset, int transpose_out) {
+    constexpr int WAVES = conv_waves(NB);
+    constexpr int THREADS = 64 * WAVES;
+    constexpr int kPatchStride = patch_stride(NB);
+    constexpr int HALO = (KS - 1) / 2;
+    constexpr int U = steps_per_iteration(KS);
+    constexpr int GROUPS = KS == 1 ? U : 1;    // 4-row groups per iteration
+    constexpr int kBatch = 10;                 // 16-byte loads in flight per lane
+    extern __shared__ __align__(16) float weights[];   // [steps][MB][64]
+    EMPH_STAMP(0);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kk = lane >> 4;      // k index inside the k-step
+    const int col = lane & 15;     // A: row inside the m-tile, B: position
+    const int rows = padded_rows(c_in, KS);
+    const int m_tiles = (c_out + 15) >> 4;
+    const int m_padded = gridDim.y * MB;
+    const int m_first = blockIdx.y * MB;
+    const int iterations = rows / (4 * GROUPS);
+    const int chunks = (iterations + chunk_iterations - 1) / chunk_iterations;
+    const int last_row = c_in - 1;
+    float* patch = weights + patch_offset + wave * (16 * kPatchStride);
+    float* bias_lds = weights + patch_offset + WAVES * (16 * kPatchStride);   // [MB*16]
+
+    // ---- weight staging: pack[step][m_padded][64] -> weights[step][MB][64].
+    // When the workgroup owns every m-tile the source is one contiguous run and
+    // goes through LDS-DMA (global_load_lds: 1 KiB per wave instruction, no
+    // VGPRs, every piece in flight at once — measured 1.1 us for 76.8 KB against
+    // 4.4 us through registers).  Otherwise rows are gathered through
+    // registers, kBatch requests a lane.
+    float4 staged[kBatch];
+    auto stage_issue = [&](int first, int count, int pass) {
+        const int quads = count * U * MB * 16;
+        if (m_padded == MB) {
+            if (pass) return;
+            const float* source = pack + static_cast<int64_t>(first) * U * MB * 64;
+            for (int base = wave * 64; base < quads; base += THREADS) {
+                if (base + 64 <= quads) {
+                    __builtin_amdgcn_global_load_lds(
+                        (const __attribute__((address_space(1))) void*)(
+                            source + 4 * (base + lane)),
+                        (__attribute__((address_space(3))) void*)(weights + 4 * base),
+                        16, 0, 0);
+                } else if (base + lane < quads) {
+                    reinterpret_cast<float4*>(weights)[base + lane] =
+                        reinterpret_cast<const float4*>(source)[base + lane];
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int index = (pass * kBatch + j) * THREADS + static_cast<int>(threadIdx.x);
+            if (index < quads) {
+                const int step = index / (MB * 16);
+                const int rest = index - step * (MB * 16);
+                staged[j] = reinterpret_cast<const float4*>(
+                    pack + ((static_cast<int64_t>(first) * U + step) * m_padded +
+                            m_first) * 64)[rest];
+            }
+        }
+    };
+    auto stage_commit = [&](int count, int pass) {
+        if (m_padded == MB) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0): LDS-DMA landed
+            return;
+        }
+        const int quads = count * U * MB * 16;
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int index = (pass * kBatch + j) * THREADS + static_cast<int>(threadIdx.x);
+            if (index < quads) reinterpret_cast<float4*>(weights)[index] = staged[j];
+        }
+    };
+    auto stage_passes = [&](int count) {
+        if (m_padded == MB) return 1;
+        return (count * U * MB * 16 + THREADS * kBatch - 1) / (THREADS * kBatch);
+    };
+
+    // ---- per-tile state
+    Tile span;
+    int t0 = 0;
+    bool active = false;
+    bool inside[U][NB];
+    const float* lane_base = x;
+    auto open_tile = [&](int group) {
+        const int tile = group * WAVES + wave;
+        active = tile < n_tiles;                      // wave-uniform
+        span = load_tile(tiles, active ? tile : 0);
+        t0 = span.first;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const int t = t0 + 16 * n + col + (KS == 1 ? 0 : u - HALO);
+                inside[u][n] = t >= 0 && t < span.count;
+            }
+        // B fragments are read at compile-time offsets from this address; what
+        // lies outside the segment (its halo, or a neighbour's columns) is
+        // valid memory by the layout contract and is masked to zero below
+        lane_base = x + span.offset + t0 + col - HALO;
+    };
+    // rows 4*group .. 4*group+3 of x; rows past c_in are clamped to a valid
+    // address here and zeroed by `row_inside` in select_b()
+    constexpr int RUN = KS == 1 ? 1 : KS;     // consecutive floats per fragment row
+    auto load_b = [&](Run<RUN> (&b)[GROUPS][NB], int iteration) {
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+            const int first = min(4 * (iteration * GROUPS + g), last_row & ~3);
+            const float* source = lane_base +
+                                  static_cast<int64_t>(first + min(kk, last_row - first)) * ldx;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) b[g][n].load(source + 16 * n);
+        }
+    };
+    // A fragments of one iteration: U*MB conflict-free LDS reads
+    auto load_a = [&](float (&a)[U][MB], int local) {
+        const float* fragment = weights + (local * U * MB << 6) + lane;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) a[u][m] = fragment[(u * MB + m) << 6];
+    };
+
+    float a0[U][MB];
+    Run<RUN> b0[GROUPS][NB];
+    const int groups_of_tiles = (n_tiles + WAVES - 1) / WAVES;
+    open_tile(blockIdx.x);
+    if (chunks == 1) {
+        if (!(transpose_out & 2)) stage_issue(0, iterations, 0);
+        if (active) load_b(b0, 0);
+        for (int index = threadIdx.x; index < MB * 16; index += THREADS) {
+            const int channel = m_first * 16 + index;
+            bias_lds[index] = (bias != nullptr && channel < c_out) ? bias[channel] : 0.f;
+        }
+        if (!(transpose_out & 2)) {
+            stage_commit(iterations, 0);
+            for (int pass = 1; pass < stage_passes(iterations); ++pass) {
+                stage_issue(0, iterations, pass);
+                stage_commit(iterations, pass);
+            }
+        }
+        __syncthreads();
+    } else {
+        for (int index = threadIdx.x; index < MB * 16; index += THREADS) {
+            const int channel = m_first * 16 + index;
+            bias_lds[index] = (bias != nullptr && channel < c_out) ? bias[channel] : 0.f;
+        }
+    }
+    EMPH_STAMP(1);
+
+    for (int group = blockIdx.x; group < groups_of_tiles; group += gridDim.x) {
+        if (group != static_cast<int>(blockIdx.x)) {
+            open_tile(group);
+            if (chunks == 1 && active) load_b(b0, 0);
+        }
+        f32x4 acc[MB][NB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // zero what lies outside the segment / past the last input row; this
+        // is also the point where the wave waits for the fragments to land
+        auto select_b = [&](float (&bv)[U][NB], const Run<RUN> (&b)[GROUPS][NB],
+                            int iteration) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int rows_group = iteration * GROUPS + (KS == 1 ? u : 0);
+                const bool row_inside = 4 * rows_group + kk < c_in;
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+                    bv[u][n] = (inside[u][n] && row_inside)
+                                   ? b[KS == 1 ? u : 0][n].get(KS == 1 ? 0 : u)
+                                   : 0.f;
+            }
+        };
+        auto compute = [&](const float (&a)[U][MB], const float (&bv)[U][NB]) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            a[u][m], bv[u][n], acc[m][n], 0, 0, 0);
+        };
+
+        for (int chunk = 0; chunk < chunks; ++chunk) {
+            const int first = chunk * chunk_iterations;
+            const int count = min(chunk_iterations, iterations - first);  // even
+            if (chunks > 1) {
+                __syncthreads();           // everyone is done with the old chunk
+                for (int pass = 0; pass < stage_passes(count); ++pass) {
+                    stage_issue(first, count, pass);
+                    stage_commit(count, pass);
+                }
+                __syncthreads();
+                if (active) load_b(b0, first);
+            }
+            if (!active || (transpose_out & 4)) continue;
+            // Software pipeline, one iteration deep: move the operands that
+            // have landed into their MFMA registers (select_b masks B; A is
+            // copied), immediately re-request the SAME registers for the next
+            // iteration (B from global memory, A from LDS), then run this
+            // iteration's MFMAs while those are in flight.  One load site per
+            // operand keeps the loop-carried registers stable (a two-site
+            // ping-pong made hipcc copy freshly loaded values at the loop end,
+            // i.e. wait for them there), and the waits sit where nothing newer
+            // is outstanding.  sched_barrier pins the three phases.
+            float av[U][MB], bv[U][NB];
+            load_a(a0, 0);
+            EMPH_STAMP(2);
+#pragma unroll 1
+            for (int local = 0; local < count; ++local) {
+                select_b(bv, b0, first + local);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m) av[u][m] = a0[u][m];
+                __builtin_amdgcn_sched_barrier(0);
+                // the last iteration re-reads itself instead of branching
+                const int next = min(local + 1, count - 1);
+                load_b(b0, first + next);
+                load_a(a0, next);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(av, bv);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!active) continue;
+        EMPH_STAMP(3);
+
+        // ---- epilogue.  The MFMA result layout D[row = 4*(lane>>4) + r]
+        // [col = lane&15] would store 64-byte pieces of four rows per
+        // instruction; each 16-row m-tile is instead turned through a
+        // wave-private LDS patch and written by store_patch() as full row runs.
+        // Only the register dump is unrolled: bias, activation and the stores
+        // are rolled loops, which keeps the kernel's code small.
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (m_first + m >= m_tiles) break;
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    patch[(4 * kk + r) * kPatchStride + 16 * n + col] = acc[m][n][r];
+            wave_lds_fence();
+            store_patch<NB>(patch, y, ldy, bias_lds + 16 * m, (m_first + m) * 16, c_out,
+                            act, span, transpose_out & 1);
+            wave_lds_fence();
+        }
+        EMPH_STAMP(4);
+    }
+}
+
+template <int KS, int MB, int NB>
+int launch_conv(int n_tiles, int m_blocks, size_t weight_bytes, hipStream_t s,
+                const float* x, int64_t ldx, float* y, int64_t ldy,
+                const float* pack, const float* bias, int c_in, int c_out, int act,
+                const int32_t* tiles, int chunk_iterations, int transpose_out) {
+    constexpr int WAVES = conv_waves(NB);
+    const size_t lds = weight_bytes +
+                       (WAVES * 16 * patch_stride(NB) + MB * 16) * sizeof(float);
+    const int patch_offset = static_cast<int>(weight_bytes / sizeof(float));
+    auto kernel = conv1d_kernel<KS, MB, NB>;
+    if (lds > 64 * 1024) {
+        hipError_t status = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (status != hipSuccess) {
+            set_error("emph_conv1d: cannot reserve %zu bytes of LDS: %s", lds,
+                      hipGetErrorString(status));
+            return static_cast<int>(status);
+        }
+    }
+    // persistent workgroups: LDS admits one (two for small packs) per CU
+    const int groups_of_tiles = (n_tiles + WAVES - 1) / WAVES;
+    const int resident = 256 * (lds > 80 * 1024 ? 1 : 2);
+    dim3 grid(groups_of_tiles < resident ? groups_of_tiles : resident, m_blocks);
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * WAVES), lds, s, x, ldx, y, ldy, pack,
+                       bias, c_in, c_out, act, tiles, n_tiles, chunk_iterations,
+                       patch_offset, transpose_out);
+    return check_launch("emph_conv1d");
+}
 
 template <int KS, int MB>
-int launch_conv_nb(int tile_n, dim3 grid, size_t lds, hipStream_t s,
-                   const float* x, int64_t ldx, float* y, int64_t ldy,
-                   const float* pack, const float* bias, int c_in, int c_out,
-                   int act, const int64_t* seg, int axis, const int32_t* tiles,
+int launch_conv_nb(int tile_n, int n_tiles, int m_blocks, size_t weight_bytes,
+                   hipStream_t s, const float* x, int64_t ldx, float* y,
+                   int64_t ldy, const float* pack, const float* bias, int c_in,
+                   int c_out, int act, const int32_t* tiles, int chunk_iterations,
                    int transpose_out) {
     switch (tile_n) {
         case 16:
-            hipLaunchKernelGGL((conv1d_kernel<KS, MB, 1>), grid, dim3(64), lds, s,
-                               x, ldx, y, ldy, pack, bias, c_in, c_out, act, seg,
-                               axis, tiles, transpose_out);
-            break;
+            return launch_conv<KS, MB, 1>(n_tiles, m_blocks, weight_bytes, s, x, ldx, y,
+                                          ldy, pack, bias, c_in, c_out, act, tiles,
+                                          chunk_iterations, transpose_out);
         case 32:
-            hipLaunchKernelGGL((conv1d_kernel<KS, MB, 2>), grid, dim3(64), lds, s,
-                               x, ldx, y, ldy, pack, bias, c_in, c_out, act, seg,
-                               axis, tiles, transpose_out);
-            break;
+            return launch_conv<KS, MB, 2>(n_tiles, m_blocks, weight_bytes, s, x, ldx, y,
+                                          ldy, pack, bias, c_in, c_out, act, tiles,
+                                          chunk_iterations, transpose_out);
         default:
-            hipLaunchKernelGGL((conv1d_kernel<KS, MB, 4>), grid, dim3(64), lds, s,
-                               x, ldx, y, ldy, pack, bias, c_in, c_out, act, seg,
-                               axis, tiles, transpose_out);
-            break;
+            return launch_conv<KS, MB, 4>(n_tiles, m_blocks, weight_bytes, s, x, ldx, y,
+                                          ldy, pack, bias, c_in, c_out, act, tiles,
+                                          chunk_iterations, transpose_out);
     }
-    return check_launch("emph_conv1d");
 }
 
 }  // namespace emph
@@ -287,11 +561,10 @@ int emph_conv_pack(const float* host_weight, int32_t c_out, int32_t c_in,
 int emph_conv1d(const float* x, int64_t ldx, float* y, int64_t ldy,
                 const float* pack, const float* bias, int32_t c_in,
                 int32_t c_out, int32_t kernel_size, int32_t activation,
-                const int64_t* seg, int32_t axis, const int32_t* tiles,
-                int32_t n_tiles, int32_t tile_n, int32_t transpose_out,
-                void* stream) {
+                const int32_t* tiles, int32_t n_tiles, int32_t tile_n,
+                int32_t transpose_out, void* stream) {
     if (n_tiles == 0) return EMPH_OK;
-    EMPH_REQUIRE(x && y && pack && seg && tiles, EMPH_EINVAL,
+    EMPH_REQUIRE(x && y && pack && tiles, EMPH_EINVAL,
                  "emph_conv1d: null pointer");
     EMPH_REQUIRE(kernel_size == 1 || kernel_size == 3 || kernel_size == 5 ||
                      kernel_size == 7,
@@ -304,21 +577,37 @@ int emph_conv1d(const float* x, int64_t ldx, float* y, int64_t ldy,
                  c_out);
     EMPH_REQUIRE(activation >= EMPH_ACT_NONE && activation <= EMPH_ACT_LEAKY_RELU,
                  EMPH_EINVAL, "emph_conv1d: unknown activation %d", activation);
-    EMPH_REQUIRE((ldx & 3) == 0, EMPH_EINVAL,
-                 "emph_conv1d: ldx must be a multiple of 4");
+    EMPH_REQUIRE(ldx > 0 && ldx < (int64_t{1} << 28), EMPH_ERANGE,
+                 "emph_conv1d: ldx out of range");
     const int m_tiles = (c_out + 15) / 16;
     const int mb = conv_m_block(c_out);
-    const size_t lds = static_cast<size_t>(padded_rows(c_in, kernel_size)) *
-                       stage_stride(tile_n) * sizeof(float);
-    dim3 grid(n_tiles, (m_tiles + mb - 1) / mb);
+    // K iterations resident in LDS at a time (even, see the ping-pong loop)
+    const int u = steps_per_iteration(kernel_size);
+    const int groups = kernel_size == 1 ? u : 1;
+    const int iterations = padded_rows(c_in, kernel_size) / (4 * groups);
+    const size_t iteration_bytes = static_cast<size_t>(u) * mb * 64 * sizeof(float);
+    int chunk_iterations = static_cast<int>(kConvLdsBudget / iteration_bytes) & ~1;
+    if (chunk_iterations > iterations) chunk_iterations = iterations;
+    const size_t weight_bytes = chunk_iterations * iteration_bytes;
+    const int m_blocks = (m_tiles + mb - 1) / mb;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    // experiment knob: EMPH_CONV_SKIP=2 skips weight staging, =4 skips the MFMA
+    // loop (results are wrong; timing only)
+    static const int skip = [] {
+        const char* text = getenv("EMPH_CONV_SKIP");
+        return text ? atoi(text) : 0;
+    }();
+    transpose_out = (transpose_out ? 1 : 0) | skip;
 #define EMPH_CONV(KS)                                                             \
-    return mb == 5 ? launch_conv_nb<KS, 5>(tile_n, grid, lds, s, x, ldx, y, ldy,  \
-                                           pack, bias, c_in, c_out, activation,  \
-                                           seg, axis, tiles, transpose_out)      \
-                   : launch_conv_nb<KS, 4>(tile_n, grid, lds, s, x, ldx, y, ldy,  \
-                                           pack, bias, c_in, c_out, activation,  \
-                                           seg, axis, tiles, transpose_out)
+    return mb == 5                                                                \
+               ? launch_conv_nb<KS, 5>(tile_n, n_tiles, m_blocks, weight_bytes, s, x, \
+                                       ldx, y, ldy, pack, bias, c_in, c_out,      \
+                                       activation, tiles, chunk_iterations,       \
+                                       transpose_out)                             \
+               : launch_conv_nb<KS, 4>(tile_n, n_tiles, m_blocks, weight_bytes, s, x, \
+                                       ldx, y, ldy, pack, bias, c_in, c_out,      \
+                                       activation, tiles, chunk_iterations,       \
+                                       transpose_out)
     switch (kernel_size) {
         case 1: EMPH_CONV(1);
         case 3: EMPH_CONV(3);

@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    const int segment = tiles[2 * blockIdx.x];
-    const int frame0 = tiles[2 * blockIdx.x + 1];
+    const int segment = tiles[EMPH_TILE_FIELDS * blockIdx.x];
+    const int frame0 = tiles[EMPH_TILE_FIELDS * blockIdx.x + 1];
     const int64_t* row = seg + static_cast<int64_t>(segment) * EMPH_SEG_FIELDS;
     const int64_t audio_off = row[EMPH_SEG_AUDIO_OFF];
     const int64_t audio_len = row[EMPH_SEG_AUDIO_LEN];

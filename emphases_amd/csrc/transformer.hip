@@ -26,11 +26,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // grid = n_tiles (blocks of `tile_n` positions); block = 256
 __global__ __launch_bounds__(256) void add_position_kernel(
     float* __restrict__ x, int64_t ldx, const float* __restrict__ table,
-    int channels, int max_positions, const int64_t* __restrict__ seg, int axis,
-    const int32_t* __restrict__ tiles, int tile_n) {
-    const int segment = tiles[2 * blockIdx.x];
-    const int t0 = tiles[2 * blockIdx.x + 1];
-    const Span span = load_span(seg, segment, axis);
+    int channels, int max_positions, const int32_t* __restrict__ tiles,
+    int tile_n) {
+    const Tile span = load_tile(tiles, blockIdx.x);
+    const int t0 = span.first;
     const int count = min(tile_n, span.count - t0);
     for (int index = threadIdx.x; index < channels * tile_n; index += 256) {
         const int c = index / tile_n;
@@ -78,7 +77,7 @@ template <int D>
 __global__ __launch_bounds__(64) void attention_kernel(
     const float* __restrict__ qk, const float* __restrict__ v,
     float* __restrict__ out, int64_t ld, int channels,
-    const int64_t* __restrict__ seg, int axis, const int32_t* __restrict__ tiles) {
+    const int32_t* __restrict__ tiles) {
     constexpr int QT = 4;                 // 16-query tiles per wave
     constexpr int KSTEPS = D / 4;         // k-steps of the QK^T product
     constexpr int MT = (D + 15) / 16;     // 16-row tiles of O^T
@@ -86,16 +85,15 @@ __global__ __launch_bounds__(64) void attention_kernel(
     const int col = lane & 15;
     const int kk = lane >> 4;
     const int head = blockIdx.y;
-    const int segment = tiles[2 * blockIdx.x];
-    const int q0 = tiles[2 * blockIdx.x + 1];
-    const Span span = load_span(seg, segment, axis);
+    const Tile span = load_tile(tiles, blockIdx.x);
+    const int q0 = span.first;
     const int length = span.count;
     const float scale = 1.f / sqrtf(static_cast<float>(D));
 
     const float* q_rows = qk + static_cast<int64_t>(head * D) * ld + span.offset;
     const float* k_rows =
         qk + static_cast<int64_t>(channels + head * D) * ld + span.offset;
-    const float* v_rows = v + span.offset * channels + head * D;
+    const float* v_rows = v + static_cast<int64_t>(span.offset) * channels + head * D;
 
     float bq[QT][KSTEPS];
 #pragma unroll
@@ -201,16 +199,15 @@ using namespace emph;
 extern "C" {
 
 int emph_add_position(float* x, int64_t ldx, const float* table, int32_t channels,
-                      int32_t max_positions, const int64_t* seg, int32_t axis,
-                      const int32_t* tiles, int32_t n_tiles, int32_t tile_n,
-                      void* stream) {
+                      int32_t max_positions, const int32_t* tiles,
+                      int32_t n_tiles, int32_t tile_n, void* stream) {
     if (n_tiles == 0) return EMPH_OK;
-    EMPH_REQUIRE(x && table && seg && tiles, EMPH_EINVAL,
+    EMPH_REQUIRE(x && table && tiles, EMPH_EINVAL,
                  "emph_add_position: null pointer");
     EMPH_REQUIRE(tile_n > 0 && channels > 0, EMPH_EINVAL, "emph_add_position: bad shape");
     hipLaunchKernelGGL(add_position_kernel, dim3(n_tiles), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, ldx, table, channels,
-                       max_positions, seg, axis, tiles, tile_n);
+                       max_positions, tiles, tile_n);
     return check_launch("emph_add_position");
 }
 
@@ -235,11 +232,10 @@ int emph_add_layernorm(const float* x, const float* r, float* y, int64_t ld,
 }
 
 int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
-                   int32_t channels, int32_t heads, const int64_t* seg,
-                   int32_t axis, const int32_t* tiles, int32_t n_tiles,
-                   void* stream) {
+                   int32_t channels, int32_t heads, const int32_t* tiles,
+                   int32_t n_tiles, void* stream) {
     if (n_tiles == 0) return EMPH_OK;
-    EMPH_REQUIRE(qk && v && out && seg && tiles, EMPH_EINVAL,
+    EMPH_REQUIRE(qk && v && out && tiles, EMPH_EINVAL,
                  "emph_attention: null pointer");
     EMPH_REQUIRE(heads > 0 && channels % heads == 0, EMPH_EINVAL,
                  "emph_attention: channels %d not divisible by heads %d", channels,
@@ -250,15 +246,15 @@ int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
     switch (d) {
         case 32:
             hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64), 0, s, qk, v, out, ld,
-                               channels, seg, axis, tiles);
+                               channels, tiles);
             break;
         case 40:
             hipLaunchKernelGGL(attention_kernel<40>, grid, dim3(64), 0, s, qk, v, out, ld,
-                               channels, seg, axis, tiles);
+                               channels, tiles);
             break;
         case 64:
             hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64), 0, s, qk, v, out, ld,
-                               channels, seg, axis, tiles);
+                               channels, tiles);
             break;
         default:
             set_error("emph_attention: head dimension %d not in {32, 40, 64}", d);

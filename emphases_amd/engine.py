@@ -14,6 +14,8 @@ of the batch at once, with per-chunk (B=1) edge semantics.  The reference
 keeps its model on function attributes of `infer` (`core.py:298-315`); here the
 cache is an explicit object.
 """
+import contextlib
+
 import numpy as np
 import torch
 
@@ -65,6 +67,9 @@ class Engine:
         self.device = runtime.require_gpu(device)
         self.lib = runtime.library()
         self.conv_tile = conv_tile
+        # when a list, every kernel launch is bracketed by HIP events on the
+        # launch stream: (name, algorithmic flops, start, end)
+        self.timers = None
         state = weights_module.load(state, config)
         self.state = state
         dev = self.device
@@ -152,7 +157,8 @@ class Engine:
         if self.device.type == 'cuda':
             pinned = pinned.pin_memory()
         device_buffer = pinned.to(self.device, non_blocking=True)
-        views = {'_buffer': device_buffer, '_pinned': pinned, 'tile': tile}
+        views = {'_buffer': device_buffer, '_pinned': pinned, 'tile': tile,
+                 'positions': (plan.total_frames, plan.total_words)}
         for name, (start, size) in offsets.items():
             views[name] = (device_buffer[start:start + size], size)
         return views
@@ -161,15 +167,37 @@ class Engine:
     # Kernel wrappers
     ###########################################################################
 
+    @contextlib.contextmanager
+    def _timed(self, name, flops=0.):
+        if self.timers is None:
+            yield
+            return
+        begin = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        begin.record()
+        yield
+        end.record()
+        self.timers.append((name, flops, begin, end))
+
     def _conv(self, layer, x, ldx, y, ldy, meta, axis, block, activation,
               transpose_out=False):
         tiles, size = meta[('tiles', axis, block)]
+        positions = meta['positions'][axis]
+        name = (f'conv1d_{"frames" if axis == runtime.AXIS_FRAMES else "words"}'
+                f'_{layer.c_in}x{layer.c_out}_k{layer.kernel_size}')
+        flops = 2. * layer.c_in * layer.c_out * layer.kernel_size * positions
+        with self._timed(name, flops):
+            self._conv_launch(layer, x, ldx, y, ldy, meta, axis, block,
+                              activation, transpose_out, tiles, size)
+
+    def _conv_launch(self, layer, x, ldx, y, ldy, meta, axis, block,
+                     activation, transpose_out, tiles, size):
         runtime.check(self.lib.emph_conv1d(
             x.data_ptr(), ldx, y.data_ptr(), ldy, layer.pack.data_ptr(),
             None if layer.bias is None else layer.bias.data_ptr(),
             layer.c_in, layer.c_out, layer.kernel_size,
-            runtime.ACTIVATIONS[activation], meta['table'][0].data_ptr(), axis,
-            tiles.data_ptr(), size // 2, block, int(transpose_out),
+            runtime.ACTIVATIONS[activation], tiles.data_ptr(),
+            size // runtime.TILE_FIELDS, block, int(transpose_out),
             runtime.stream()), 'emph_conv1d')
 
     def features(self, audio, plan, meta, out=None, extra_rows=None):
@@ -201,12 +229,15 @@ class Engine:
                 len(plan.segments), dtype=torch.float32, device=self.device)
             runtime.check(self.lib.emph_frontend_peak(
                 audio.data_ptr(), table.data_ptr(), tiles.data_ptr(),
-                size // 2, self.table.data_ptr(), peak.data_ptr(),
+                size // runtime.TILE_FIELDS, self.table.data_ptr(),
+                peak.data_ptr(),
                 runtime.stream()), 'emph_frontend_peak')
         if mel_row >= 0 or loud_row >= 0:
+          with self._timed('frontend_logmel'):
             runtime.check(self.lib.emph_logmel(
                 audio.data_ptr(), table.data_ptr(), tiles.data_ptr(),
-                size // 2, self.table.data_ptr(), self.mel_start.data_ptr(),
+                size // runtime.TILE_FIELDS, self.table.data_ptr(),
+                self.mel_start.data_ptr(),
                 self.mel_count.data_ptr(), self.mel_offset.data_ptr(),
                 self.mel_values.data_ptr(), self.mel_nnz, out.data_ptr(),
                 plan.ld_frames, mel_row, loud_row,
@@ -230,18 +261,21 @@ class Engine:
                 'smaller batch_size')
         runtime.check(self.lib.emph_add_position(
             x.data_ptr(), ld, self.position.data_ptr(), channels,
-            cfg.MAX_POSITIONS, table.data_ptr(), axis, att_tiles.data_ptr(),
-            att_size // 2, ATTENTION_BLOCK, runtime.stream()),
+            cfg.MAX_POSITIONS, att_tiles.data_ptr(),
+            att_size // runtime.TILE_FIELDS, ATTENTION_BLOCK, runtime.stream()),
             'emph_add_position')
         qk, v, attended, projected = scratch
         for layer in layers:
             self._conv(layer['qk'], x, ld, qk, ld, meta, axis, block, None)
             self._conv(layer['v'], x, ld, v, channels, meta, axis, block, None,
                        transpose_out=True)
-            runtime.check(self.lib.emph_attention(
+            with self._timed('attention', 4. * channels * float(
+                    (counts.astype(np.float64) ** 2).sum())):
+              runtime.check(self.lib.emph_attention(
                 qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld, channels,
-                config.heads, table.data_ptr(), axis, att_tiles.data_ptr(),
-                att_size // 2, runtime.stream()), 'emph_attention')
+                config.heads, att_tiles.data_ptr(),
+                att_size // runtime.TILE_FIELDS, runtime.stream()),
+                'emph_attention')
             self._conv(layer['out'], attended, ld, projected, ld, meta, axis,
                        block, None)
             runtime.check(self.lib.emph_add_layernorm(
@@ -317,7 +351,8 @@ class Engine:
         check_bounds(plan, config.downsample_method)
         wa, wb = zeros(channels, ld_w), zeros(channels, ld_w)
         table = meta['table'][0]
-        runtime.check(self.lib.emph_segment_reduce(
+        with self._timed('segment_reduce'):
+          runtime.check(self.lib.emph_segment_reduce(
             encoded.data_ptr(), ld_f, meta['bounds'][0].data_ptr(),
             wa.data_ptr(), ld_w, channels, table.data_ptr(),
             meta['word_segment'][0].data_ptr(), ld_w,
@@ -332,7 +367,8 @@ class Engine:
                 runtime.AXIS_WORDS, WORD_TILE)
         logits = zeros(ld_w)
         scores = zeros(ld_w)
-        runtime.check(self.lib.emph_output_layer(
+        with self._timed('output_layer'):
+          runtime.check(self.lib.emph_output_layer(
             decoded.data_ptr(), ld_w, self.output_weight.data_ptr(),
             self.output_bias.data_ptr(), channels, config.decoder_kernel_size,
             table.data_ptr(), meta['word_segment'][0].data_ptr(), ld_w,

@@ -13,10 +13,11 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
+TILE_FIELDS = 4
 (SEG_AUDIO_OFF, SEG_AUDIO_LEN, SEG_START, SEG_LENGTH, SEG_FRAME_OFF,
  SEG_FRAMES, SEG_WORD_OFF, SEG_WORDS) = range(8)
 AXIS_FRAMES, AXIS_WORDS = 0, 1
@@ -43,16 +44,16 @@ SIGNATURES = {
     'emph_conv_pack': (_c.c_int, [_ptr, _i32, _i32, _i32, _ptr]),
     'emph_conv1d': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr, _i32,
-        _ptr, _i32, _i32, _i32, _ptr]),
+        _i32, _i32, _ptr]),
     'emph_segment_reduce': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _i64, _i32, _ptr]),
     'emph_output_layer': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _i64, _i32, _i32,
         _ptr, _ptr, _ptr]),
     'emph_add_position': (_c.c_int, [
-        _ptr, _i64, _ptr, _i32, _i32, _ptr, _i32, _ptr, _i32, _i32, _ptr]),
+        _ptr, _i64, _ptr, _i32, _i32, _ptr, _i32, _i32, _ptr]),
     'emph_attention': (_c.c_int, [
-        _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i32, _ptr, _i32, _ptr]),
+        _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i32, _ptr]),
     'emph_add_layernorm': (_c.c_int, [
         _ptr, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _f32, _i64, _i64, _ptr]),
 }

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 1
+#define EMPH_ABI_VERSION 2
 
 /* Segment-table fields */
 enum {
@@ -52,6 +52,17 @@ enum {
 
 /* Which axis of the segment table a ragged op walks */
 enum { EMPH_AXIS_FRAMES = 0, EMPH_AXIS_WORDS = 1 };
+
+/* Tile table: int32 [num_tiles][EMPH_TILE_FIELDS], 16-byte aligned.  Ragged
+ * ops work on fixed-width blocks of positions of one segment on one axis; the
+ * row carries everything a block needs so that no kernel chases pointers. */
+enum {
+    EMPH_TILE_SEGMENT = 0, /* row of the segment table                        */
+    EMPH_TILE_FIRST = 1,   /* first position of the block inside the segment  */
+    EMPH_TILE_OFFSET = 2,  /* first column of the segment on the packed axis  */
+    EMPH_TILE_COUNT = 3,   /* positions in the segment                        */
+    EMPH_TILE_FIELDS = 4
+};
 
 /* Activations (emphases/config/defaults.py:181 and config/hparam-search/) */
 enum {
@@ -107,7 +118,7 @@ int emph_frontend_table_fill(float* host_table);
  *
  *   audio        float32 [*]        all utterances back to back
  *   seg          int64 [n_seg][8]   segment table
- *   tiles        int32 [n_tiles][2] (segment, first frame) per 32-frame block
+ *   tiles        int32 [n_tiles][4] tile table of the frame axis, 32-frame blocks
  *   table        float32            from emph_frontend_table_fill
  *   mel_start/mel_count/mel_offset  int32 [80] run of each filterbank row
  *   mel_values   float32 [nnz]      run values (librosa.filters.mel restated)
@@ -155,17 +166,15 @@ int emph_conv_pack(const float* host_weight, int32_t c_out, int32_t c_in,
  * (model/layers/transformer.py:18-23).
  *
  *   x     float32 [c_in, ldx]   y  float32 [c_out, ldy]
- *   axis  EMPH_AXIS_FRAMES or EMPH_AXIS_WORDS (which columns of `seg`)
- *   tiles int32 [n_tiles][2]    (segment, first position), block = tile_n
- *   tile_n 16, 32 or 64 positions per tile
+ *   tiles int32 [n_tiles][4]    tile table of the walked axis, block = tile_n
+ *   tile_n 16, 32 or 64 positions per tile (one wave each)
  *   transpose_out  0: y is [c_out, ldy];  1: y is [ldy, c_out] (position-major)
  */
 int emph_conv1d(const float* x, int64_t ldx, float* y, int64_t ldy,
                 const float* pack, const float* bias, int32_t c_in,
                 int32_t c_out, int32_t kernel_size, int32_t activation,
-                const int64_t* seg, int32_t axis, const int32_t* tiles,
-                int32_t n_tiles, int32_t tile_n, int32_t transpose_out,
-                void* stream);
+                const int32_t* tiles, int32_t n_tiles, int32_t tile_n,
+                int32_t transpose_out, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Frame -> word resampling                                                  */
@@ -217,8 +226,8 @@ int emph_output_layer(const float* x, int64_t ldx, const float* weight,
  * float32 [max_positions][channels]; tiles are blocks of `tile_n` positions. */
 int emph_add_position(float* x, int64_t ldx, const float* table,
                       int32_t channels, int32_t max_positions,
-                      const int64_t* seg, int32_t axis, const int32_t* tiles,
-                      int32_t n_tiles, int32_t tile_n, void* stream);
+                      const int32_t* tiles, int32_t n_tiles, int32_t tile_n,
+                      void* stream);
 
 /* Multi-head self-attention core: softmax(Q K^T / sqrt(d)) V per segment and
  * head, never materialising the score matrix.  Replaces the attention inside
@@ -228,13 +237,12 @@ int emph_add_position(float* x, int64_t ldx, const float* table,
  *   qk   float32 [2*channels, ld]   rows 0..c-1 = Q, c..2c-1 = K
  *   v    float32 [ld, channels]     position-major V
  *   out  float32 [channels, ld]
- *   tiles int32 [n_tiles][2]        (segment, first query), block = 64 queries
+ *   tiles int32 [n_tiles][4]        tile table, block = 64 queries
  * Head dimension (channels / heads) must be 32, 40 or 64.
  */
 int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
-                   int32_t channels, int32_t heads, const int64_t* seg,
-                   int32_t axis, const int32_t* tiles, int32_t n_tiles,
-                   void* stream);
+                   int32_t channels, int32_t heads, const int32_t* tiles,
+                   int32_t n_tiles, void* stream);
 
 /* y = LayerNorm(x + r) over channels for columns [first_column,
  * first_column + columns) (post-LN residual of nn.TransformerEncoderLayer,

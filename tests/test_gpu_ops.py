@@ -1,0 +1,337 @@
+"""GPU: every C-ABI operator on seeded random ragged inputs against a plain
+torch CPU fp32 reference of the same op (one segment at a time, B=1)."""
+import numpy as np
+import pytest
+import torch
+
+from emphases_amd import batch, runtime, synth
+
+pytestmark = pytest.mark.gpu
+
+DEVICE = 'cuda:0'
+
+
+def ragged_plan(frames, words_per_segment=None, seed=0):
+    segments = []
+    for index, count in enumerate(frames):
+        if words_per_segment is None:
+            bounds = synth.word_frames(seed + index, count, 1, 25) \
+                if count else np.zeros((2, 0), dtype=np.int64)
+        else:
+            bounds = words_per_segment[index]
+        segments.append(batch.Segment(
+            index, 0, bounds.shape[1], 0, 0, count, bounds))
+    return batch.Plan(segments, [0] * len(frames), [0] * len(frames))
+
+
+class Meta:
+    def __init__(self, plan, requests):
+        host, offsets = plan.pack_metadata(requests)
+        self.buffer = torch.from_numpy(host).to(DEVICE)
+        self.offsets = offsets
+
+    def view(self, name):
+        start, size = self.offsets[name]
+        return self.buffer[start:start + size], size
+
+
+def random_packed(rows, plan, axis, seed):
+    ld = plan.ld_frames if axis == runtime.AXIS_FRAMES else plan.ld_words
+    values = synth.weights(seed, (rows, ld), 1.0)
+    return torch.from_numpy(values)
+
+
+def spans(plan, axis):
+    if axis == runtime.AXIS_FRAMES:
+        return list(zip(plan.frame_off, plan.frames))
+    return list(zip(plan.word_off, plan.words))
+
+
+###############################################################################
+# conv1d
+###############################################################################
+
+
+ACTIVATIONS = {
+    None: lambda x: x, 'relu': torch.relu,
+    'gelu': torch.nn.functional.gelu, 'silu': torch.nn.functional.silu,
+    'leaky_relu': lambda x: torch.nn.functional.leaky_relu(x, 0.01)}
+
+
+@pytest.mark.parametrize('c_in,c_out,kernel_size,activation,tile', [
+    (80, 80, 3, 'relu', 64), (80, 80, 3, 'relu', 32), (80, 80, 3, None, 16),
+    (80, 80, 5, 'gelu', 32), (80, 80, 7, 'silu', 64), (80, 80, 1, None, 32),
+    (64, 64, 3, 'leaky_relu', 32), (128, 128, 3, 'relu', 32),
+    (81, 80, 3, None, 32), (80, 160, 1, None, 64), (80, 240, 1, 'relu', 16),
+    (80, 1, 3, None, 16), (3, 7, 5, 'relu', 16)])
+def test_conv1d(c_in, c_out, kernel_size, activation, tile):
+    lib = runtime.library()
+    plan = ragged_plan([200, 1, 17, 64, 65, 3, 130])
+    axis = runtime.AXIS_FRAMES
+    meta = Meta(plan, [(axis, tile)])
+    x = random_packed(c_in, plan, axis, 11)
+    x[:, :batch.LEAD] = float('nan')           # padding must never be read as data
+    weight = synth.weights(5, (c_out, c_in, kernel_size), 0.2)
+    bias = synth.weights(6, (c_out,), 0.5)
+    y = torch.full((c_out, plan.ld_frames), 7.0, device=DEVICE)
+    pack = torch.from_numpy(runtime.conv_pack(weight)).to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    x_dev, bias_dev = x.to(DEVICE), torch.from_numpy(bias).to(DEVICE)
+    runtime.check(lib.emph_conv1d(
+        x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
+        pack.data_ptr(), bias_dev.data_ptr(), c_in,
+        c_out, kernel_size, runtime.ACTIVATIONS[activation],
+        tiles.data_ptr(), size // 4, tile, 0, None), 'emph_conv1d')
+    y = y.cpu()
+    for off, count in spans(plan, axis):
+        want = ACTIVATIONS[activation](torch.nn.functional.conv1d(
+            x[None, :, off:off + count], torch.from_numpy(weight),
+            torch.from_numpy(bias), padding=(kernel_size - 1) // 2))[0]
+        got = y[:, off:off + count]
+        assert torch.isfinite(got).all()
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) < 2e-5 * scale
+    # columns outside every segment are left untouched
+    assert float(y[:, :batch.LEAD].min()) == 7.0
+
+
+def test_conv1d_transposed_output():
+    lib = runtime.library()
+    plan = ragged_plan([100, 33])
+    axis, tile = runtime.AXIS_FRAMES, 32
+    meta = Meta(plan, [(axis, tile)])
+    x = random_packed(80, plan, axis, 2)
+    weight = synth.weights(3, (80, 80, 1), 0.2)
+    bias = synth.weights(4, (80,), 0.5)
+    y = torch.zeros((plan.ld_frames, 80), device=DEVICE)
+    pack = torch.from_numpy(runtime.conv_pack(weight)).to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    x_dev, bias_dev = x.to(DEVICE), torch.from_numpy(bias).to(DEVICE)
+    runtime.check(lib.emph_conv1d(
+        x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), 80,
+        pack.data_ptr(), bias_dev.data_ptr(), 80, 80,
+        1, 0, tiles.data_ptr(), size // 4, tile, 1, None), 'emph_conv1d')
+    for off, count in spans(plan, axis):
+        want = torch.from_numpy(weight[:, :, 0]) @ x[:, off:off + count] + \
+            torch.from_numpy(bias)[:, None]
+        assert float((y[off:off + count].cpu().T - want).abs().max()) < 2e-5
+
+
+def test_conv1d_rejects_bad_arguments():
+    lib = runtime.library()
+    assert lib.emph_conv1d(None, 4, None, 4, None, None, 80, 80, 3, 0, None, 1,
+                           32, 0, None) == -1
+    x = torch.zeros(16, device=DEVICE)
+    p = x.data_ptr()
+    assert lib.emph_conv1d(p, 4, p, 4, p, None, 80, 80, 4, 0, p, 1, 32, 0,
+                           None) == -2      # even kernel size
+    assert b'kernel_size' in lib.emph_last_error()
+    assert lib.emph_conv1d(p, 4, p, 4, p, None, 80, 80, 3, 0, p, 1, 48, 0,
+                           None) == -2      # tile size
+    assert lib.emph_conv1d(p, 4, p, 4, p, None, 80, 80, 3, 0, p, 0, 32, 0,
+                           None) == 0       # empty batch is a no-op
+
+
+###############################################################################
+# segment reduce (emphases/core.py:426-469)
+###############################################################################
+
+
+def reduce_reference(x, bounds, mode):
+    count = bounds.shape[1]
+    out = torch.zeros((x.shape[0], count))
+    for j in range(count):
+        start, end = int(bounds[0, j]), int(bounds[1, j])
+        piece = x[:, start:end]                 # python slice truncation
+        if mode == 'sum':
+            out[:, j] = piece.sum(1)
+        elif mode == 'average':
+            out[:, j] = piece.mean(1)
+        elif mode == 'max':
+            out[:, j] = piece.max(1).values
+        else:
+            out[:, j] = x[:, (start + end) // 2]
+    return out
+
+
+@pytest.mark.parametrize('mode', ['sum', 'average', 'max', 'center'])
+@pytest.mark.parametrize('channels', [80, 7])
+def test_segment_reduce(mode, channels):
+    lib = runtime.library()
+    frames = [300, 40, 1000]
+    words = [synth.word_frames(4, 300, 1, 70),
+             np.array([[0, 1, 3], [1, 3, 40]]),
+             synth.word_frames(5, 1000, 8, 60)]
+    plan = ragged_plan(frames, words)
+    meta = Meta(plan, [])
+    x = random_packed(channels, plan, runtime.AXIS_FRAMES, 9)
+    out = torch.full((channels, plan.ld_words), -5.0, device=DEVICE)
+    x_dev = x.to(DEVICE)
+    runtime.check(lib.emph_segment_reduce(
+        x_dev.data_ptr(), plan.ld_frames,
+        meta.view('bounds')[0].data_ptr(), out.data_ptr(), plan.ld_words,
+        channels, meta.view('table')[0].data_ptr(),
+        meta.view('word_segment')[0].data_ptr(), plan.ld_words,
+        runtime.REDUCTIONS[mode], None), 'emph_segment_reduce')
+    out = out.cpu()
+    for (off, count), (woff, wcount), bounds in zip(
+            spans(plan, runtime.AXIS_FRAMES), spans(plan, runtime.AXIS_WORDS),
+            words):
+        want = reduce_reference(x[:, off:off + count], bounds, mode)
+        got = out[:, woff:woff + wcount]
+        assert float((got - want).abs().max()) < 2e-5
+    assert float(out[:, :batch.LEAD].max()) == -5.0
+
+
+def test_segment_reduce_edge_cases():
+    """Empty word: 0 under sum, NaN under average (as the reference); an end
+    beyond the chunk is truncated like a Python slice."""
+    lib = runtime.library()
+    words = [np.array([[0, 10, 10, 25], [10, 10, 25, 60]])]
+    plan = ragged_plan([30], words)
+    meta = Meta(plan, [])
+    x = random_packed(8, plan, runtime.AXIS_FRAMES, 1)
+    x_dev = x.to(DEVICE)
+    for mode in ('sum', 'average'):
+        out = torch.zeros((8, plan.ld_words), device=DEVICE)
+        runtime.check(lib.emph_segment_reduce(
+            x_dev.data_ptr(), plan.ld_frames,
+            meta.view('bounds')[0].data_ptr(), out.data_ptr(), plan.ld_words,
+            8, meta.view('table')[0].data_ptr(),
+            meta.view('word_segment')[0].data_ptr(), plan.ld_words,
+            runtime.REDUCTIONS[mode], None), 'emph_segment_reduce')
+        off, woff = int(plan.frame_off[0]), int(plan.word_off[0])
+        want = reduce_reference(x[:, off:off + 30], words[0], mode)
+        got = out[:, woff:woff + 4].cpu()
+        if mode == 'sum':
+            assert float(got[:, 1].abs().max()) == 0.0
+            assert float((got - want).abs().max()) < 1e-5
+        else:
+            assert torch.isnan(got[:, 1]).all() and torch.isnan(want[:, 1]).all()
+            keep = [0, 2, 3]
+            assert float((got[:, keep] - want[:, keep]).abs().max()) < 1e-5
+
+
+def test_downsample_wrapper_matches_reference_errors():
+    import emphases_amd
+    from emphases_amd import config as cfg
+    xs = torch.from_numpy(synth.weights(3, (2, 80, 50), 1.0))
+    bounds = torch.tensor([[[0, 10, 20], [10, 20, 50]],
+                           [[0, 5, 5], [5, 5, 0]]])
+    lengths = torch.tensor([3, 2])
+    got = emphases_amd.downsample(xs, bounds, lengths)
+    assert got.shape == (2, 80, 3) and not got.is_cuda
+    assert float((got[0, :, 2] - xs[0, :, 20:50].sum(1)).abs().max()) < 2e-5
+    assert float(got[1, :, 1].abs().max()) == 0.0       # empty word, sum
+    assert float(got[1, :, 2].abs().max()) == 0.0       # beyond word_lengths
+    with pytest.raises(IndexError):                     # core.py:449-452
+        emphases_amd.downsample(
+            xs, bounds, lengths, cfg.Config(downsample_method='max'))
+
+
+###############################################################################
+# output layer + postprocess
+###############################################################################
+
+
+@pytest.mark.parametrize('kernel_size,post', [(3, 'bce'), (1, 'mse'), (5, None)])
+def test_output_layer(kernel_size, post):
+    lib = runtime.library()
+    words = [synth.word_frames(1, 300, 5, 30), np.array([[0], [12]]),
+             synth.word_frames(2, 90, 2, 9)]
+    plan = ragged_plan([300, 12, 90], words)
+    meta = Meta(plan, [])
+    axis = runtime.AXIS_WORDS
+    x = random_packed(80, plan, axis, 13)
+    weight = synth.weights(14, (1, 80, kernel_size), 0.1)
+    bias = synth.weights(15, (1,), 0.5)
+    logits = torch.zeros(plan.ld_words, device=DEVICE)
+    scores = torch.zeros(plan.ld_words, device=DEVICE)
+    x_dev = x.to(DEVICE)
+    weight_dev = torch.from_numpy(weight).to(DEVICE)
+    bias_dev = torch.from_numpy(bias).to(DEVICE)
+    runtime.check(lib.emph_output_layer(
+        x_dev.data_ptr(), plan.ld_words, weight_dev.data_ptr(),
+        bias_dev.data_ptr(), 80, kernel_size,
+        meta.view('table')[0].data_ptr(),
+        meta.view('word_segment')[0].data_ptr(), plan.ld_words, axis,
+        runtime.POSTPROCESS[post], logits.data_ptr(), scores.data_ptr(), None),
+        'emph_output_layer')
+    for off, count in spans(plan, axis):
+        want = torch.nn.functional.conv1d(
+            x[None, :, off:off + count], torch.from_numpy(weight),
+            torch.from_numpy(bias), padding=(kernel_size - 1) // 2)[0, 0]
+        assert float((logits[off:off + count].cpu() - want).abs().max()) < 2e-5
+        if post == 'bce':
+            want = torch.sigmoid(want)
+        elif post == 'mse':
+            want = torch.clamp(want, 0., 1.)
+        assert float((scores[off:off + count].cpu() - want).abs().max()) < 2e-6
+
+
+###############################################################################
+# transformer pieces
+###############################################################################
+
+
+@pytest.mark.parametrize('channels,heads', [(80, 2), (64, 2), (128, 2)])
+def test_attention(channels, heads):
+    lib = runtime.library()
+    plan = ragged_plan([130, 16, 1, 700, 65])
+    axis = runtime.AXIS_FRAMES
+    meta = Meta(plan, [(axis, 64)])
+    ld = plan.ld_frames
+    qk = random_packed(2 * channels, plan, axis, 21) * 3.0
+    v = torch.from_numpy(synth.weights(22, (ld, channels), 1.0))
+    out = torch.zeros((channels, ld), device=DEVICE)
+    tiles, size = meta.view(('tiles', axis, 64))
+    qk_dev, v_dev = qk.to(DEVICE), v.to(DEVICE)
+    runtime.check(lib.emph_attention(
+        qk_dev.data_ptr(), v_dev.data_ptr(), out.data_ptr(), ld,
+        channels, heads, tiles.data_ptr(), size // 4, None), 'emph_attention')
+    out = out.cpu()
+    d = channels // heads
+    for off, count in spans(plan, axis):
+        q = qk[:channels, off:off + count].T.reshape(count, heads, d)
+        k = qk[channels:, off:off + count].T.reshape(count, heads, d)
+        vv = v[off:off + count].reshape(count, heads, d)
+        scores = torch.einsum('qhd,khd->hqk', q, k) / np.sqrt(d)
+        want = torch.einsum(
+            'hqk,khd->qhd', torch.softmax(scores, -1), vv).reshape(
+                count, channels).T
+        assert float((out[:, off:off + count] - want).abs().max()) < 2e-5
+
+
+def test_add_layernorm_and_position():
+    lib = runtime.library()
+    plan = ragged_plan([100, 37])
+    ld = plan.ld_frames
+    axis = runtime.AXIS_FRAMES
+    x = random_packed(80, plan, axis, 31) * 4.0
+    r = random_packed(80, plan, axis, 32)
+    gamma = torch.from_numpy(1.0 + synth.weights(33, (80,), 0.2))
+    beta = torch.from_numpy(synth.weights(34, (80,), 0.2))
+    y = torch.zeros((80, ld), device=DEVICE)
+    x_dev, r_dev = x.to(DEVICE), r.to(DEVICE)
+    gamma_dev, beta_dev = gamma.to(DEVICE), beta.to(DEVICE)
+    runtime.check(lib.emph_add_layernorm(
+        x_dev.data_ptr(), r_dev.data_ptr(), y.data_ptr(), ld, 80,
+        gamma_dev.data_ptr(), beta_dev.data_ptr(), 1e-5, 0, ld,
+        None), 'emph_add_layernorm')
+    want = torch.nn.functional.layer_norm(
+        (x + r).T, (80,), gamma, beta, 1e-5).T
+    assert float((y.cpu() - want).abs().max()) < 2e-5
+
+    meta = Meta(plan, [(axis, 64)])
+    table = torch.from_numpy(synth.weights(35, (5000, 80), 1.0))
+    z = x.to(DEVICE).clone()
+    table_dev = table.to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, 64))
+    runtime.check(lib.emph_add_position(
+        z.data_ptr(), ld, table_dev.data_ptr(), 80, 5000, tiles.data_ptr(),
+        size // 4, 64, None), 'emph_add_position')
+    z = z.cpu()
+    for off, count in spans(plan, axis):
+        want = x[:, off:off + count] + table[:count].T
+        assert float((z[:, off:off + count] - want).abs().max()) == 0.0
+    assert torch.equal(z[:, :batch.LEAD], x[:, :batch.LEAD])

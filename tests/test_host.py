@@ -1,0 +1,351 @@
+"""CPU: host-side logic of the product (chunking, bounds, layout, file I/O),
+and the C-ABI library's exported surface.  No kernel is launched here."""
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import emphases_amd
+from conftest import ROOT, case_names, seconds
+from emphases_amd import (alignment, batch, config as cfg, convert, load,
+                          melbasis, runtime, synth, weights)
+from oracle import librosa_mel
+from oracle import prominence as oracle
+
+
+###############################################################################
+# Chunking (emphases/core.py:345-418)
+###############################################################################
+
+
+def plans(chunk_goldens):
+    return case_names(chunk_goldens)
+
+
+def test_chunk_plans_match_reference(chunk_goldens):
+    names = plans(chunk_goldens)
+    assert 'dropped_chunk_b0' in names and 'floor_b300' in names
+    for name in names:
+        bounds = chunk_goldens[f'{name}/bounds_frames'].astype(np.int64)
+        batch_size = int(chunk_goldens[f'{name}/batch_size'])
+        batch_size = None if batch_size < 0 else batch_size
+        samples = int(bounds[1, -1]) * 160
+        want_frames = chunk_goldens[f'{name}/chunk_frames']
+        want_words = chunk_goldens[f'{name}/chunk_words']
+        want_bounds = chunk_goldens[f'{name}/chunk_bounds']
+
+        # product
+        words = emphases_amd.Alignment.from_frames(bounds)
+        segments = batch.chunk_utterance(words, samples, batch_size)
+        assert [s.frames for s in segments] == want_frames.tolist(), name
+        assert [s.bounds.shape[1] for s in segments] == \
+            want_words.tolist(), name
+        np.testing.assert_array_equal(
+            np.concatenate([s.bounds for s in segments], axis=1), want_bounds)
+
+        # oracle
+        kept = [c for c in oracle.chunks(seconds(bounds), samples, batch_size)
+                if not c['dropped']]
+        assert [(c['end_sample'] - c['start_sample']) // 160 for c in kept] \
+            == want_frames.tolist(), name
+        np.testing.assert_array_equal(
+            np.concatenate([c['bounds'] for c in kept], axis=1), want_bounds)
+
+
+def test_dropped_chunk_has_no_scores(chunk_goldens):
+    """core.py:414-415 swallows the reflect-pad error: the 2-frame chunk's
+    word gets no score."""
+    bounds = chunk_goldens['dropped_chunk_b0/bounds_frames']
+    assert bounds.shape[1] == 4
+    assert chunk_goldens['dropped_chunk_b0/chunk_words'].sum() == 3
+    words = emphases_amd.Alignment.from_frames(bounds)
+    segments = batch.chunk_utterance(words, int(bounds[1, -1]) * 160, 0)
+    assert [(s.start_word, s.end_word) for s in segments] == \
+        [(0, 1), (2, 3), (3, 4)]
+
+
+def test_float_floor_quirk():
+    """convert.py:29-31 floor-divides in float64: 8.03 s is frame 802."""
+    assert convert.seconds_to_frames(8.03) == 802.0
+    assert convert.seconds_to_frames(8.02) == 802.0
+    assert convert.seconds_to_frames(16.06) == 1605.0
+    assert convert.seconds_to_frames(1.0) == 100.0
+    assert isinstance(convert.seconds_to_frames(1.0), float)
+    assert convert.frames_to_samples(802) == 128320
+    assert oracle.seconds_to_frames(8.03) == 802.0
+
+
+def test_chunk_frames_follow_stft_length():
+    times = [(0.0, 0.5), (0.5, 1.0)]
+    (segment,) = batch.chunk_utterance(times, 16000)
+    assert segment.frames == 100 and segment.length == 16000
+    assert segment.start_sample == 0
+
+
+###############################################################################
+# Packed layout
+###############################################################################
+
+
+def test_plan_layout():
+    segments = []
+    lengths = []
+    for index, frames in enumerate([1000, 37, 250]):
+        bounds = synth.word_frames(index, frames, 3, 40)
+        segments.extend(batch.chunk_utterance(
+            emphases_amd.Alignment.from_frames(bounds), frames * 160, None,
+            index))
+        lengths.append(frames * 160)
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+    plan = batch.Plan(segments, offsets, lengths)
+    assert plan.total_frames == 1287
+    assert np.all(plan.frame_off % batch.ALIGN == 0)
+    assert np.all(plan.word_off % batch.ALIGN == 0)
+    assert plan.frame_off[0] >= batch.LEAD
+    assert plan.ld_frames % 4 == 0
+    assert plan.ld_frames >= plan.frame_off[-1] + plan.frames[-1] + batch.TAIL
+    # ranges do not overlap
+    ends = plan.frame_off + plan.frames
+    assert np.all(plan.frame_off[1:] >= ends[:-1])
+    tiles = plan.tiles(runtime.AXIS_FRAMES, 64)
+    assert tiles.dtype == np.int32
+    assert tiles.shape[1] == runtime.TILE_FIELDS
+    assert tiles[:, 0].tolist() == [0] * 16 + [1] + [2] * 4
+    assert tiles[16].tolist() == [1, 0, int(plan.frame_off[1]), 37]
+    assert tiles[-1].tolist() == [2, 192, int(plan.frame_off[2]), 250]
+    # every word column is labelled with its segment, padding with -1
+    columns = plan.word_columns()
+    assert len(columns) == plan.total_words
+    assert np.all(plan.word_segment[columns] >= 0)
+    assert (plan.word_segment >= 0).sum() == plan.total_words
+    meta, where = plan.pack_metadata([(runtime.AXIS_FRAMES, 64)])
+    start, size = where['table']
+    assert start == 0 and size == 3 * runtime.SEG_FIELDS * 2
+    table = meta[start:start + size].view(np.int64).reshape(3, -1)
+    np.testing.assert_array_equal(table, plan.table)
+    assert table[1, runtime.SEG_AUDIO_OFF] == 160000
+
+
+###############################################################################
+# Mel basis, weights, synthetic data
+###############################################################################
+
+
+def test_mel_basis_matches_oracle_bitwise():
+    ours = melbasis.filterbank()
+    theirs = librosa_mel.mel(sr=16000, n_fft=1024, n_mels=80)
+    assert np.array_equal(ours, theirs)
+    sparse = melbasis.default()
+    assert sparse.nnz == sparse.values.size == 1001
+    dense = np.zeros_like(ours)
+    for row in range(80):
+        lo, n, off = (sparse.row_start[row], sparse.row_count[row],
+                      sparse.row_offset[row])
+        dense[row, lo:lo + n] = sparse.values[off:off + n]
+    assert np.array_equal(dense, ours)
+
+
+def test_bundled_checkpoint_is_the_reference_weights():
+    state = weights.load()
+    assert len(state) == 28
+    assert sum(v.size for v in state.values()) == 250881
+    flat = np.concatenate([v.ravel() for v in state.values()])
+    digest = hashlib.sha256(flat.astype('<f4').tobytes()).hexdigest()
+    # SURVEY.md App. E
+    assert digest == \
+        'be2fb6555ba5fab57a4abb3c4e55a6cefc9dbd03c3ccbdcc2c735784aa277e69'
+
+
+def test_parameter_layouts():
+    assert sum(int(np.prod(s)) for s in weights.parameter_shapes().values()) \
+        == 250881
+    transformer = cfg.Config(architecture='transformer')
+    assert sum(int(np.prod(s)) for s in
+               weights.parameter_shapes(transformer).values()) == 489921
+    inference = cfg.Config(downsample_location='inference')
+    assert sum(int(np.prod(s)) for s in
+               weights.parameter_shapes(inference).values()) == 135201
+    with pytest.raises(ValueError):
+        cfg.Config(architecture='lstm')
+    with pytest.raises(ValueError):
+        cfg.Config(downsample_method='median')
+    with pytest.raises(KeyError):
+        weights.load({'input_layer.weight': np.zeros((80, 80, 3))})
+
+
+def test_synthetic_data_is_deterministic():
+    assert synth.splitmix64(0, 2).tolist() == \
+        [16294208416658607535, 7960286522194355700]
+    audio = synth.audio(9, 600)
+    assert audio.shape == (1, 96000) and audio.dtype == np.float32
+    assert np.all(audio[0, 32000:40000] == 0)          # the silent stretch
+    assert np.array_equal(np.rint(audio * 32768) / 32768, audio)
+    bounds = synth.word_frames(0, 1000)
+    assert bounds[0, 0] == 0 and bounds[1, -1] == 1000
+    assert np.all(bounds[0, 1:] == bounds[1, :-1])
+    a = weights.random_state(cfg.DEFAULT, 7)['input_layer.weight']
+    b = weights.random_state(cfg.DEFAULT, 7)['input_layer.weight']
+    assert np.array_equal(a, b) and abs(float(a.mean())) < 0.01
+
+
+def test_golden_audio_regenerates(cases):
+    """The committed int16 audio equals what synth produces here."""
+    np.testing.assert_array_equal(
+        np.rint(synth.audio(0, 1000)[0] * 32768).astype(np.int16),
+        cases['utt_10s/pcm'])
+
+
+###############################################################################
+# Alignment protocol and file I/O
+###############################################################################
+
+
+def test_alignment_protocol(tmp_path):
+    bounds = synth.word_frames(3, 250)
+    names = synth.word_names(bounds.shape[1])
+    words = emphases_amd.Alignment.from_frames(bounds, names)
+    assert len(words) == bounds.shape[1]
+    assert words[1].start() == bounds[0, 1] / 100.
+    assert abs(words[1].duration() -
+               (bounds[1, 1] - bounds[0, 1]) / 100.) < 1e-12
+    assert words.word_bounds(16000, 160, silences=True) == \
+        [tuple(int(v) for v in pair) for pair in bounds.T]
+    # a slice reports bounds relative to its first word
+    assert words[2:4].word_bounds(16000, 160, silences=True)[0][0] == 0
+    silent = sum(1 for n in names if n == alignment.SILENCE)
+    assert len(words.word_bounds(16000, 160)) == len(words) - silent
+    for suffix in ('.TextGrid', '.json'):
+        file = tmp_path / f'utt{suffix}'
+        words.save(file)
+        loaded = emphases_amd.Alignment(file)
+        assert [str(w) for w in loaded] == [str(w) for w in words]
+        assert [(w.start(), w.end()) for w in loaded] == \
+            [(w.start(), w.end()) for w in words]
+    with pytest.raises(ValueError):
+        emphases_amd.Alignment(tmp_path / 'utt.lab')
+
+
+def test_textgrid_with_phone_tier(tmp_path):
+    text = '''File type = "ooTextFile"
+Object class = "TextGrid"
+
+xmin = 0
+xmax = 1.0
+tiers? <exists>
+size = 2
+item []:
+    item [1]:
+        class = "IntervalTier"
+        name = "phones"
+        xmin = 0
+        xmax = 1.0
+        intervals: size = 3
+        intervals [1]:
+            xmin = 0
+            xmax = 0.3
+            text = "HH"
+        intervals [2]:
+            xmin = 0.3
+            xmax = 0.5
+            text = "AY"
+        intervals [3]:
+            xmin = 0.5
+            xmax = 1.0
+            text = "sp"
+    item [2]:
+        class = "IntervalTier"
+        name = "words"
+        xmin = 0
+        xmax = 1.0
+        intervals: size = 2
+        intervals [1]:
+            xmin = 0
+            xmax = 0.5
+            text = "hi"
+        intervals [2]:
+            xmin = 0.5
+            xmax = 1.0
+            text = ""
+'''
+    file = tmp_path / 'two_tier.TextGrid'
+    file.write_text(text)
+    words = emphases_amd.Alignment(file)
+    assert [str(w) for w in words] == ['hi', alignment.SILENCE]
+    assert words.word_bounds(16000, 160, silences=True) == [(0, 50), (50, 100)]
+
+
+def test_wav_roundtrip_and_resample(tmp_path):
+    audio = synth.audio(2, 50)
+    file = tmp_path / 'a.wav'
+    load.save_wav(file, audio)
+    loaded, rate = load.wav(file)
+    assert rate == 16000 and np.array_equal(loaded.numpy(), audio)
+    assert np.array_equal(load.audio(file).numpy(), audio)
+    # 8 kHz tone survives 2x upsampling
+    n = np.arange(8000)
+    tone = torch.from_numpy(
+        np.sin(2 * np.pi * 440 * n / 8000).astype(np.float32))[None]
+    up = load.resample(tone, 8000)
+    assert up.shape == (1, 16000)
+    want = np.sin(2 * np.pi * 440 * np.arange(16000) / 16000)
+    assert np.abs(up[0, 200:-200].numpy() - want[200:-200]).max() < 2e-2
+    assert emphases_amd.resample(tone, 16000) is tone
+
+
+###############################################################################
+# C ABI
+###############################################################################
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'emphases_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    declared = set(re.findall(r'\b(emph_\w+)\s*\(', header))
+    assert declared == set(runtime.SIGNATURES), \
+        declared ^ set(runtime.SIGNATURES)
+    library = runtime.library()          # raises if any symbol is missing
+    assert library.emph_abi_version() == runtime.ABI_VERSION
+    assert library.emph_frontend_table_size() > 1024
+
+
+def test_host_side_abi_helpers():
+    table = runtime.frontend_table()
+    n = np.arange(1024)
+    np.testing.assert_allclose(
+        table[:1024], 0.5 - 0.5 * np.cos(2 * np.pi * n / 1024), atol=1e-7)
+    weight = np.arange(80 * 80 * 3, dtype=np.float32).reshape(80, 80, 3)
+    pack = runtime.conv_pack(weight)
+    # pack[step][m][lane] = W[16 m + (lane & 15)][4 group + (lane >> 4)][tap]
+    step, m, lane = 7, 3, 37
+    group, tap = divmod(step, 3)
+    assert pack.reshape(-1, 5, 64)[step, m, lane] == \
+        weight[16 * m + (lane & 15), 4 * group + (lane >> 4), tap]
+    odd = runtime.conv_pack(np.ones((1, 81, 3), dtype=np.float32))
+    assert odd.sum() == 81 * 3          # padding rows/channels are zero
+    library = runtime.library()
+    assert library.emph_conv_pack(None, 1, 1, 1, None) == -1
+    assert b'null' in library.emph_last_error()
+
+
+def test_no_silent_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    bounds = synth.word_frames(0, 100)
+    words = emphases_amd.Alignment.from_frames(bounds)
+    with pytest.raises(runtime.LibraryError, match='no CPU fallback'):
+        emphases_amd.from_alignment_and_audio(
+            words, torch.zeros(1, 16000), 16000)
+    with pytest.raises(NotImplementedError):
+        emphases_amd.from_text_and_audio('hi', torch.zeros(1, 16000), 16000)
+
+
+def test_product_does_not_import_the_oracle():
+    for directory, _, files in os.walk(os.path.join(ROOT, 'emphases_amd')):
+        for file in files:
+            if file.endswith('.py'):
+                source = open(os.path.join(directory, file)).read()
+                assert not re.search(
+                    r'^\s*(from|import)\s+oracle', source, flags=re.M), file

@@ -1,0 +1,114 @@
+// Standalone micro-benchmark of emph_conv1d on the C2 layout (64 x 1000 frames).
+// Build: hipcc -O3 --offload-arch=gfx950 -DEMPH_STAMPS -I. tools/micro/conv_bench.hip \
+//            emphases_amd/csrc/frontend.hip -o gpurun_out/conv_bench   (frontend.hip supplies set_error)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+
+#ifdef EMPH_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#define EMPH_STAMP(slot)                                                          \
+    do {                                                                          \
+        if (g_stamps != nullptr && (threadIdx.x & 63) == 0) {                     \
+            unsigned long long now = __builtin_amdgcn_s_memrealtime();           \
+            g_stamps[(static_cast<size_t>(blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8 + \
+                     (slot)] = now;                                               \
+            if ((slot) == 2 || (slot) == 3)                                       \
+                g_stamps[(static_cast<size_t>(blockIdx.x) * 8 + (threadIdx.x >> 6)) * 8 + \
+                         (slot) + 3] = __builtin_amdgcn_s_memtime();              \
+        }                                                                         \
+    } while (0)
+#endif
+#include "../../emphases_amd/csrc/conv.hip"
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+int main(int argc, char** argv) {
+    const int segments = 64, frames = 1000, c = 80, ks = 3;
+    const int64_t ld = 16 + static_cast<int64_t>(segments) * 1008 + 64;
+    std::vector<float> hx(c * ld);
+    for (size_t i = 0; i < hx.size(); ++i) hx[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
+    std::vector<float> hw(c * c * ks);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 40503u) % 1000) / 5000.f - 0.1f;
+    std::vector<float> hpack(emph_conv_pack_size(c, c, ks));
+    emph_conv_pack(hw.data(), c, c, ks, hpack.data());
+    std::vector<float> hbias(c, 0.1f);
+    float *x, *y, *pack, *bias;
+    CHECK(hipMalloc(&x, hx.size() * 4)); CHECK(hipMalloc(&y, hx.size() * 4));
+    CHECK(hipMalloc(&pack, hpack.size() * 4)); CHECK(hipMalloc(&bias, c * 4));
+    CHECK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(pack, hpack.data(), hpack.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(bias, hbias.data(), c * 4, hipMemcpyHostToDevice));
+    hipEvent_t start, stop;
+    CHECK(hipEventCreate(&start)); CHECK(hipEventCreate(&stop));
+    for (int tile_n : {64, 32, 16}) {
+        std::vector<int32_t> tiles;
+        for (int s = 0; s < segments; ++s)
+            for (int t = 0; t < frames; t += tile_n) {
+                tiles.push_back(s); tiles.push_back(t);
+                tiles.push_back(16 + s * 1008); tiles.push_back(frames);
+            }
+        const int n_tiles = tiles.size() / 4;
+        int32_t* dtiles;
+        CHECK(hipMalloc(&dtiles, tiles.size() * 4));
+        CHECK(hipMemcpy(dtiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+        for (int rep = 0; rep < 5; ++rep)
+            emph_conv1d(x, ld, y, ld, pack, bias, c, c, ks, 1, dtiles, n_tiles, tile_n, 0, nullptr);
+        CHECK(hipDeviceSynchronize());
+        const int reps = 50;
+        CHECK(hipEventRecord(start));
+        for (int rep = 0; rep < reps; ++rep)
+            emph_conv1d(x, ld, y, ld, pack, bias, c, c, ks, 1, dtiles, n_tiles, tile_n, 0, nullptr);
+        CHECK(hipEventRecord(stop));
+        CHECK(hipEventSynchronize(stop));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, start, stop));
+        const double us = ms * 1e3 / reps;
+        printf("tile %2d: %7.2f us/launch  %6.1f TFLOP/s\n", tile_n, us,
+               2.0 * c * c * ks * segments * frames / us * 1e-6);
+#ifdef EMPH_STAMPS
+        {
+            const size_t slots = 512 * 8 * 8;
+            unsigned long long* stamps;
+            CHECK(hipMalloc(&stamps, slots * 8));
+            CHECK(hipMemset(stamps, 0, slots * 8));
+            CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &stamps, sizeof(stamps)));
+            emph_conv1d(x, ld, y, ld, pack, bias, c, c, ks, 1, dtiles, n_tiles, tile_n, 0, nullptr);
+            CHECK(hipDeviceSynchronize());
+            std::vector<unsigned long long> host(slots);
+            CHECK(hipMemcpy(host.data(), stamps, slots * 8, hipMemcpyDeviceToHost));
+            unsigned long long* null_ptr = nullptr;
+            CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &null_ptr, sizeof(null_ptr)));
+            unsigned long long first = ~0ull;
+            for (size_t i = 0; i < slots; i += 8) if (host[i]) first = std::min(first, host[i]);
+            // s_memrealtime ticks at 100 MHz: 10 ns each
+            const char* names[8] = {"start", "staged", "setup", "loop", "store", "", "", ""};
+            for (int slot = 0; slot < 5; ++slot) {
+                std::vector<double> values;
+                for (size_t i = 0; i < slots; i += 8)
+                    if (host[i] && host[i + slot]) values.push_back((host[i + slot] - first) * 0.01);
+                if (values.empty()) continue;
+                std::sort(values.begin(), values.end());
+                printf("   %-7s waves=%4zu  min %6.2f  median %6.2f  max %6.2f us since first wave start\n",
+                       names[slot], values.size(), values.front(), values[values.size() / 2], values.back());
+            }
+            {
+                std::vector<double> clocks;
+                for (size_t i = 0; i < slots; i += 8)
+                    if (host[i] && host[i + 3] > host[i + 2])
+                        clocks.push_back(double(host[i + 6] - host[i + 5]) /
+                                         (double(host[i + 3] - host[i + 2]) * 10.0));
+                std::sort(clocks.begin(), clocks.end());
+                if (!clocks.empty())
+                    printf("   shader clock during the K loop: median %.2f GHz (min %.2f max %.2f)\n",
+                           clocks[clocks.size() / 2], clocks.front(), clocks.back());
+            }
+            CHECK(hipFree(stamps));
+        }
+#endif
+        CHECK(hipFree(dtiles));
+    }
+    return 0;
+}
