@@ -115,8 +115,7 @@ __host__ __device__ inline int padded_rows(int c_in, int ks) {
 }
 
 constexpr int kConvLdsBudget = 136 * 1024;            // weights only
-// Waves per workgroup: two per SIMD for the narrow tiles (one wave's load
-// latency and epilogue hide under the other's MFMAs), one for the wide tile.
+// Waves per workgroup (one or two per SIMD), chosen at launch.
 __host__ __device__ constexpr int conv_waves(int nb) { return nb == 4 ? 4 : 8; }
 // floats per row of the epilogue patch; 16-byte aligned rows, and the two
 // 16-lane k-groups of a 32-lane ds_write phase land on disjoint banks
@@ -199,13 +198,12 @@ __device__ __forceinline__ void store_patch(const float* patch, float* __restric
 //   tile descriptor -> request the weight pack (registers) and the first B
 //   fragments -> commit pack + bias to LDS -> barrier -> K loop -> epilogue out
 //   of LDS (no global reads).
-template <int KS, int MB, int NB>
-__global__ __launch_bounds__(64 * conv_waves(NB)) void conv1d_kernel(
+template <int KS, int MB, int NB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void conv1d_kernel(
     const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
     const float* __restrict__ pack, const float* __restrict__ bias, int c_in,
     int c_out, int act, const int32_t* __restrict__ tiles, int n_tiles,
     int chunk_iterations, int patch_offset, int transpose_out) {
-    constexpr int WAVES = conv_waves(NB);
     constexpr int THREADS = 64 * WAVES;
     constexpr int kPatchStride = patch_stride(NB);
     constexpr int HALO = (KS - 1) / 2;
@@ -460,16 +458,16 @@ __global__ __launch_bounds__(64 * conv_waves(NB)) void conv1d_kernel(
     }
 }
 
-template <int KS, int MB, int NB>
-int launch_conv(int n_tiles, int m_blocks, size_t weight_bytes, hipStream_t s,
-                const float* x, int64_t ldx, float* y, int64_t ldy,
-                const float* pack, const float* bias, int c_in, int c_out, int act,
-                const int32_t* tiles, int chunk_iterations, int transpose_out) {
-    constexpr int WAVES = conv_waves(NB);
+template <int KS, int MB, int NB, int WAVES>
+int launch_conv_waves(int n_tiles, int m_blocks, size_t weight_bytes, hipStream_t s,
+                      const float* x, int64_t ldx, float* y, int64_t ldy,
+                      const float* pack, const float* bias, int c_in, int c_out,
+                      int act, const int32_t* tiles, int chunk_iterations,
+                      int transpose_out) {
     const size_t lds = weight_bytes +
                        (WAVES * 16 * patch_stride(NB) + MB * 16) * sizeof(float);
     const int patch_offset = static_cast<int>(weight_bytes / sizeof(float));
-    auto kernel = conv1d_kernel<KS, MB, NB>;
+    auto kernel = conv1d_kernel<KS, MB, NB, WAVES>;
     if (lds > 64 * 1024) {
         hipError_t status = hipFuncSetAttribute(
             reinterpret_cast<const void*>(kernel),
@@ -488,6 +486,27 @@ int launch_conv(int n_tiles, int m_blocks, size_t weight_bytes, hipStream_t s,
                        bias, c_in, c_out, act, tiles, n_tiles, chunk_iterations,
                        patch_offset, transpose_out);
     return check_launch("emph_conv1d");
+}
+
+template <int KS, int MB, int NB>
+int launch_conv(int n_tiles, int m_blocks, size_t weight_bytes, hipStream_t s,
+                const float* x, int64_t ldx, float* y, int64_t ldy,
+                const float* pack, const float* bias, int c_in, int c_out, int act,
+                const int32_t* tiles, int chunk_iterations, int transpose_out) {
+    // experiment knob EMPH_CONV_WAVES=4|8 (default: 4 for wide tiles, 8 otherwise)
+    static const int forced = [] {
+        const char* text = getenv("EMPH_CONV_WAVES");
+        return text ? atoi(text) : 0;
+    }();
+    const int waves = forced ? forced : conv_waves(NB);
+    if (waves == 4)
+        return launch_conv_waves<KS, MB, NB, 4>(n_tiles, m_blocks, weight_bytes, s, x,
+                                                ldx, y, ldy, pack, bias, c_in, c_out,
+                                                act, tiles, chunk_iterations,
+                                                transpose_out);
+    return launch_conv_waves<KS, MB, NB, 8>(n_tiles, m_blocks, weight_bytes, s, x, ldx,
+                                            y, ldy, pack, bias, c_in, c_out, act, tiles,
+                                            chunk_iterations, transpose_out);
 }
 
 template <int KS, int MB>

@@ -4,8 +4,9 @@
 // (emphases/core.py:426-469: one slice + reduce + copy, i.e. >= 3 kernel
 // launches and a host sync, per word).  It is HBM-bound: every frame embedding
 // is read exactly once (320 B per frame for 80 channels) in 64-byte row
-// segments; one wave owns one word, lanes are 16 frames x 4 channels, and the
-// frame axis is folded with a 16-lane butterfly.
+// segments; one wave owns one word, lanes are 16 frames x 4 channels, every
+// load of a 32-frame round is in flight at once, and the frame axis is folded
+// with a 16-lane butterfly.
 //
 // emph_output_layer replaces Conv1d(channels, 1, k, 'same')
 // (emphases/model/core.py:33-37,138) fused with emphases.postprocess
@@ -16,7 +17,9 @@
 
 namespace emph {
 
-// grid.x = blocks of 4 words over the packed word axis; block = 256
+// grid.x = blocks of 4 words over the packed word axis; block = 256 (one wave
+// per word).  CGROUPS = channel groups of 4 held in registers.
+template <int CGROUPS>
 __global__ __launch_bounds__(256) void segment_reduce_kernel(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ bounds,
     float* __restrict__ out, int64_t ldw, int channels,
@@ -27,21 +30,20 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(
     if (word >= total_words) return;
     const int segment = word_segment[word];
     if (segment < 0) return;                      // alignment padding column
+    const int raw_start = bounds[word];
+    const int raw_end = bounds[ldw + word];
     const int64_t* row = seg + static_cast<int64_t>(segment) * EMPH_SEG_FIELDS;
     const int64_t frame_off = row[EMPH_SEG_FRAME_OFF];
     const int frames = static_cast<int>(row[EMPH_SEG_FRAMES]);
     // Python slice semantics: clamp to the chunk (core.py:446-454)
-    int start = bounds[word];
-    int end = bounds[ldw + word];
-    const int raw_count = end - start;
-    start = max(0, min(start, frames));
-    end = max(start, min(end, frames));
+    const int start = max(0, min(raw_start, frames));
+    const int end = max(start, min(raw_end, frames));
 
     const int fr = lane & 15;
     const int cg = lane >> 4;
     if (mode == EMPH_REDUCE_CENTER) {
         // gather at (start + end) // 2 of the UNclamped bounds (core.py:459-466)
-        const int center = (bounds[word] + bounds[ldw + word]) >> 1;
+        const int center = (raw_start + raw_end) >> 1;
         for (int c = lane; c < channels; c += 64)
             out[static_cast<int64_t>(c) * ldw + word] =
                 (center >= 0 && center < frames)
@@ -49,24 +51,49 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(
                     : 0.f;
         return;
     }
+    const int groups = (channels + 3) >> 2;
+    const float identity = mode == EMPH_REDUCE_MAX ? -INFINITY : 0.f;
     const float* base = x + frame_off;
-    for (int c = cg; c < channels; c += 4) {
-        const float* src = base + static_cast<int64_t>(c) * ldx;
-        float value = mode == EMPH_REDUCE_MAX ? -INFINITY : 0.f;
-        if (mode == EMPH_REDUCE_MAX) {
-            for (int t = start + fr; t < end; t += 16) value = fmaxf(value, src[t]);
+    float acc[CGROUPS];
 #pragma unroll
-            for (int offset = 8; offset > 0; offset >>= 1)
-                value = fmaxf(value, __shfl_xor(value, offset));
-        } else {
-            for (int t = start + fr; t < end; t += 16) value += src[t];
+    for (int g = 0; g < CGROUPS; ++g) acc[g] = identity;
+    // 32 frames x every channel group per round, all loads unconditional
+    // (clamped address, masked value) so that they are all in flight together:
+    // a dependent L2/HBM round trip costs 1-2 us here
+    for (int t0 = start; t0 < end; t0 += 32) {
+        float value[2][CGROUPS];
 #pragma unroll
-            for (int offset = 8; offset > 0; offset >>= 1)
-                value += __shfl_xor(value, offset);
-            if (mode == EMPH_REDUCE_AVERAGE)
-                value = value / static_cast<float>(raw_count > 0 ? end - start : 0);
+        for (int half = 0; half < 2; ++half) {
+            const int t = min(t0 + 16 * half + fr, max(end - 1, 0));
+#pragma unroll
+            for (int g = 0; g < CGROUPS; ++g) {
+                const int c = min(4 * min(g, groups - 1) + cg, channels - 1);
+                value[half][g] = base[static_cast<int64_t>(c) * ldx + t];
+            }
         }
-        if (fr == 0) out[static_cast<int64_t>(c) * ldw + word] = value;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const bool live = t0 + 16 * half + fr < end;
+#pragma unroll
+            for (int g = 0; g < CGROUPS; ++g) {
+                const float v = live ? value[half][g] : identity;
+                acc[g] = mode == EMPH_REDUCE_MAX ? fmaxf(acc[g], v) : acc[g] + v;
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < CGROUPS; ++g) {
+        float value = acc[g];
+#pragma unroll
+        for (int offset = 8; offset > 0; offset >>= 1) {
+            const float other = __shfl_xor(value, offset);
+            value = mode == EMPH_REDUCE_MAX ? fmaxf(value, other) : value + other;
+        }
+        if (mode == EMPH_REDUCE_AVERAGE)
+            value = value / static_cast<float>(end - start);   // 0/0 = NaN
+        const int c = 4 * g + cg;
+        if (fr == 0 && g < groups && c < channels)
+            out[static_cast<int64_t>(c) * ldw + word] = value;
     }
 }
 
@@ -125,10 +152,18 @@ int emph_segment_reduce(const float* x, int64_t ldx, const int32_t* bounds,
                  "emph_segment_reduce: unknown mode %d", mode);
     EMPH_REQUIRE(channels > 0 && total_words <= ldw, EMPH_EINVAL,
                  "emph_segment_reduce: bad shape");
+    EMPH_REQUIRE(channels <= 128, EMPH_ERANGE,
+                 "emph_segment_reduce: channels %d > 128", channels);
     const unsigned blocks = static_cast<unsigned>((total_words + 3) / 4);
-    hipLaunchKernelGGL(segment_reduce_kernel, dim3(blocks), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, ldx, bounds, out, ldw,
-                       channels, seg, word_segment, total_words, mode);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (channels <= 80)
+        hipLaunchKernelGGL(segment_reduce_kernel<20>, dim3(blocks), dim3(256), 0, s, x,
+                           ldx, bounds, out, ldw, channels, seg, word_segment,
+                           total_words, mode);
+    else
+        hipLaunchKernelGGL(segment_reduce_kernel<32>, dim3(blocks), dim3(256), 0, s, x,
+                           ldx, bounds, out, ldw, channels, seg, word_segment,
+                           total_words, mode);
     return check_launch("emph_segment_reduce");
 }
 

@@ -93,6 +93,20 @@ class Engine:
             if config.has_decoder else None
         self.output_weight = to(state['output_layer.weight'])
         self.output_bias = to(state['output_layer.bias'])
+        # fused word stage (csrc/decoder.hip): conv decoder, or no decoder
+        self.fused_words = config.architecture == 'convolution' or \
+            not config.has_decoder
+        self.word_block = WORD_TILE
+        if self.fused_words:
+            layers = self.word_decoder if config.has_decoder else []
+            self.decoder_layers = len(layers)
+            self.decoder_packs = torch.cat([l.pack for l in layers]) \
+                if layers else None
+            self.decoder_biases = torch.cat([l.bias for l in layers]) \
+                if layers else None
+            self.word_block = int(self.lib.emph_word_decoder_block(
+                self.decoder_layers, config.decoder_kernel_size,
+                config.decoder_kernel_size))
         if config.architecture == 'transformer':
             self.position = to(weights_module.positional_encoding(
                 cfg.MAX_POSITIONS, config.channels))
@@ -147,7 +161,7 @@ class Engine:
         requests = [
             (runtime.AXIS_FRAMES, FRONTEND_BLOCK),
             (runtime.AXIS_FRAMES, tile),
-            (runtime.AXIS_WORDS, WORD_TILE)]
+            (runtime.AXIS_WORDS, self.word_block)]
         if self.config.architecture == 'transformer':
             requests += [(runtime.AXIS_FRAMES, ATTENTION_BLOCK),
                          (runtime.AXIS_WORDS, ATTENTION_BLOCK)]
@@ -349,8 +363,10 @@ class Engine:
             stages['encoder'] = encoded
 
         check_bounds(plan, config.downsample_method)
-        wa, wb = zeros(channels, ld_w), zeros(channels, ld_w)
         table = meta['table'][0]
+        logits = zeros(ld_w)
+        scores = zeros(ld_w)
+        wa, wb = zeros(channels, ld_w), zeros(channels, ld_w)
         with self._timed('segment_reduce'):
           runtime.check(self.lib.emph_segment_reduce(
             encoded.data_ptr(), ld_f, meta['bounds'][0].data_ptr(),
@@ -360,13 +376,30 @@ class Engine:
             'emph_segment_reduce')
         if stages is not None:
             stages['downsampled'] = wa.clone()
+        if self.fused_words:
+            tiles, size = meta[('tiles', runtime.AXIS_WORDS, self.word_block)]
+            with self._timed('word_decoder', 2. * channels * (
+                    channels * config.decoder_kernel_size * self.decoder_layers
+                    + config.decoder_kernel_size) * plan.total_words):
+                runtime.check(self.lib.emph_word_decoder(
+                    wa.data_ptr(), ld_w, tiles.data_ptr(),
+                    size // runtime.TILE_FIELDS, channels,
+                    None if self.decoder_packs is None
+                    else self.decoder_packs.data_ptr(),
+                    None if self.decoder_biases is None
+                    else self.decoder_biases.data_ptr(),
+                    self.decoder_layers, config.decoder_kernel_size,
+                    runtime.ACTIVATIONS[config.activation],
+                    self.output_weight.data_ptr(), self.output_bias.data_ptr(),
+                    config.decoder_kernel_size,
+                    runtime.POSTPROCESS[config.loss], logits.data_ptr(),
+                    scores.data_ptr(), runtime.stream()), 'emph_word_decoder')
+            return scores, logits
         decoded = wa
         if config.downsample_location == 'intermediate':
             decoded, _ = self._stack_forward(
                 self.word_decoder, wa, wb, ld_w, plan, meta,
-                runtime.AXIS_WORDS, WORD_TILE)
-        logits = zeros(ld_w)
-        scores = zeros(ld_w)
+                runtime.AXIS_WORDS, self.word_block)
         with self._timed('output_layer'):
           runtime.check(self.lib.emph_output_layer(
             decoded.data_ptr(), ld_w, self.output_weight.data_ptr(),

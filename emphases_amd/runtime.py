@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -50,6 +50,10 @@ SIGNATURES = {
     'emph_output_layer': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _i64, _i32, _i32,
         _ptr, _ptr, _ptr]),
+    'emph_word_decoder_block': (_i32, [_i32, _i32, _i32]),
+    'emph_word_decoder': (_c.c_int, [
+        _ptr, _i64, _ptr, _i32, _i32, _ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr,
+        _i32, _i32, _ptr, _ptr, _ptr]),
     'emph_add_position': (_c.c_int, [
         _ptr, _i64, _ptr, _i32, _i32, _ptr, _i32, _i32, _ptr]),
     'emph_attention': (_c.c_int, [

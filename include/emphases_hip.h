@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 2
+#define EMPH_ABI_VERSION 3
 
 /* Segment-table fields */
 enum {
@@ -216,6 +216,44 @@ int emph_output_layer(const float* x, int64_t ldx, const float* weight,
                       const int32_t* position_segment, int64_t total,
                       int32_t axis, int32_t post, float* logits,
                       float* scores, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Fused word stage of the convolutional model                               */
+/* ------------------------------------------------------------------------ */
+
+/* Output words per workgroup of emph_word_decoder for a decoder of `layers`
+ * convolutions of `kernel_size` followed by an output convolution of
+ * `out_kernel_size`: 64 minus the receptive-field halo on both sides.  The
+ * word-axis tile table handed to emph_word_decoder must use this block. */
+int32_t emph_word_decoder_block(int32_t layers, int32_t kernel_size,
+                                int32_t out_kernel_size);
+
+/* `layers` x [Conv1d 'same' + activation] at word rate -> Conv1d(channels, 1)
+ * -> postprocess, in one launch with the word activations resident in LDS and
+ * the weights streamed through LDS by LDS-DMA.
+ *
+ * Replaces word_decoder (emphases/model/core.py:105-107; model/layers/
+ * convolution.py:25-30), output_layer (model/core.py:33-37,138) and
+ * emphases.postprocess (core.py:335-342).  `layers` = 0 gives the
+ * DOWNSAMPLE_LOCATION 'inference' / 'loss' models (model/core.py:109-130).
+ *
+ *   x           float32 [channels, ldx]  word embeddings (word axis), e.g. the
+ *                                        output of emph_segment_reduce
+ *   tiles       int32 [n_tiles][4]       word-axis tile table, block =
+ *                                        emph_word_decoder_block(...)
+ *   packs       float32                  emph_conv_pack of every decoder layer,
+ *                                        back to back
+ *   biases      float32 [layers][channels]
+ *   out_weight  float32 [1][channels][out_kernel_size], out_bias float32 [1]
+ *   logits, scores  float32 [ldx] (either may be NULL)
+ * channels must be a multiple of 16, at most 128.
+ */
+int emph_word_decoder(const float* x, int64_t ldx, const int32_t* tiles,
+                      int32_t n_tiles, int32_t channels, const float* packs,
+                      const float* biases, int32_t layers, int32_t kernel_size,
+                      int32_t activation, const float* out_weight,
+                      const float* out_bias, int32_t out_kernel_size,
+                      int32_t post, float* logits, float* scores, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Transformer blocks (emphases/model/layers/transformer.py:13-52)           */

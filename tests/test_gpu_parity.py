@@ -268,3 +268,20 @@ def test_transformer_position_limit():
     plan = batch.Plan(segments, [0], [frames * 160])
     with pytest.raises(RuntimeError, match='positional encoding'):
         engine.forward(torch.zeros(frames * 160, device=engine.device), plan)
+
+
+def test_many_words_per_segment(default_engine):
+    """Segments far longer than the 64-word window of the fused word stage
+    (halo recompute across word tiles), incl. 1-frame words."""
+    state = {k: torch.from_numpy(v) for k, v in weights.load().items()}
+    for index, (frames, low, high) in enumerate(
+            [(3000, 2, 12), (700, 1, 3), (65 * 8, 8, 8)]):
+        audio = torch.from_numpy(synth.audio(30 + index, frames))
+        bounds = synth.word_frames(30 + index, frames, low, high)
+        assert bounds.shape[1] > 64
+        words = emphases_amd.Alignment.from_frames(bounds)
+        got = emphases_amd.from_alignment_and_audio(words, audio, 16000)
+        want = oracle.from_alignment_and_audio(seconds(bounds), audio, state)
+        assert got.shape == want.shape
+        assert np.abs(got.numpy() - want.numpy()).max() < SCORE_TOLERANCE
+        assert np.abs(got.numpy() - want.numpy()).max() < 5e-6
