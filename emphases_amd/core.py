@@ -90,7 +90,8 @@ def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
         packed = packed.to(device, non_blocking=True)
         with torch.cuda.device(device):
             scores, _ = engine.forward(packed, plan)
-        scores = scores if gpu is not None else scores.cpu()
+        # forward() returns workspace buffers: detach the result from them
+        scores = scores.clone() if gpu is not None else scores.cpu()
         pieces = [[] for _ in audios]
         for segment, off, count in zip(
                 plan.segments, plan.word_off, plan.words):
@@ -304,6 +305,7 @@ class Model:
                 features.to(device, torch.float32), plan, plan.frame_off,
                 plan.frames, plan.ld_frames, device)
             _, logits = engine.forward(None, plan, features=packed)
+            logits = logits.clone()
         width = int(max(int(n) for n in word_lengths))
         result = torch.zeros(
             (features.shape[0], 1, width), dtype=torch.float32, device=device)

@@ -468,7 +468,10 @@ int launch_conv_waves(int n_tiles, int m_blocks, size_t weight_bytes, hipStream_
                        (WAVES * 16 * patch_stride(NB) + MB * 16) * sizeof(float);
     const int patch_offset = static_cast<int>(weight_bytes / sizeof(float));
     auto kernel = conv1d_kernel<KS, MB, NB, WAVES>;
-    if (lds > 64 * 1024) {
+    // raise the kernel's dynamic-LDS limit once per size (not a stream
+    // operation: kept out of the steady state so that launches stay capturable)
+    static size_t reserved = 64 * 1024;
+    if (lds > reserved) {
         hipError_t status = hipFuncSetAttribute(
             reinterpret_cast<const void*>(kernel),
             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -477,6 +480,7 @@ int launch_conv_waves(int n_tiles, int m_blocks, size_t weight_bytes, hipStream_
                       hipGetErrorString(status));
             return static_cast<int>(status);
         }
+        reserved = lds;
     }
     // persistent workgroups: LDS admits one (two for small packs) per CU
     const int groups_of_tiles = (n_tiles + WAVES - 1) / WAVES;

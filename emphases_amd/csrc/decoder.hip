@@ -318,7 +318,8 @@ int emph_word_decoder(const float* x, int64_t ldx, const int32_t* tiles,
     do {                                                                            \
         auto kernel = m_tiles <= 5 ? word_decoder_kernel<KS, 5>                     \
                                    : word_decoder_kernel<KS, 8>;                    \
-        if (lds > 64 * 1024) {                                                      \
+        static size_t reserved[2] = {64 * 1024, 64 * 1024};                         \
+        if (lds > reserved[m_tiles <= 5]) {                                         \
             hipError_t status = hipFuncSetAttribute(                                \
                 reinterpret_cast<const void*>(kernel),                              \
                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
@@ -326,6 +327,7 @@ int emph_word_decoder(const float* x, int64_t ldx, const int32_t* tiles,
                 set_error("emph_word_decoder: cannot reserve %zu bytes of LDS", lds); \
                 return static_cast<int>(status);                                    \
             }                                                                       \
+            reserved[m_tiles <= 5] = lds;                                           \
         }                                                                           \
         hipLaunchKernelGGL(kernel, dim3(n_tiles), dim3(threads), lds, s, x, ldx,     \
                            tiles, block, halo, channels, packs, biases, layers,      \

@@ -24,6 +24,10 @@
 
 #include "common.h"
 
+#ifndef EMPH_STAMP
+#define EMPH_STAMP(slot)   // in-kernel timeline stamps: tools/micro only
+#endif
+
 namespace emph {
 
 namespace {
@@ -42,6 +46,9 @@ constexpr int kStage = kHop * (kBlockFrames - 1) + kFft;       // 5984 samples
 constexpr int kExRow = 72;                                     // complex per exchange row
 constexpr int kExFloats = 2 * 8 * kExRow;                      // 1152 floats per wave
 constexpr int kOutStride = kBlockFrames + 1;
+constexpr int kMagFloats = 520;                                 // 513 magnitudes per wave
+constexpr int kRunA = 20;    // longest run of bins among filterbank rows 0..63
+constexpr int kRunB = 10;    // a quarter of the longest run among rows 64..79
 
 // Table layout (floats)
 constexpr int kTabWindow = 0;                  // [1024]
@@ -115,12 +122,13 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     constexpr bool kPeak = MODE == 1;
 
     extern __shared__ __align__(16) float lds[];
+    EMPH_STAMP(0);
     float* stage = lds;                                  // [kStage]
     float* exchange = stage + kStage;                    // [4][kExFloats]
     float* tile = exchange + 4 * kExFloats;              // [80][kOutStride]
     float* loud_tile = tile + kMels * kOutStride;        // [kBlockFrames]
-    float* basis = loud_tile + kBlockFrames;             // [mel_nnz]
-    float* weights = basis + (kMel ? ((mel_nnz + 3) & ~3) : 0);  // [513+]
+    float* mel_sums = loud_tile + kBlockFrames;          // [4][kMagFloats] magnitudes
+    float* weights = mel_sums + 4 * kMagFloats;          // [513+]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -136,22 +144,32 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     const int64_t frame_off = row[EMPH_SEG_FRAME_OFF];
     const int frames = static_cast<int>(row[EMPH_SEG_FRAMES]);
 
-    // ---- stage the block's samples: zero pad + slice + reflect in one pass
+    // ---- stage the block's samples: zero pad + slice + reflect in one pass.
+    // Every load is unconditional (clamped address, masked value) and the loop
+    // is fully unrolled, so a thread's 24 requests are in flight together; a
+    // predicated, rolled loop pays one 1-2 us memory round trip per sample.
     const int64_t first = static_cast<int64_t>(frame0) * kHop - kPad;
-    for (int index = tid; index < kStage; index += 256) {
-        int64_t r = first + index;             // position in the chunk
-        if (r < 0) r = -r;                     // reflect (no edge repeat)
-        if (r >= length) r = 2 * (length - 1) - r;
-        float value = 0.f;
-        if (r >= 0 && r < length) {
-            const int64_t a = start + r - kPad;   // undo the 432 zero pad
-            if (a >= 0 && a < audio_len) value = audio[audio_off + a];
+    {
+        constexpr int kPerThread = (kStage + 255) / 256;
+        float value[kPerThread];
+        bool live[kPerThread];
+        const float* source = audio + audio_off;
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            int64_t r = first + tid + 256 * j;     // position in the chunk
+            if (r < 0) r = -r;                     // reflect (no edge repeat)
+            if (r >= length) r = 2 * (length - 1) - r;
+            const int64_t a = start + r - kPad;    // undo the 432 zero pad
+            live[j] = r >= 0 && r < length && a >= 0 && a < audio_len;
+            const int64_t clamped = a < 0 ? 0 : (a >= audio_len ? audio_len - 1 : a);
+            value[j] = source[audio_len > 0 ? clamped : 0];
         }
-        stage[index] = value;
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const int index = tid + 256 * j;
+            if (index < kStage) stage[index] = live[j] ? value[j] : 0.f;
+        }
     }
-    if (kMel)
-        for (int index = tid; index < mel_nnz; index += 256)
-            basis[index] = mel_values[index];
     if (kLoud)
         for (int index = tid; index < kBins; index += 256)
             weights[index] = a_weights[index];
@@ -175,24 +193,35 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     }
     const cf tw_nyquist = {table[kTabTw3 + 2 * 512], table[kTabTw3 + 2 * 512 + 1]};
 
-    // mel rows owned by this lane: row `lane`, and a quarter of row 64+lane/4
-    int row_a_start = 0, row_a_count = 0, row_a_off = 0;
-    int row_b_start = 0, row_b_count = 0, row_b_off = 0;
+    // Sparse mel projection: every filterbank row is a contiguous run of bins.
+    // Rows 0..63 (runs of at most kRunA bins) get one lane each; rows 64..79
+    // (runs of at most 4*kRunB) get four lanes each.  The run weights live in
+    // registers for the whole block, zero-padded to a fixed length so that the
+    // per-frame loops are fully unrolled with every LDS read independent.
+    float weight_a[kRunA], weight_b[kRunB];
+    int start_a = 0, start_b = 0;
     if (kMel) {
-        row_a_start = mel_start[lane];
-        row_a_count = mel_count[lane];
-        row_a_off = mel_offset[lane];
-        const int rb = 64 + (lane >> 2);
-        row_b_start = mel_start[rb];
-        row_b_count = mel_count[rb];
-        row_b_off = mel_offset[rb];
+        start_a = mel_start[lane];
+        const int count_a = mel_count[lane];
+        const int offset_a = mel_offset[lane];
+#pragma unroll
+        for (int j = 0; j < kRunA; ++j)
+            weight_a[j] = j < count_a ? mel_values[min(offset_a + j, mel_nnz - 1)] : 0.f;
+        const int row_b = 64 + (lane >> 2);
+        start_b = mel_start[row_b] + (lane & 3);
+        const int count_b = mel_count[row_b];
+        const int offset_b = mel_offset[row_b];
+#pragma unroll
+        for (int j = 0; j < kRunB; ++j) {
+            const int index = (lane & 3) + 4 * j;
+            weight_b[j] = index < count_b ? mel_values[min(offset_b + index, mel_nnz - 1)] : 0.f;
+        }
     }
 
     __syncthreads();
+    EMPH_STAMP(1);
 
     cf* ex = reinterpret_cast<cf*>(exchange + wave * kExFloats);
-    // magnitudes reuse the wave's exchange buffer once the spectrum is consumed
-    float* mag = exchange + wave * kExFloats;
     float peak = 0.f;
     float floor_db = 0.f;
     if (kLoud) {
@@ -213,6 +242,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(
                 *reinterpret_cast<const float2*>(samples + 2 * (p + 64 * q));
             v[q] = {pair.x * window[2 * q], pair.y * window[2 * q + 1]};
         }
+        if (local == wave) EMPH_STAMP(2);
         dft8(v);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -221,6 +251,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         }
         wave_lds_fence();
 
+        if (local == wave) EMPH_STAMP(3);
         // pass 2: lane (r, p0) takes A[p0 + 8 p1][r], radix-8 over p1
 #pragma unroll
         for (int p1 = 0; p1 < 8; ++p1) v[p1] = ex[r1 * kExRow + p0 + 8 * p1];
@@ -233,6 +264,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         }
         wave_lds_fence();
 
+        if (local == wave) EMPH_STAMP(4);
         // pass 3: lane (r, t) takes C[r][p0][t], radix-8 over p0
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = ex[r1 * kExRow + p0 * 8 + q];
@@ -243,6 +275,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         for (int u = 0; u < 8; ++u) ex[r1 + 8 * p0 + 64 * u] = v[u];
         wave_lds_fence();
 
+        if (local == wave) EMPH_STAMP(5);
         // real-FFT split for bins k = lane + 64 j (and k = 512 on lane 0)
         float power[9];
 #pragma unroll
@@ -264,6 +297,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         }
         wave_lds_fence();
 
+        if (local == wave) EMPH_STAMP(6);
         if (kPeak) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) peak = fmaxf(peak, power[j]);
@@ -294,23 +328,22 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         }
 
         if (kMel) {
+            float* mag = mel_sums + wave * kMagFloats;
 #pragma unroll
             for (int j = 0; j < 8; ++j) mag[lane + 64 * j] = sqrtf(power[j] + 1e-6f);
             if (lane == 0) mag[512] = sqrtf(power[8] + 1e-6f);
             wave_lds_fence();
-
-            // rows 0..63: one lane per row (runs of 4..20 bins)
             float acc = 0.f;
-            for (int j = 0; j < row_a_count; ++j)
-                acc = fmaf(basis[row_a_off + j], mag[row_a_start + j], acc);
+#pragma unroll
+            for (int j = 0; j < kRunA; ++j)
+                acc = fmaf(weight_a[j], mag[min(start_a + j, kBins - 1)], acc);
             float value = logf(fmaxf(acc, 1e-5f));
             if (normalize) value = (value + 10.f) / 10.f;
             tile[lane * kOutStride + local] = value;
-
-            // rows 64..79: four lanes per row (runs of 21..37 bins)
             acc = 0.f;
-            for (int j = lane & 3; j < row_b_count; j += 4)
-                acc = fmaf(basis[row_b_off + j], mag[row_b_start + j], acc);
+#pragma unroll
+            for (int j = 0; j < kRunB; ++j)
+                acc = fmaf(weight_b[j], mag[min(start_b + 4 * j, kBins - 1)], acc);
             acc += __shfl_xor(acc, 1);
             acc += __shfl_xor(acc, 2);
             if ((lane & 3) == 0) {
@@ -320,7 +353,9 @@ __global__ __launch_bounds__(256) void frontend_kernel(
             }
             wave_lds_fence();
         }
+        if (local == wave) EMPH_STAMP(7);
     }
+    EMPH_STAMP(8);
 
     if (kPeak) {
         peak = wave_max(peak);
@@ -344,11 +379,12 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     if (kLoud && tid < valid)
         out[static_cast<int64_t>(loud_row) * ld + frame_off + frame0 + tid] =
             loud_tile[tid];
+    EMPH_STAMP(9);
 }
 
-size_t frontend_lds_bytes(bool mel, bool loud, int mel_nnz) {
-    size_t floats = kStage + 4 * kExFloats + kMels * kOutStride + kBlockFrames;
-    if (mel) floats += (mel_nnz + 3) & ~3;
+size_t frontend_lds_bytes(bool loud) {
+    size_t floats = kStage + 4 * kExFloats + kMels * kOutStride + kBlockFrames +
+                    4 * kMagFloats;
     if (loud) floats += 516;
     return floats * sizeof(float);
 }
@@ -411,7 +447,7 @@ int emph_logmel(const float* audio, const int64_t* seg, const int32_t* tiles,
                  "emph_logmel: mel_nnz %d out of range", mel_nnz);
     EMPH_REQUIRE(!loud || (seg_peak && a_weights), EMPH_EINVAL,
                  "emph_logmel: loudness needs seg_peak and a_weights");
-    const size_t lds = frontend_lds_bytes(mel, loud, mel_nnz);
+    const size_t lds = frontend_lds_bytes(loud);
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* peak = const_cast<float*>(seg_peak);
 #define EMPH_LAUNCH(MODE)                                                      \
@@ -435,7 +471,7 @@ int emph_frontend_peak(const float* audio, const int64_t* seg,
     if (n_tiles == 0) return EMPH_OK;
     EMPH_REQUIRE(audio && seg && tiles && table && seg_peak, EMPH_EINVAL,
                  "emph_frontend_peak: null pointer");
-    const size_t lds = frontend_lds_bytes(false, false, 0);
+    const size_t lds = frontend_lds_bytes(false);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int32_t* none_i = nullptr;
     const float* none_f = nullptr;

@@ -70,6 +70,7 @@ class Engine:
         # when a list, every kernel launch is bracketed by HIP events on the
         # launch stream: (name, algorithmic flops, start, end)
         self.timers = None
+        self._workspace = {}
         state = weights_module.load(state, config)
         self.state = state
         dev = self.device
@@ -193,6 +194,19 @@ class Engine:
         end.record()
         self.timers.append((name, flops, begin, end))
 
+    def _buffer(self, name, *shape):
+        """Reusable float32 scratch tensor.  Contents are undefined: every
+        kernel masks what lies outside a segment by selection, never by
+        arithmetic, so stale or non-finite padding cannot leak into results."""
+        key = (name, shape)
+        tensor = self._workspace.get(key)
+        if tensor is None:
+            for stale in [k for k in self._workspace if k[0] == name]:
+                del self._workspace[stale]
+            tensor = torch.empty(shape, dtype=torch.float32, device=self.device)
+            self._workspace[key] = tensor
+        return tensor
+
     def _conv(self, layer, x, ldx, y, ldy, meta, axis, block, activation,
               transpose_out=False):
         tiles, size = meta[('tiles', axis, block)]
@@ -201,30 +215,22 @@ class Engine:
                 f'_{layer.c_in}x{layer.c_out}_k{layer.kernel_size}')
         flops = 2. * layer.c_in * layer.c_out * layer.kernel_size * positions
         with self._timed(name, flops):
-            self._conv_launch(layer, x, ldx, y, ldy, meta, axis, block,
-                              activation, transpose_out, tiles, size)
+            runtime.check(self.lib.emph_conv1d(
+                x.data_ptr(), ldx, y.data_ptr(), ldy, layer.pack.data_ptr(),
+                None if layer.bias is None else layer.bias.data_ptr(),
+                layer.c_in, layer.c_out, layer.kernel_size,
+                runtime.ACTIVATIONS[activation], tiles.data_ptr(),
+                size // runtime.TILE_FIELDS, block, int(transpose_out),
+                runtime.stream()), 'emph_conv1d')
 
-    def _conv_launch(self, layer, x, ldx, y, ldy, meta, axis, block,
-                     activation, transpose_out, tiles, size):
-        runtime.check(self.lib.emph_conv1d(
-            x.data_ptr(), ldx, y.data_ptr(), ldy, layer.pack.data_ptr(),
-            None if layer.bias is None else layer.bias.data_ptr(),
-            layer.c_in, layer.c_out, layer.kernel_size,
-            runtime.ACTIVATIONS[activation], tiles.data_ptr(),
-            size // runtime.TILE_FIELDS, block, int(transpose_out),
-            runtime.stream()), 'emph_conv1d')
-
-    def features(self, audio, plan, meta, out=None, extra_rows=None):
+    def features(self, audio, plan, meta, extra_rows=None):
         """Feature matrix [num_features, ld_frames] of every segment
         (`data/preprocess/core.py:71-125`).  Pitch/periodicity rows come from
         a third-party neural tracker (`penn`) and are accepted only as
         precomputed packed rows in `extra_rows`."""
         config = self.config
         rows = config.num_features
-        if out is None:
-            out = torch.empty(
-                (rows, plan.ld_frames), dtype=torch.float32,
-                device=self.device)
+        out = self._buffer('features', rows, plan.ld_frames)
         mel_row = 0 if config.mel_feature else -1
         loud_row = rows - 1 if config.loudness_feature else -1
         extra = int(config.pitch_feature) + int(config.periodicity_feature)
@@ -236,36 +242,36 @@ class Engine:
             first = cfg.NUM_MELS if config.mel_feature else 0
             out[first:first + extra] = extra_rows
         tiles, size = meta[('tiles', runtime.AXIS_FRAMES, FRONTEND_BLOCK)]
+        count = size // runtime.TILE_FIELDS
         table = meta['table'][0]
         peak = None
         if config.loudness_feature:
             peak = torch.zeros(
                 len(plan.segments), dtype=torch.float32, device=self.device)
-            runtime.check(self.lib.emph_frontend_peak(
-                audio.data_ptr(), table.data_ptr(), tiles.data_ptr(),
-                size // runtime.TILE_FIELDS, self.table.data_ptr(),
-                peak.data_ptr(),
-                runtime.stream()), 'emph_frontend_peak')
+            with self._timed('frontend_peak'):
+                runtime.check(self.lib.emph_frontend_peak(
+                    audio.data_ptr(), table.data_ptr(), tiles.data_ptr(),
+                    count, self.table.data_ptr(), peak.data_ptr(),
+                    runtime.stream()), 'emph_frontend_peak')
         if mel_row >= 0 or loud_row >= 0:
-          with self._timed('frontend_logmel'):
-            runtime.check(self.lib.emph_logmel(
-                audio.data_ptr(), table.data_ptr(), tiles.data_ptr(),
-                size // runtime.TILE_FIELDS, self.table.data_ptr(),
-                self.mel_start.data_ptr(),
-                self.mel_count.data_ptr(), self.mel_offset.data_ptr(),
-                self.mel_values.data_ptr(), self.mel_nnz, out.data_ptr(),
-                plan.ld_frames, mel_row, loud_row,
-                None if peak is None else peak.data_ptr(),
-                self.a_weights.data_ptr(), int(config.normalize),
-                runtime.stream()), 'emph_logmel')
+            with self._timed('frontend_logmel'):
+                runtime.check(self.lib.emph_logmel(
+                    audio.data_ptr(), table.data_ptr(), tiles.data_ptr(),
+                    count, self.table.data_ptr(), self.mel_start.data_ptr(),
+                    self.mel_count.data_ptr(), self.mel_offset.data_ptr(),
+                    self.mel_values.data_ptr(), self.mel_nnz, out.data_ptr(),
+                    plan.ld_frames, mel_row, loud_row,
+                    None if peak is None else peak.data_ptr(),
+                    self.a_weights.data_ptr(), int(config.normalize),
+                    runtime.stream()), 'emph_logmel')
         return out
 
-    def _transformer(self, layers, x, ld, plan, meta, axis, block, scratch):
+    def _transformer(self, layers, x, ld, plan, meta, axis, block, tag):
         """`Transformer.forward` (transformer.py:25-30) in place on x."""
         config = self.config
         channels = config.channels
-        table = meta['table'][0]
         att_tiles, att_size = meta[('tiles', axis, ATTENTION_BLOCK)]
+        att_count = att_size // runtime.TILE_FIELDS
         counts = plan.frames if axis == runtime.AXIS_FRAMES else plan.words
         if len(counts) and int(counts.max()) > cfg.MAX_POSITIONS:
             # transformer.py:40,51-52: the encoding table has 5000 rows
@@ -273,58 +279,57 @@ class Engine:
                 f'a chunk of {int(counts.max())} positions exceeds the '
                 f'{cfg.MAX_POSITIONS}-entry positional encoding; pass a '
                 'smaller batch_size')
-        runtime.check(self.lib.emph_add_position(
-            x.data_ptr(), ld, self.position.data_ptr(), channels,
-            cfg.MAX_POSITIONS, att_tiles.data_ptr(),
-            att_size // runtime.TILE_FIELDS, ATTENTION_BLOCK, runtime.stream()),
-            'emph_add_position')
-        qk, v, attended, projected = scratch
+        with self._timed('add_position'):
+            runtime.check(self.lib.emph_add_position(
+                x.data_ptr(), ld, self.position.data_ptr(), channels,
+                cfg.MAX_POSITIONS, att_tiles.data_ptr(), att_count,
+                ATTENTION_BLOCK, runtime.stream()), 'emph_add_position')
+        qk = self._buffer(tag + '_qk', 2 * channels, ld)
+        v = self._buffer(tag + '_v', ld, channels)
+        attended = self._buffer(tag + '_attended', channels, ld)
+        projected = self._buffer(tag + '_projected', channels, ld)
+        attention_flops = 4. * channels * float(
+            (counts.astype(np.float64) ** 2).sum())
+
+        def add_layernorm(norm):
+            with self._timed('add_layernorm'):
+                runtime.check(self.lib.emph_add_layernorm(
+                    x.data_ptr(), projected.data_ptr(), x.data_ptr(), ld,
+                    channels, norm[0].data_ptr(), norm[1].data_ptr(),
+                    config.layer_norm_eps, 0, ld, runtime.stream()),
+                    'emph_add_layernorm')
+
         for layer in layers:
             self._conv(layer['qk'], x, ld, qk, ld, meta, axis, block, None)
             self._conv(layer['v'], x, ld, v, channels, meta, axis, block, None,
                        transpose_out=True)
-            with self._timed('attention', 4. * channels * float(
-                    (counts.astype(np.float64) ** 2).sum())):
-              runtime.check(self.lib.emph_attention(
-                qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld, channels,
-                config.heads, att_tiles.data_ptr(),
-                att_size // runtime.TILE_FIELDS, runtime.stream()),
-                'emph_attention')
+            with self._timed('attention', attention_flops):
+                runtime.check(self.lib.emph_attention(
+                    qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld,
+                    channels, config.heads, att_tiles.data_ptr(), att_count,
+                    runtime.stream()), 'emph_attention')
             self._conv(layer['out'], attended, ld, projected, ld, meta, axis,
                        block, None)
-            runtime.check(self.lib.emph_add_layernorm(
-                x.data_ptr(), projected.data_ptr(), x.data_ptr(), ld, channels,
-                layer['norm1'][0].data_ptr(), layer['norm1'][1].data_ptr(),
-                config.layer_norm_eps, 0, ld, runtime.stream()),
-                'emph_add_layernorm')
+            add_layernorm(layer['norm1'])
             self._conv(layer['linear1'], x, ld, attended, ld, meta, axis,
                        block, 'relu')
             self._conv(layer['linear2'], attended, ld, projected, ld, meta,
                        axis, block, None)
-            runtime.check(self.lib.emph_add_layernorm(
-                x.data_ptr(), projected.data_ptr(), x.data_ptr(), ld, channels,
-                layer['norm2'][0].data_ptr(), layer['norm2'][1].data_ptr(),
-                config.layer_norm_eps, 0, ld, runtime.stream()),
-                'emph_add_layernorm')
+            add_layernorm(layer['norm2'])
         return x
 
-    def _stack_forward(self, layers, x, other, ld, plan, meta, axis, block):
+    def _stack_forward(self, layers, x, other, ld, plan, meta, axis, block,
+                       tag):
         """Frame encoder / word decoder; returns the tensor holding the
-        result (one of x / other)."""
+        result (x or other)."""
         config = self.config
         if config.architecture == 'convolution':
             for layer in layers:
                 self._conv(layer, x, ld, other, ld, meta, axis, block,
                            config.activation)
                 x, other = other, x
-            return x, other
-        channels = config.channels
-        empty = lambda *shape: torch.zeros(  # noqa: E731
-            shape, dtype=torch.float32, device=self.device)
-        scratch = (empty(2 * channels, ld), empty(ld, channels),
-                   empty(channels, ld), other)
-        return self._transformer(
-            layers, x, ld, plan, meta, axis, block, scratch), other
+            return x
+        return self._transformer(layers, x, ld, plan, meta, axis, block, tag)
 
     ###########################################################################
     # Forward
@@ -336,7 +341,9 @@ class Engine:
 
         audio: float32 device tensor, all utterances back to back.
         Returns (scores, logits): float32 [ld_words] on the packed word axis
-        (`plan.word_columns()` picks the valid entries)."""
+        (`plan.word_columns()` picks the valid entries; other entries are
+        undefined).  The tensors are workspace buffers: they are overwritten
+        by the next forward() of this engine."""
         config = self.config
         if config.downsample_location == 'input':
             raise NotImplementedError(
@@ -346,38 +353,38 @@ class Engine:
         block = meta['tile']
         channels = config.channels
         ld_f, ld_w = plan.ld_frames, plan.ld_words
-        zeros = lambda *shape: torch.zeros(  # noqa: E731
-            shape, dtype=torch.float32, device=self.device)
+        frames, words = runtime.AXIS_FRAMES, runtime.AXIS_WORDS
         if features is None:
             features = self.features(audio, plan, meta, extra_rows=extra_rows)
-        a, b = zeros(channels, ld_f), zeros(channels, ld_f)
-        self._conv(self.input_layer, features, ld_f, a, ld_f, meta,
-                   runtime.AXIS_FRAMES, block, None)
+        a = self._buffer('frames_a', channels, ld_f)
+        b = self._buffer('frames_b', channels, ld_f)
+        self._conv(self.input_layer, features, ld_f, a, ld_f, meta, frames,
+                   block, None)
         if stages is not None:
-            stages['features'] = features
+            stages['features'] = features.clone()
             stages['input_layer'] = a.clone()
-        encoded, _ = self._stack_forward(
-            self.frame_encoder, a, b, ld_f, plan, meta, runtime.AXIS_FRAMES,
-            block)
+        encoded = self._stack_forward(
+            self.frame_encoder, a, b, ld_f, plan, meta, frames, block,
+            'frames')
         if stages is not None:
-            stages['encoder'] = encoded
+            stages['encoder'] = encoded.clone()
 
         check_bounds(plan, config.downsample_method)
         table = meta['table'][0]
-        logits = zeros(ld_w)
-        scores = zeros(ld_w)
-        wa, wb = zeros(channels, ld_w), zeros(channels, ld_w)
+        logits = self._buffer('logits', ld_w)
+        scores = self._buffer('scores', ld_w)
+        wa = self._buffer('words_a', channels, ld_w)
         with self._timed('segment_reduce'):
-          runtime.check(self.lib.emph_segment_reduce(
-            encoded.data_ptr(), ld_f, meta['bounds'][0].data_ptr(),
-            wa.data_ptr(), ld_w, channels, table.data_ptr(),
-            meta['word_segment'][0].data_ptr(), ld_w,
-            runtime.REDUCTIONS[config.downsample_method], runtime.stream()),
-            'emph_segment_reduce')
+            runtime.check(self.lib.emph_segment_reduce(
+                encoded.data_ptr(), ld_f, meta['bounds'][0].data_ptr(),
+                wa.data_ptr(), ld_w, channels, table.data_ptr(),
+                meta['word_segment'][0].data_ptr(), ld_w,
+                runtime.REDUCTIONS[config.downsample_method],
+                runtime.stream()), 'emph_segment_reduce')
         if stages is not None:
             stages['downsampled'] = wa.clone()
         if self.fused_words:
-            tiles, size = meta[('tiles', runtime.AXIS_WORDS, self.word_block)]
+            tiles, size = meta[('tiles', words, self.word_block)]
             with self._timed('word_decoder', 2. * channels * (
                     channels * config.decoder_kernel_size * self.decoder_layers
                     + config.decoder_kernel_size) * plan.total_words):
@@ -395,20 +402,40 @@ class Engine:
                     runtime.POSTPROCESS[config.loss], logits.data_ptr(),
                     scores.data_ptr(), runtime.stream()), 'emph_word_decoder')
             return scores, logits
-        decoded = wa
-        if config.downsample_location == 'intermediate':
-            decoded, _ = self._stack_forward(
-                self.word_decoder, wa, wb, ld_w, plan, meta,
-                runtime.AXIS_WORDS, self.word_block)
+        wb = self._buffer('words_b', channels, ld_w)
+        decoded = self._stack_forward(
+            self.word_decoder, wa, wb, ld_w, plan, meta, words,
+            self.word_block, 'words')
         with self._timed('output_layer'):
-          runtime.check(self.lib.emph_output_layer(
-            decoded.data_ptr(), ld_w, self.output_weight.data_ptr(),
-            self.output_bias.data_ptr(), channels, config.decoder_kernel_size,
-            table.data_ptr(), meta['word_segment'][0].data_ptr(), ld_w,
-            runtime.AXIS_WORDS, runtime.POSTPROCESS[config.loss],
-            logits.data_ptr(), scores.data_ptr(), runtime.stream()),
-            'emph_output_layer')
+            runtime.check(self.lib.emph_output_layer(
+                decoded.data_ptr(), ld_w, self.output_weight.data_ptr(),
+                self.output_bias.data_ptr(), channels,
+                config.decoder_kernel_size, table.data_ptr(),
+                meta['word_segment'][0].data_ptr(), ld_w, words,
+                runtime.POSTPROCESS[config.loss], logits.data_ptr(),
+                scores.data_ptr(), runtime.stream()), 'emph_output_layer')
         return scores, logits
+
+    def capture(self, audio, plan, meta=None):
+        """Capture forward() for this (audio buffer, plan) into a HIP graph.
+
+        Returns `(replay, scores, logits)`: `replay()` re-enqueues the whole
+        kernel sequence with one host call (about 10 us instead of one
+        launch per kernel) and refreshes `scores` / `logits` in place.  The
+        audio tensor may be refilled between replays; its address and the
+        plan must not change."""
+        meta = meta or self.upload(plan)
+        self.timers = None
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):       # warm up: attribute calls, buffers
+            for _ in range(2):
+                self.forward(audio, plan, meta)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            scores, logits = self.forward(audio, plan, meta)
+        return graph.replay, scores, logits
 
 
 def check_bounds(plan, method):

@@ -76,6 +76,12 @@ class SparseBasis:
             offset += hi - lo
         self.values = np.concatenate(values).astype(np.float32)
         self.max_count = int(self.row_count.max())
+        # limits of the HIP front-end (csrc/frontend.hip: kRunA, kRunB)
+        if rows != 80 or self.row_count[:64].max() > 20 or \
+                self.row_count[64:].max() > 40:
+            raise ValueError(
+                'the front-end kernel needs 80 filterbank rows whose runs hold '
+                'at most 20 bins (rows 0..63) / 40 bins (rows 64..79)')
 
     @property
     def nnz(self):

@@ -121,7 +121,9 @@ int emph_frontend_table_fill(float* host_table);
  *   tiles        int32 [n_tiles][4] tile table of the frame axis, 32-frame blocks
  *   table        float32            from emph_frontend_table_fill
  *   mel_start/mel_count/mel_offset  int32 [80] run of each filterbank row
- *   mel_values   float32 [nnz]      run values (librosa.filters.mel restated)
+ *   mel_values   float32 [nnz]      run values (librosa.filters.mel restated);
+ *                                   runs of rows 0..63 may hold at most 20 bins,
+ *                                   runs of rows 64..79 at most 40
  *   out          float32 [rows, ld] rows 0..79 receive the mel rows when
  *                                   `mel_row >= 0` (row index of the first)
  *   loud_row     row that receives A-weighted loudness, or -1

@@ -1,0 +1,82 @@
+// Standalone timeline of emph_logmel on the C2 layout (64 x 10 s).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <algorithm>
+#include <vector>
+#include <math.h>
+__device__ unsigned long long* g_stamps = nullptr;
+#define EMPH_STAMP(slot)                                                          \
+    do {                                                                          \
+        if (g_stamps != nullptr && (threadIdx.x & 63) == 0)                       \
+            g_stamps[(static_cast<size_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + \
+                     (slot)] = __builtin_amdgcn_s_memrealtime();                  \
+    } while (0)
+#include "../../emphases_amd/csrc/frontend.hip"
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+int main() {
+    const int segments = 64, frames = 1000, samples = 160000;
+    const int64_t ld = 16 + static_cast<int64_t>(segments) * 1008 + 128;
+    std::vector<float> haudio(static_cast<size_t>(segments) * samples);
+    for (size_t i = 0; i < haudio.size(); ++i) haudio[i] = 0.1f * sinf(0.01f * (i % 100000)) + 1e-3f * ((i * 2654435761u) % 1000) / 1000.f;
+    std::vector<int64_t> hseg(segments * 8, 0);
+    std::vector<int32_t> tiles;
+    for (int s = 0; s < segments; ++s) {
+        hseg[s * 8 + 0] = static_cast<int64_t>(s) * samples; hseg[s * 8 + 1] = samples;
+        hseg[s * 8 + 2] = 0; hseg[s * 8 + 3] = samples;
+        hseg[s * 8 + 4] = 16 + s * 1008; hseg[s * 8 + 5] = frames;
+        for (int t = 0; t < frames; t += 32) { tiles.push_back(s); tiles.push_back(t); tiles.push_back(16 + s * 1008); tiles.push_back(frames); }
+    }
+    // a plausible sparse basis: 80 rows, runs like the real one
+    std::vector<int32_t> start(80), count(80), offset(80);
+    std::vector<float> values;
+    int bin = 1;
+    for (int m = 0; m < 80; ++m) {
+        count[m] = m < 64 ? 4 + (16 * m) / 63 : 21 + (m - 64);
+        start[m] = std::min(bin, 512 - count[m]); offset[m] = values.size();
+        for (int j = 0; j < count[m]; ++j) values.push_back(0.01f);
+        bin += std::max(1, count[m] / 2);
+    }
+    std::vector<float> table(emph_frontend_table_size());
+    emph_frontend_table_fill(table.data());
+    float *audio, *dtable, *dvalues, *out; int64_t* seg; int32_t *dtiles, *dstart, *dcount, *doffset;
+    CHECK(hipMalloc(&audio, haudio.size() * 4)); CHECK(hipMemcpy(audio, haudio.data(), haudio.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&dtable, table.size() * 4)); CHECK(hipMemcpy(dtable, table.data(), table.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&dvalues, values.size() * 4)); CHECK(hipMemcpy(dvalues, values.data(), values.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&out, 80 * ld * 4));
+    CHECK(hipMalloc(&seg, hseg.size() * 8)); CHECK(hipMemcpy(seg, hseg.data(), hseg.size() * 8, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&dtiles, tiles.size() * 4)); CHECK(hipMemcpy(dtiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&dstart, 320)); CHECK(hipMemcpy(dstart, start.data(), 320, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&dcount, 320)); CHECK(hipMemcpy(dcount, count.data(), 320, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&doffset, 320)); CHECK(hipMemcpy(doffset, offset.data(), 320, hipMemcpyHostToDevice));
+    const int n_tiles = tiles.size() / 4;
+    auto launch = [&]() {
+        int status = emph_logmel(audio, seg, dtiles, n_tiles, dtable, dstart, dcount, doffset, dvalues,
+                                 (int)values.size(), out, ld, 0, -1, nullptr, nullptr, 0, nullptr);
+        if (status) { printf("launch failed %d %s\n", status, emph_last_error()); exit(1); }
+    };
+    for (int i = 0; i < 3; ++i) launch();
+    CHECK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < 20; ++i) launch();
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("frontend: %d blocks, %.2f us/launch (%.1f ns/frame)\n", n_tiles, ms * 1e3 / 20, ms * 1e6 / 20 / (segments * frames));
+    const size_t slots = static_cast<size_t>(n_tiles) * 4 * 16;
+    unsigned long long* stamps; CHECK(hipMalloc(&stamps, slots * 8)); CHECK(hipMemset(stamps, 0, slots * 8));
+    CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &stamps, sizeof(stamps)));
+    launch(); CHECK(hipDeviceSynchronize());
+    std::vector<unsigned long long> host(slots);
+    CHECK(hipMemcpy(host.data(), stamps, slots * 8, hipMemcpyDeviceToHost));
+    const char* names[16] = {"start", "staged", "f0 loaded", "f0 pass1", "f0 pass2", "f0 pass3", "f0 split", "f0 mel", "frames", "stored", "", "", "", "", "", ""};
+    for (int slot = 1; slot < 10; ++slot) {
+        std::vector<double> values2;
+        for (size_t i = 0; i < slots; i += 16) if (host[i] && host[i + slot]) values2.push_back((host[i + slot] - host[i]) * 0.01);
+        if (values2.empty()) continue;
+        std::sort(values2.begin(), values2.end());
+        printf("   %-10s waves=%5zu  min %7.2f  median %7.2f  max %7.2f us after the wave's start\n", names[slot], values2.size(), values2.front(), values2[values2.size() / 2], values2.back());
+    }
+    return 0;
+}
