@@ -125,9 +125,13 @@ def main():
         [torch.from_numpy(a).reshape(-1) for a in audios]).to(device)
     meta = engine.upload(plan)
     columns = torch.from_numpy(plan.word_columns()).to(device)
-    gathered = [
-        torch.empty(plan.total_words, dtype=torch.float32, device=device)
-        for _ in range(world)] if world > 1 else None
+    gathered = send = None
+    if world > 1:
+        # ranks hold different numbers of words: pad to the largest shard
+        most = torch.tensor([plan.total_words], device=device)
+        torch.distributed.all_reduce(most, op=torch.distributed.ReduceOp.MAX)
+        send = torch.zeros(int(most.item()), dtype=torch.float32, device=device)
+        gathered = [torch.empty_like(send) for _ in range(world)]
 
     if args.no_graph:
         scores_buffer = None
@@ -144,9 +148,9 @@ def main():
     def step():
         scores = run_path()
         if world > 1:
-            # every rank's utterances have the same word counts only by
-            # construction of this synthetic workload; pad to the max otherwise
-            torch.distributed.all_gather(gathered, scores[columns])
+            # the one exchange of the path: RCCL all_gather of per-word scores
+            send[:plan.total_words] = scores[columns]
+            torch.distributed.all_gather(gathered, send)
         return scores
 
     def barrier():
