@@ -187,6 +187,13 @@ def main():
     dominant = max(kernels, key=lambda name: kernels[name][1])
     launches, seconds, flops = kernels[dominant]
     achieved = flops / seconds / 1e12
+    # HBM bytes per launch of that kernel from the committed PMC passes
+    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
+    traffic = None
+    summary = os.path.join(ROOT, 'profiles', 'r1_pmc_summary.json')
+    if args.config == 'conv' and os.path.exists(summary):
+        with open(summary) as file:
+            traffic = json.load(file).get(dominant, {}).get('traffic_bytes')
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -218,7 +225,8 @@ def main():
                 'avg_launch_us': seconds / launches * 1e6,
                 'share_of_step': seconds / min(args.steps, 10) /
                     (elapsed / args.steps),
-                'traffic': None},
+                'traffic': traffic,
+                'algorithmic_flops_per_launch': flops / launches},
             'kernels_us_per_step': {
                 name: value[1] / min(args.steps, 10) * 1e6
                 for name, value in kernels.items()},

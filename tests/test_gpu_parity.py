@@ -285,3 +285,32 @@ def test_many_words_per_segment(default_engine):
         assert got.shape == want.shape
         assert np.abs(got.numpy() - want.numpy()).max() < SCORE_TOLERANCE
         assert np.abs(got.numpy() - want.numpy()).max() < 5e-6
+
+
+def test_file_api_and_cli(tmp_path, cases):
+    """from_files_to_files / CLI: TextGrid + WAV in, .TextGrid + .pt out
+    (emphases/core.py:115-179, emphases/__main__.py)."""
+    import subprocess
+    import sys
+    from emphases_amd import load
+    audio, bounds, _ = case_inputs(cases, 'utt_10s')
+    words = emphases_amd.Alignment.from_frames(
+        bounds, synth.word_names(bounds.shape[1]))
+    words.save(tmp_path / 'utt.TextGrid')
+    load.save_wav(tmp_path / 'utt.wav', audio)
+    emphases_amd.from_files_to_files(
+        [tmp_path / 'utt.TextGrid'], [tmp_path / 'utt.wav'],
+        [tmp_path / 'out'], gpu=0)
+    scores = torch.load(tmp_path / 'out.pt')
+    assert scores.shape == (1, bounds.shape[1]) and not scores.is_cuda
+    assert np.abs(scores[0].numpy() - cases['utt_10s/scores']).max() < \
+        SCORE_TOLERANCE
+    saved = emphases_amd.Alignment(tmp_path / 'out.TextGrid')
+    assert len(saved) == len(words)
+    from conftest import ROOT
+    subprocess.run(
+        [sys.executable, '-m', 'emphases_amd', '--text_files',
+         str(tmp_path / 'utt.TextGrid'), '--audio_files',
+         str(tmp_path / 'utt.wav'), '--output_prefixes',
+         str(tmp_path / 'cli'), '--gpu', '0'], check=True, cwd=ROOT)
+    assert torch.equal(torch.load(tmp_path / 'cli.pt'), scores)
