@@ -163,29 +163,44 @@ __device__ __forceinline__ void store_patch(const float* patch, float* __restric
     const int col = lane & 15;
     const bool vector_ok = (ldy & 3) == 0 && (span.offset & 3) == 0 &&
                            (reinterpret_cast<uintptr_t>(y) & 15) == 0;
-#pragma unroll 1
+    // all LDS reads of the patch first (independent), then the stores
+    constexpr int kQuads = (NB * 4 + 15) / 16;
+    float4 value[4][kQuads];
+    float b[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int row = 4 * pass + kk;
+        b[pass] = bias[row];
+#pragma unroll
+        for (int q = 0; q < kQuads; ++q) {
+            const int quad = min(col + 16 * q, NB * 4 - 1);
+            value[pass][q] =
+                *reinterpret_cast<const float4*>(patch + row * stride + 4 * quad);
+        }
+    }
+#pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int row = 4 * pass + kk;
         const int channel = channel0 + row;
         if (channel >= c_out) continue;
-        const float b = bias[row];
-#pragma unroll 1
-        for (int quad = col; quad < NB * 4; quad += 16) {
+#pragma unroll
+        for (int q = 0; q < kQuads; ++q) {
+            const int quad = col + 16 * q;
             const int t = t0 + 4 * quad;
-            if (t >= span.count) continue;
-            float4 value = *reinterpret_cast<const float4*>(patch + row * stride + 4 * quad);
-            value.x = activate(value.x + b, act);
-            value.y = activate(value.y + b, act);
-            value.z = activate(value.z + b, act);
-            value.w = activate(value.w + b, act);
+            if (quad >= NB * 4 || t >= span.count) continue;
+            float4 v = value[pass][q];
+            v.x = activate(v.x + b[pass], act);
+            v.y = activate(v.y + b[pass], act);
+            v.z = activate(v.z + b[pass], act);
+            v.w = activate(v.w + b[pass], act);
             float* out = y + static_cast<int64_t>(channel) * ldy + span.offset + t;
             if (vector_ok && t + 3 < span.count) {
-                *reinterpret_cast<float4*>(out) = value;
+                *reinterpret_cast<float4*>(out) = v;
             } else {
-                out[0] = value.x;
-                if (t + 1 < span.count) out[1] = value.y;
-                if (t + 2 < span.count) out[2] = value.z;
-                if (t + 3 < span.count) out[3] = value.w;
+                out[0] = v.x;
+                if (t + 1 < span.count) out[1] = v.y;
+                if (t + 2 < span.count) out[2] = v.z;
+                if (t + 3 < span.count) out[3] = v.w;
             }
         }
     }
@@ -427,8 +442,22 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_kernel(
                 const int next = min(local + 1, count - 1);
                 load_b(b0, first + next);
                 load_a(a0, next);
-                __builtin_amdgcn_sched_barrier(0);
                 compute(av, bv);
+                // Issue order inside the block: the requests (and the address
+                // arithmetic in front of them) are threaded between the MFMAs —
+                // global loads first, they have the longest way to go — instead
+                // of running ahead of them with the matrix pipe idle.
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);   // VALU/SALU
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+                }
+#pragma unroll
+                for (int k = 0; k < U * MB; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // MFMA
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

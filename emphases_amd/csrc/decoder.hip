@@ -168,41 +168,34 @@ __global__ __launch_bounds__(128 * MAX_M) void word_decoder_kernel(
             const int groups_here = min(chunk_steps, steps - first) / KS;
             const float* b_base = source + (4 * (first / KS) + kk) * kActStride +
                                   kLeadCols + (narrow ? 16 : 32) * half + col - HALO;
-            // one 4-row group per trip, software-pipelined: the LDS reads of
-            // group g+1 are in flight while the 2*KS MFMAs of group g run
-            // (sched_barrier keeps hipcc from sinking the reads to their uses)
-            float a[KS], b[KS][2], a_next[KS], b_next[KS][2];
-            auto read_group = [&](float (&av)[KS], float (&bv)[KS][2], int g) {
+            // kTrip 4-row groups per trip: their 3*KS*kTrip LDS reads are issued
+            // together (one exposed LDS latency per trip instead of one per
+            // group), then the MFMAs run back to back
+            constexpr int kTrip = 4;
+            for (int g = 0; g < groups_here; g += kTrip) {
+                float a[kTrip][KS], b[kTrip][KS][2];
 #pragma unroll
-                for (int tap = 0; tap < KS; ++tap) {
-                    av[tap] = fragment[(g * KS + tap) * m_tiles * 64];
-                    bv[tap][0] = b_base[4 * g * kActStride + tap];
-                    bv[tap][1] = b_base[4 * g * kActStride + tap + 16];
-                }
-            };
-            read_group(a_next, b_next, 0);
-#ifdef EMPH_DECODER_SKIP
-            if (!(EMPH_DECODER_SKIP & 2))
-#endif
-            for (int g = 0; g < groups_here; ++g) {
+                for (int i = 0; i < kTrip; ++i) {
+                    const int gi = min(g + i, groups_here - 1);
 #pragma unroll
-                for (int tap = 0; tap < KS; ++tap) {
-                    a[tap] = a_next[tap];
-                    b[tap][0] = b_next[tap][0];
-                    b[tap][1] = b_next[tap][1];
+                    for (int tap = 0; tap < KS; ++tap) {
+                        a[i][tap] = fragment[(gi * KS + tap) * m_tiles * 64];
+                        b[i][tap][0] = b_base[4 * gi * kActStride + tap];
+                        b[i][tap][1] = b_base[4 * gi * kActStride + tap + 16];
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                read_group(a_next, b_next, min(g + 1, groups_here - 1));
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int tap = 0; tap < KS; ++tap) {
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tap], b[tap][0],
-                                                                  acc[0], 0, 0, 0);
-                    if (!narrow)
-                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tap], b[tap][1],
-                                                                      acc[1], 0, 0, 0);
+                for (int i = 0; i < kTrip; ++i) {
+                    if (g + i >= groups_here) break;          // wave-uniform
+#pragma unroll
+                    for (int tap = 0; tap < KS; ++tap) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            a[i][tap], b[i][tap][0], acc[0], 0, 0, 0);
+                        if (!narrow)
+                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                a[i][tap], b[i][tap][1], acc[1], 0, 0, 0);
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // bias + activation; re-apply the segment's zero halo
