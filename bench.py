@@ -45,6 +45,15 @@ def parse_args():
                         choices=['conv', 'transformer'])
     parser.add_argument('--tile', type=int, default=None)
     parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--streams', type=int, default=2,
+                        help='batches in flight: consecutive steps alternate '
+                             'between this many HIP streams (each with its '
+                             'own workspace), so that the VALU-bound front-end '
+                             'of one batch overlaps the MFMA-bound encoder of '
+                             'the previous one')
+    parser.add_argument('--no-winograd', action='store_true',
+                        help='direct (3-tap) form of the frame-rate convs '
+                             'instead of Winograd F(2,3)')
     parser.add_argument('--no-graph', action='store_true',
                         help='launch kernel by kernel instead of replaying '
                              'the captured HIP graph')
@@ -117,7 +126,8 @@ def main():
     state = None if args.config == 'conv' else \
         emphases_amd.weights.random_state(config, seed=0)
     engine = emphases_amd.engine.Engine(
-        config, state, device, conv_tile=args.tile)
+        config, state, device, conv_tile=args.tile,
+        winograd=not args.no_winograd)
 
     audios, alignments, bounds = workload(rank)
     plan = build_plan(audios, alignments)
@@ -125,32 +135,47 @@ def main():
         [torch.from_numpy(a).reshape(-1) for a in audios]).to(device)
     meta = engine.upload(plan)
     columns = torch.from_numpy(plan.word_columns()).to(device)
-    gathered = send = None
+    most_words = plan.total_words
     if world > 1:
         # ranks hold different numbers of words: pad to the largest shard
         most = torch.tensor([plan.total_words], device=device)
         torch.distributed.all_reduce(most, op=torch.distributed.ReduceOp.MAX)
-        send = torch.zeros(int(most.item()), dtype=torch.float32, device=device)
-        gathered = [torch.empty_like(send) for _ in range(world)]
+        most_words = int(most.item())
 
-    if args.no_graph:
-        scores_buffer = None
-
-        def run_path():
-            return engine.forward(packed, plan, meta)[0]
-    else:
-        replay, scores_buffer, _ = engine.capture(packed, plan, meta)
-
-        def run_path():
-            replay()
-            return scores_buffer
+    # One lane per stream: its own engine workspace (weights are shared
+    # read-only through the same state), its own captured graph.
+    lanes = []
+    for index in range(max(1, args.streams)):
+        lane_engine = engine if index == 0 else emphases_amd.engine.Engine(
+            config, state, device, conv_tile=args.tile,
+            winograd=not args.no_winograd)
+        stream = torch.cuda.Stream(device=device) if args.streams > 1 \
+            else torch.cuda.current_stream()
+        with torch.cuda.stream(stream):
+            send = torch.zeros(most_words, dtype=torch.float32, device=device)
+            gathered = [torch.empty_like(send) for _ in range(world)]
+            if args.no_graph:
+                lanes.append((stream, lane_engine, None, None, send, gathered))
+            else:
+                replay, buffer, _ = lane_engine.capture(packed, plan, meta)
+                lanes.append((stream, lane_engine, replay, buffer, send, gathered))
+    torch.cuda.synchronize()
+    counter = [0]
 
     def step():
-        scores = run_path()
-        if world > 1:
-            # the one exchange of the path: RCCL all_gather of per-word scores
-            send[:plan.total_words] = scores[columns]
-            torch.distributed.all_gather(gathered, send)
+        stream, lane_engine, replay, buffer, send, gathered = \
+            lanes[counter[0] % len(lanes)]
+        counter[0] += 1
+        with torch.cuda.stream(stream):
+            if replay is None:
+                scores = lane_engine.forward(packed, plan, meta)[0]
+            else:
+                replay()
+                scores = buffer
+            if world > 1:
+                # the one exchange of the path: RCCL all_gather of word scores
+                send[:plan.total_words] = scores[columns]
+                torch.distributed.all_gather(gathered, send)
         return scores
 
     def barrier():
@@ -216,6 +241,7 @@ def main():
                     plan.total_frames, 'words_per_gpu': plan.total_words,
                 'conv_tile': meta['tile'],
                 'launch': 'eager' if args.no_graph else 'hipGraph replay',
+                'batches_in_flight': len(lanes),
                 'parallelism': f'utterance-sharded x{world}'},
             'frames_per_s_per_gpu': plan.total_frames * args.steps / elapsed,
             'roofline': {
@@ -226,7 +252,10 @@ def main():
                 'share_of_step': seconds / min(args.steps, 10) /
                     (elapsed / args.steps),
                 'traffic': traffic,
-                'algorithmic_flops_per_launch': flops / launches},
+                'algorithmic_flops_per_launch': flops / launches,
+                # Winograd F(2,3) executes 2/3 of the direct form's MFMA work
+                'executed_mfma_flops_per_launch': flops / launches * (
+                    2. / 3. if 'winograd' in dominant else 1.)},
             'kernels_us_per_step': {
                 name: value[1] / min(args.steps, 10) * 1e6
                 for name, value in kernels.items()},

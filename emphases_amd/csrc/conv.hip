@@ -62,6 +62,14 @@ struct Run<3> {
     __device__ __forceinline__ float get(int i) const { return a[i]; }
 };
 template <>
+struct Run<4> {
+    f32x4u a;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const f32x4u*>(p);
+    }
+    __device__ __forceinline__ float get(int i) const { return a[i]; }
+};
+template <>
 struct Run<5> {
     f32x4u a;
     float b;
@@ -487,6 +495,193 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// Winograd F(2,3) variant of the kernel_size-3 convolution.
+//
+// Two adjacent outputs share four inputs d0..d3 = x[2p-1 .. 2p+2]:
+//   m0 = (d0 - d2) g0              m1 = (d1 + d2) (g0 + g1 + g2)/2
+//   m2 = (d2 - d1) (g0 - g1 + g2)/2   m3 = (d1 - d3) g2
+//   y[2p] = m0 + m1 + m2           y[2p+1] = m1 - m2 - m3
+// i.e. four [c_out x c_in] GEMMs over PAIRS of positions instead of three over
+// positions: 2/3 of the MFMA work.  The input transform is two packed adds per
+// fragment, the output transform four adds per accumulator, the transformed
+// weights G_j are formed in float64 on the host.  In fp32 the result differs
+// from the direct form by ~1e-7 of the output scale (per-word scores move by
+// ~1e-7, measured against the reference goldens), far inside the 1e-4 budget.
+//
+// Structure as conv1d_kernel: 4 waves, the (c_in/4 x 4 x MB x 64)-float pack in
+// LDS by LDS-DMA, one wave = MB m-tiles x NB pair-tiles (NB*32 positions), B
+// fragments as one unaligned 16-byte run per lane, one-iteration pipeline.
+// pack[m_block][group][j][m][lane] = G_j[(m_block*MB + m)*16 + (lane & 15)]
+//                                       [4*group + (lane >> 4)]
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void conv1d_winograd_kernel(
+    const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+    const float* __restrict__ pack, const float* __restrict__ bias, int c_in,
+    int c_out, int act, const int32_t* __restrict__ tiles, int n_tiles,
+    int patch_offset) {
+    EMPH_STAMP(0);
+    constexpr int WAVES = 4;
+    constexpr int THREADS = 64 * WAVES;
+    constexpr int kPatchStride = patch_stride(2 * NB);
+    extern __shared__ __align__(16) float weights[];   // [groups][4][MB][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kk = lane >> 4;
+    const int col = lane & 15;
+    const int iterations = (c_in + 3) >> 2;            // 4-row groups
+    const int m_tiles = (c_out + 15) >> 4;
+    const int m_first = blockIdx.y * MB;
+    const int last_row = c_in - 1;
+    float* patch = weights + patch_offset + wave * (16 * kPatchStride);
+    float* bias_lds = weights + patch_offset + WAVES * (16 * kPatchStride);
+
+    // ---- per-tile state
+    Tile span;
+    int t0 = 0;
+    bool active = false;
+    bool inside[4][NB];
+    const float* lane_base = x;
+    auto open_tile = [&](int group) {
+        const int tile = group * WAVES + wave;
+        active = tile < n_tiles;
+        span = load_tile(tiles, active ? tile : 0);
+        t0 = span.first;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const int t = t0 + 32 * n + 2 * col - 1 + i;
+                inside[i][n] = t >= 0 && t < span.count;
+            }
+        lane_base = x + span.offset + t0 + 2 * col - 1;
+    };
+    auto load_b = [&](Run<4> (&b)[NB], int iteration) {
+        const int first = min(4 * iteration, last_row & ~3);
+        const float* source =
+            lane_base + static_cast<int64_t>(first + min(kk, last_row - first)) * ldx;
+#pragma unroll
+        for (int n = 0; n < NB; ++n) b[n].load(source + 32 * n);
+    };
+    auto load_a = [&](float (&a)[4][MB], int iteration) {
+        const float* fragment = weights + (iteration * 4 * MB << 6) + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) a[j][m] = fragment[(j * MB + m) << 6];
+    };
+
+    Run<4> b0[NB];
+    float a0[4][MB];
+    const int groups_of_tiles = (n_tiles + WAVES - 1) / WAVES;
+    open_tile(blockIdx.x);
+    {
+        const int quads = iterations * 4 * MB * 16;
+        const float* source =
+            pack + static_cast<int64_t>(blockIdx.y) * iterations * 4 * MB * 64;
+        for (int base = wave * 64; base < quads; base += THREADS)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(source + 4 * (base + lane)),
+                (__attribute__((address_space(3))) void*)(weights + 4 * base), 16, 0, 0);
+        if (active) load_b(b0, 0);
+        for (int index = threadIdx.x; index < MB * 16; index += THREADS) {
+            const int channel = m_first * 16 + index;
+            bias_lds[index] = (bias != nullptr && channel < c_out) ? bias[channel] : 0.f;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): LDS-DMA landed
+        __syncthreads();
+    }
+    EMPH_STAMP(1);
+
+    for (int group = blockIdx.x; group < groups_of_tiles; group += gridDim.x) {
+        if (group != static_cast<int>(blockIdx.x)) {
+            open_tile(group);
+            if (active) load_b(b0, 0);
+        }
+        if (!active) continue;
+        f32x4 acc[4][MB][NB];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[j][m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        float av[4][MB], v[4][NB];
+        load_a(a0, 0);
+        EMPH_STAMP(2);
+#pragma unroll 1
+        for (int iteration = 0; iteration < iterations; ++iteration) {
+            // input transform of the fragments that have landed (masked to the
+            // segment's zero halo first), and the A copies
+            const bool row_inside = 4 * iteration + kk < c_in;
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                float d[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    d[i] = (inside[i][n] && row_inside) ? b0[n].get(i) : 0.f;
+                v[0][n] = d[0] - d[2];
+                v[1][n] = d[1] + d[2];
+                v[2][n] = d[2] - d[1];
+                v[3][n] = d[1] - d[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) av[j][m] = a0[j][m];
+            __builtin_amdgcn_sched_barrier(0);
+            const int next = min(iteration + 1, iterations - 1);
+            load_b(b0, next);
+            load_a(a0, next);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n)
+                        acc[j][m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            av[j][m], v[j][n], acc[j][m][n], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x006, 6, 0);   // VALU/SALU
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+            }
+#pragma unroll
+            for (int k = 0; k < 4 * MB; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        EMPH_STAMP(3);
+        // ---- output transform + epilogue through the LDS patch:
+        // pair p of pair-tile n -> positions 32 n + 2 col (+1)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            if (m_first + m >= m_tiles) break;
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m1 = acc[1][m][n][r], m2 = acc[2][m][n][r];
+                    float2 pair;
+                    pair.x = acc[0][m][n][r] + m1 + m2;
+                    pair.y = m1 - m2 - acc[3][m][n][r];
+                    *reinterpret_cast<float2*>(
+                        patch + (4 * kk + r) * kPatchStride + 32 * n + 2 * col) = pair;
+                }
+            wave_lds_fence();
+            store_patch<2 * NB>(patch, y, ldy, bias_lds + 16 * m, (m_first + m) * 16, c_out,
+                                act, span, 0);
+            wave_lds_fence();
+        }
+        EMPH_STAMP(4);
+    }
+}
+
 template <int KS, int MB, int NB, int WAVES>
 int launch_conv_waves(int n_tiles, int m_blocks, size_t weight_bytes, hipStream_t s,
                       const float* x, int64_t ldx, float* y, int64_t ldy,
@@ -564,6 +759,36 @@ int launch_conv_nb(int tile_n, int n_tiles, int m_blocks, size_t weight_bytes,
     }
 }
 
+template <int MB, int NB>
+static int launch_winograd(const float* x, int64_t ldx, float* y, int64_t ldy,
+                           const float* pack, const float* bias, int c_in, int c_out,
+                           int act, const int32_t* tiles, int n_tiles, int m_blocks,
+                           hipStream_t s) {
+    const size_t weight_bytes = static_cast<size_t>((c_in + 3) / 4) * 4 * MB * 64 * sizeof(float);
+    const size_t lds = weight_bytes + (4 * 16 * patch_stride(2 * NB) + MB * 16) * sizeof(float);
+    EMPH_REQUIRE(lds <= 160 * 1024, EMPH_ERANGE,
+                 "emph_conv1d_winograd: %zu bytes of LDS needed (c_in too large)", lds);
+    auto kernel = conv1d_winograd_kernel<MB, NB>;
+    static size_t reserved = 64 * 1024;
+    if (lds > reserved) {
+        hipError_t status = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (status != hipSuccess) {
+            set_error("emph_conv1d_winograd: cannot reserve %zu bytes of LDS: %s", lds,
+                      hipGetErrorString(status));
+            return static_cast<int>(status);
+        }
+        reserved = lds;
+    }
+    const int groups_of_tiles = (n_tiles + 3) / 4;
+    dim3 grid(groups_of_tiles < 256 ? groups_of_tiles : 256, m_blocks);
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, x, ldx, y, ldy, pack, bias, c_in,
+                       c_out, act, tiles, n_tiles,
+                       static_cast<int>(weight_bytes / sizeof(float)));
+    return check_launch("emph_conv1d_winograd");
+}
+
 }  // namespace emph
 
 using namespace emph;
@@ -608,6 +833,76 @@ int emph_conv_pack(const float* host_weight, int32_t c_out, int32_t c_in,
                     host_pack[(step * m_padded + m) * 64 + lane] = value;
                 }
     return EMPH_OK;
+}
+
+int64_t emph_conv_winograd_pack_size(int32_t c_out, int32_t c_in) {
+    const int mb = conv_m_block(c_out);
+    const int64_t m_padded = round_up((c_out + 15) / 16, mb);
+    return static_cast<int64_t>((c_in + 3) / 4) * 4 * m_padded * 64;
+}
+
+int64_t emph_conv_winograd_lds_bytes(int32_t c_out, int32_t c_in) {
+    const int mb = conv_m_block(c_out);
+    return (static_cast<int64_t>((c_in + 3) / 4) * 4 * mb * 64 +
+            4 * 16 * patch_stride(4) + mb * 16) * static_cast<int64_t>(sizeof(float));
+}
+
+int emph_conv_winograd_pack(const float* host_weight, int32_t c_out, int32_t c_in,
+                            float* host_pack) {
+    EMPH_REQUIRE(host_weight && host_pack, EMPH_EINVAL,
+                 "emph_conv_winograd_pack: null pointer");
+    EMPH_REQUIRE(c_out > 0 && c_in > 0, EMPH_EINVAL, "emph_conv_winograd_pack: bad shape");
+    const int mb = conv_m_block(c_out);
+    const int m_padded = round_up((c_out + 15) / 16, mb);
+    const int blocks = m_padded / mb;
+    const int groups = (c_in + 3) / 4;
+    for (int block = 0; block < blocks; ++block)
+        for (int group = 0; group < groups; ++group)
+            for (int j = 0; j < 4; ++j)
+                for (int m = 0; m < mb; ++m)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = (block * mb + m) * 16 + (lane & 15);
+                        const int ci = 4 * group + (lane >> 4);
+                        double value = 0.;
+                        if (co < c_out && ci < c_in) {
+                            const float* w = host_weight + (static_cast<int64_t>(co) * c_in + ci) * 3;
+                            const double g0 = w[0], g1 = w[1], g2 = w[2];
+                            value = j == 0   ? g0
+                                    : j == 1 ? (g0 + g1 + g2) / 2
+                                    : j == 2 ? (g0 - g1 + g2) / 2
+                                             : g2;
+                        }
+                        host_pack[((((static_cast<int64_t>(block) * groups + group) * 4 + j) * mb +
+                                    m) << 6) + lane] = static_cast<float>(value);
+                    }
+    return EMPH_OK;
+}
+
+int emph_conv1d_winograd(const float* x, int64_t ldx, float* y, int64_t ldy,
+                         const float* pack, const float* bias, int32_t c_in,
+                         int32_t c_out, int32_t activation, const int32_t* tiles,
+                         int32_t n_tiles, int32_t tile_n, void* stream) {
+    if (n_tiles == 0) return EMPH_OK;
+    EMPH_REQUIRE(x && y && pack && tiles, EMPH_EINVAL, "emph_conv1d_winograd: null pointer");
+    EMPH_REQUIRE(tile_n == 32 || tile_n == 64, EMPH_ERANGE,
+                 "emph_conv1d_winograd: tile_n %d not in {32,64}", tile_n);
+    EMPH_REQUIRE(c_in >= 1 && c_in <= 256 && c_out >= 1 && c_out <= 1024, EMPH_ERANGE,
+                 "emph_conv1d_winograd: channels %d -> %d out of range", c_in, c_out);
+    EMPH_REQUIRE(activation >= EMPH_ACT_NONE && activation <= EMPH_ACT_LEAKY_RELU,
+                 EMPH_EINVAL, "emph_conv1d_winograd: unknown activation %d", activation);
+    const int m_tiles = (c_out + 15) / 16;
+    const int mb = conv_m_block(c_out);
+    const int m_blocks = (m_tiles + mb - 1) / mb;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mb == 5)
+        return tile_n == 64 ? launch_winograd<5, 2>(x, ldx, y, ldy, pack, bias, c_in, c_out,
+                                                    activation, tiles, n_tiles, m_blocks, s)
+                            : launch_winograd<5, 1>(x, ldx, y, ldy, pack, bias, c_in, c_out,
+                                                    activation, tiles, n_tiles, m_blocks, s);
+    return tile_n == 64 ? launch_winograd<4, 2>(x, ldx, y, ldy, pack, bias, c_in, c_out,
+                                                activation, tiles, n_tiles, m_blocks, s)
+                        : launch_winograd<4, 1>(x, ldx, y, ldy, pack, bias, c_in, c_out,
+                                                activation, tiles, n_tiles, m_blocks, s);
 }
 
 int emph_conv1d(const float* x, int64_t ldx, float* y, int64_t ldy,

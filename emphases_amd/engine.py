@@ -27,6 +27,7 @@ from . import weights as weights_module
 FRONTEND_BLOCK = 32     # frames per front-end workgroup (csrc/frontend.hip)
 ATTENTION_BLOCK = 64    # queries per attention wave (csrc/transformer.hip)
 WORD_TILE = 16
+WINOGRAD_LDS_BUDGET = 160 * 1024
 
 
 def a_weighting():
@@ -48,12 +49,20 @@ def a_weighting():
 class _Conv:
     """Device copy of one Conv1d / Linear in MFMA fragment order."""
 
-    def __init__(self, weight, bias, device):
+    def __init__(self, weight, bias, device, winograd=False):
         weight = np.asarray(weight, dtype=np.float32)
         if weight.ndim == 2:
             weight = weight[:, :, None]
         self.c_out, self.c_in, self.kernel_size = weight.shape
         self.pack = torch.from_numpy(runtime.conv_pack(weight)).to(device)
+        # Winograd F(2,3) form for the frame-rate k=3 layers whose transformed
+        # weights fit in one CU's LDS next to the output patches
+        self.winograd = None
+        if winograd and self.kernel_size == 3 and \
+                runtime.conv_winograd_lds_bytes(self.c_out, self.c_in) <= \
+                WINOGRAD_LDS_BUDGET:
+            self.winograd = torch.from_numpy(
+                runtime.conv_winograd_pack(weight)).to(device)
         self.bias = None if bias is None else torch.from_numpy(
             np.ascontiguousarray(bias, dtype=np.float32)).to(device)
 
@@ -62,8 +71,9 @@ class Engine:
     """Weights + constants on one device, and the kernel sequence."""
 
     def __init__(self, config=cfg.DEFAULT, state=None, device=None,
-                 conv_tile=None):
+                 conv_tile=None, winograd=True):
         self.config = config
+        self.winograd = winograd
         self.device = runtime.require_gpu(device)
         self.lib = runtime.library()
         self.conv_tile = conv_tile
@@ -88,7 +98,8 @@ class Engine:
 
         # Model
         self.input_layer = _Conv(
-            state['input_layer.weight'], state['input_layer.bias'], dev)
+            state['input_layer.weight'], state['input_layer.bias'], dev,
+            winograd)
         self.frame_encoder = self._stack('frame_encoder')
         self.word_decoder = self._stack('word_decoder') \
             if config.has_decoder else None
@@ -119,7 +130,8 @@ class Engine:
             for i in range(config.layers):
                 layers.append(_Conv(
                     state[f'{prefix}.{2 * i}.weight'],
-                    state[f'{prefix}.{2 * i}.bias'], dev))
+                    state[f'{prefix}.{2 * i}.bias'], dev,
+                    self.winograd and prefix == 'frame_encoder'))
             return layers
         channels = config.channels
         to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
@@ -147,14 +159,23 @@ class Engine:
     ###########################################################################
 
     def frame_tile(self, plan):
-        """Positions per conv wave on the frame axis: the widest tile that
-        still leaves about two waves per SIMD on the 256 CUs."""
+        """Positions per conv wave on the frame axis.  One workgroup is four
+        waves and the chip runs 256 workgroups at a time, so a launch costs
+        (trips over the 256 CUs) x (time of one tile): pick the tile that
+        minimises it.  Relative tile times measured on the 80x80 k=3 layer:
+        64 Winograd 1.0, 32 Winograd 0.62, 16 direct 0.40 (64/32 direct: 1.3 /
+        0.62)."""
         if self.conv_tile is not None:
             return self.conv_tile
-        for tile in (64, 32):
-            if plan.total_frames / tile >= 2048:
-                return tile
-        return 32 if plan.total_frames / 32 >= 512 else 16
+        frames = [segment.frames for segment in plan.segments]
+        cost = {64: 1.0 if self.winograd else 1.3, 32: 0.62, 16: 0.40}
+        best = None
+        for tile in (64, 32, 16):
+            tiles = sum(-(-count // tile) for count in frames)
+            trips = -(-(-(-tiles // 4)) // 256)
+            if best is None or trips * cost[tile] < best[0]:
+                best = (trips * cost[tile], tile)
+        return best[1]
 
     def upload(self, plan, tile=None):
         """One H2D copy of all integer metadata; returns device views."""
@@ -214,11 +235,22 @@ class Engine:
         name = (f'conv1d_{"frames" if axis == runtime.AXIS_FRAMES else "words"}'
                 f'_{layer.c_in}x{layer.c_out}_k{layer.kernel_size}')
         flops = 2. * layer.c_in * layer.c_out * layer.kernel_size * positions
+        bias = None if layer.bias is None else layer.bias.data_ptr()
+        if layer.winograd is not None and axis == runtime.AXIS_FRAMES and \
+                block in (32, 64) and not transpose_out:
+            # same algorithmic flops; the kernel executes two thirds of them
+            with self._timed(name.replace('conv1d', 'conv1d_winograd'), flops):
+                runtime.check(self.lib.emph_conv1d_winograd(
+                    x.data_ptr(), ldx, y.data_ptr(), ldy,
+                    layer.winograd.data_ptr(), bias, layer.c_in, layer.c_out,
+                    runtime.ACTIVATIONS[activation], tiles.data_ptr(),
+                    size // runtime.TILE_FIELDS, block, runtime.stream()),
+                    'emph_conv1d_winograd')
+            return
         with self._timed(name, flops):
             runtime.check(self.lib.emph_conv1d(
                 x.data_ptr(), ldx, y.data_ptr(), ldy, layer.pack.data_ptr(),
-                None if layer.bias is None else layer.bias.data_ptr(),
-                layer.c_in, layer.c_out, layer.kernel_size,
+                bias, layer.c_in, layer.c_out, layer.kernel_size,
                 runtime.ACTIVATIONS[activation], tiles.data_ptr(),
                 size // runtime.TILE_FIELDS, block, int(transpose_out),
                 runtime.stream()), 'emph_conv1d')

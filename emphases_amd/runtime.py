@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 5
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -45,6 +45,12 @@ SIGNATURES = {
     'emph_conv1d': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _i32, _ptr, _i32,
         _i32, _i32, _ptr]),
+    'emph_conv_winograd_pack_size': (_i64, [_i32, _i32]),
+    'emph_conv_winograd_lds_bytes': (_i64, [_i32, _i32]),
+    'emph_conv_winograd_pack': (_c.c_int, [_ptr, _i32, _i32, _ptr]),
+    'emph_conv1d_winograd': (_c.c_int, [
+        _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _ptr, _i32, _i32,
+        _ptr]),
     'emph_segment_reduce': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _i64, _i32, _ptr]),
     'emph_output_layer': (_c.c_int, [
@@ -142,6 +148,24 @@ def frontend_table():
     check(lib.emph_frontend_table_fill(table.ctypes.data),
           'emph_frontend_table_fill')
     return table
+
+
+def conv_winograd_lds_bytes(c_out, c_in):
+    return int(library().emph_conv_winograd_lds_bytes(c_out, c_in))
+
+
+def conv_winograd_pack(weight):
+    """Winograd F(2,3) pack of a [c_out, c_in, 3] weight (host, numpy)."""
+    lib = library()
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    c_out, c_in, kernel_size = weight.shape
+    assert kernel_size == 3
+    pack = np.zeros(
+        lib.emph_conv_winograd_pack_size(c_out, c_in), dtype=np.float32)
+    check(lib.emph_conv_winograd_pack(
+        weight.ctypes.data, c_out, c_in, pack.ctypes.data),
+        'emph_conv_winograd_pack')
+    return pack
 
 
 def conv_pack(weight):

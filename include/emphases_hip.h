@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 3
+#define EMPH_ABI_VERSION 5
 
 /* Segment-table fields */
 enum {
@@ -177,6 +177,22 @@ int emph_conv1d(const float* x, int64_t ldx, float* y, int64_t ldy,
                 int32_t c_out, int32_t kernel_size, int32_t activation,
                 const int32_t* tiles, int32_t n_tiles, int32_t tile_n,
                 int32_t transpose_out, void* stream);
+
+/* Winograd F(2,3) form of the kernel_size-3 convolution: the same contract and
+ * result as emph_conv1d(kernel_size = 3) up to fp32 rounding (~1e-7 of the
+ * output scale), with two thirds of the matrix-core work.  Weights are packed
+ * by emph_conv_winograd_pack (transformed in float64 on the host); tile_n is 32
+ * or 64 and the whole pack must fit in LDS (c_in * 1.25 KiB per 5 m-tiles). */
+int64_t emph_conv_winograd_pack_size(int32_t c_out, int32_t c_in);
+/* LDS bytes one workgroup needs (tile_n = 64); must be <= 160 KiB. */
+int64_t emph_conv_winograd_lds_bytes(int32_t c_out, int32_t c_in);
+int emph_conv_winograd_pack(const float* host_weight, int32_t c_out,
+                            int32_t c_in, float* host_pack);
+int emph_conv1d_winograd(const float* x, int64_t ldx, float* y, int64_t ldy,
+                         const float* pack, const float* bias, int32_t c_in,
+                         int32_t c_out, int32_t activation,
+                         const int32_t* tiles, int32_t n_tiles, int32_t tile_n,
+                         void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Frame -> word resampling                                                  */

@@ -95,6 +95,60 @@ def test_conv1d(c_in, c_out, kernel_size, activation, tile):
     assert float(y[:, :batch.LEAD].min()) == 7.0
 
 
+@pytest.mark.parametrize('c_in,c_out,activation,tile', [
+    (80, 80, 'relu', 64), (80, 80, None, 32), (81, 80, 'relu', 64),
+    (83, 80, None, 32), (80, 96, 'gelu', 64), (128, 128, 'relu', 64),
+    (64, 64, 'leaky_relu', 32), (3, 7, None, 64), (80, 1, None, 32)])
+def test_conv1d_winograd(c_in, c_out, activation, tile):
+    """F(2,3) form == Conv1d(k=3, 'same') on ragged segments, odd lengths,
+    channel counts that do not fill the last 4-row group / 16-row tile."""
+    lib = runtime.library()
+    plan = ragged_plan([200, 1, 2, 17, 64, 65, 3, 130, 31, 33])
+    axis = runtime.AXIS_FRAMES
+    meta = Meta(plan, [(axis, tile)])
+    x = random_packed(c_in, plan, axis, 11)
+    x[:, :batch.LEAD] = float('nan')
+    x[:, -batch.TAIL:] = float('nan')
+    weight = synth.weights(5, (c_out, c_in, 3), 0.2)
+    bias = synth.weights(6, (c_out,), 0.5)
+    y = torch.full((c_out, plan.ld_frames), 7.0, device=DEVICE)
+    assert runtime.conv_winograd_lds_bytes(c_out, c_in) <= 160 * 1024
+    pack = torch.from_numpy(runtime.conv_winograd_pack(weight)).to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    x_dev, bias_dev = x.to(DEVICE), torch.from_numpy(bias).to(DEVICE)
+    runtime.check(lib.emph_conv1d_winograd(
+        x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
+        pack.data_ptr(), bias_dev.data_ptr(), c_in, c_out,
+        runtime.ACTIVATIONS[activation], tiles.data_ptr(), size // 4, tile,
+        None), 'emph_conv1d_winograd')
+    y = y.cpu()
+    for off, count in spans(plan, axis):
+        want = ACTIVATIONS[activation](torch.nn.functional.conv1d(
+            x[None, :, off:off + count], torch.from_numpy(weight),
+            torch.from_numpy(bias), padding=1))[0]
+        got = y[:, off:off + count]
+        assert torch.isfinite(got).all()
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) < 2e-5 * scale
+    assert float(y[:, :batch.LEAD].min()) == 7.0
+
+
+def test_conv1d_winograd_rejects_bad_arguments():
+    lib = runtime.library()
+    buffer = torch.zeros(4096, device=DEVICE)
+    tiles = torch.zeros(4, dtype=torch.int32, device=DEVICE)
+    pointer = buffer.data_ptr()
+    # tile_n 16 is not a pair tile; 200 input channels do not fit in LDS
+    assert lib.emph_conv1d_winograd(
+        pointer, 64, pointer, 64, pointer, None, 80, 80, 0,
+        tiles.data_ptr(), 1, 16, None) == -2
+    assert lib.emph_conv1d_winograd(
+        pointer, 64, pointer, 64, pointer, None, 200, 80, 0,
+        tiles.data_ptr(), 1, 64, None) == -2
+    assert b'LDS' in lib.emph_last_error()
+    assert runtime.conv_winograd_lds_bytes(80, 200) > 160 * 1024
+
+
 def test_conv1d_transposed_output():
     lib = runtime.library()
     plan = ragged_plan([100, 33])

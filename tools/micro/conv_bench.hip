@@ -25,7 +25,18 @@ __device__ unsigned long long* g_stamps = nullptr;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+static bool g_wino = false;
+static float* g_wino_pack = nullptr;
+static int conv(const float* x, int64_t ld, float* y, const float* pack, const float* bias, int c,
+                int ks, const int32_t* tiles, int n_tiles, int tile_n) {
+    if (g_wino)
+        return emph_conv1d_winograd(x, ld, y, ld, g_wino_pack, bias, c, c, 1, tiles, n_tiles,
+                                    tile_n, nullptr);
+    return emph_conv1d(x, ld, y, ld, pack, bias, c, c, ks, 1, tiles, n_tiles, tile_n, 0, nullptr);
+}
+
 int main(int argc, char** argv) {
+    g_wino = getenv("WINO") != nullptr;
     const int segments = 64, frames = 1000, c = 80, ks = 3;
     const int64_t ld = 16 + static_cast<int64_t>(segments) * 1008 + 64;
     std::vector<float> hx(c * ld);
@@ -34,6 +45,10 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 40503u) % 1000) / 5000.f - 0.1f;
     std::vector<float> hpack(emph_conv_pack_size(c, c, ks));
     emph_conv_pack(hw.data(), c, c, ks, hpack.data());
+    std::vector<float> hwino(emph_conv_winograd_pack_size(c, c));
+    emph_conv_winograd_pack(hw.data(), c, c, hwino.data());
+    CHECK(hipMalloc(&g_wino_pack, hwino.size() * 4));
+    CHECK(hipMemcpy(g_wino_pack, hwino.data(), hwino.size() * 4, hipMemcpyHostToDevice));
     std::vector<float> hbias(c, 0.1f);
     float *x, *y, *pack, *bias;
     CHECK(hipMalloc(&x, hx.size() * 4)); CHECK(hipMalloc(&y, hx.size() * 4));
@@ -44,6 +59,7 @@ int main(int argc, char** argv) {
     hipEvent_t start, stop;
     CHECK(hipEventCreate(&start)); CHECK(hipEventCreate(&stop));
     for (int tile_n : {64, 32, 16}) {
+        if (g_wino && tile_n == 16) continue;
         std::vector<int32_t> tiles;
         for (int s = 0; s < segments; ++s)
             for (int t = 0; t < frames; t += tile_n) {
@@ -55,12 +71,12 @@ int main(int argc, char** argv) {
         CHECK(hipMalloc(&dtiles, tiles.size() * 4));
         CHECK(hipMemcpy(dtiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
         for (int rep = 0; rep < 5; ++rep)
-            emph_conv1d(x, ld, y, ld, pack, bias, c, c, ks, 1, dtiles, n_tiles, tile_n, 0, nullptr);
+            conv(x, ld, y, pack, bias, c, ks, dtiles, n_tiles, tile_n);
         CHECK(hipDeviceSynchronize());
         const int reps = 50;
         CHECK(hipEventRecord(start));
         for (int rep = 0; rep < reps; ++rep)
-            emph_conv1d(x, ld, y, ld, pack, bias, c, c, ks, 1, dtiles, n_tiles, tile_n, 0, nullptr);
+            conv(x, ld, y, pack, bias, c, ks, dtiles, n_tiles, tile_n);
         CHECK(hipEventRecord(stop));
         CHECK(hipEventSynchronize(stop));
         float ms = 0;
@@ -75,7 +91,7 @@ int main(int argc, char** argv) {
             CHECK(hipMalloc(&stamps, slots * 8));
             CHECK(hipMemset(stamps, 0, slots * 8));
             CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &stamps, sizeof(stamps)));
-            emph_conv1d(x, ld, y, ld, pack, bias, c, c, ks, 1, dtiles, n_tiles, tile_n, 0, nullptr);
+            conv(x, ld, y, pack, bias, c, ks, dtiles, n_tiles, tile_n);
             CHECK(hipDeviceSynchronize());
             std::vector<unsigned long long> host(slots);
             CHECK(hipMemcpy(host.data(), stamps, slots * 8, hipMemcpyDeviceToHost));
