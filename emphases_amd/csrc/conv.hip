@@ -135,7 +135,7 @@ __host__ __device__ constexpr int patch_stride(int nb) { return 16 * nb + 4; }
 // store, 256-byte runs per row).  Position-major output (transpose): a lane
 // owns one position and writes its 16 channels as four 16-byte stores.
 template <int NB>
-__device__ __forceinline__ void store_patch(const float* patch, float* __restrict__ y,
+__device__ __forceinline__ void store_patch(float* patch, float* __restrict__ y,
                                          int64_t ldy, const float* bias /* LDS, 16 */,
                                          int channel0, int c_out, int act, Tile span,
                                          int transpose) {
@@ -171,6 +171,21 @@ __device__ __forceinline__ void store_patch(const float* patch, float* __restric
     const int col = lane & 15;
     const bool vector_ok = (ldy & 3) == 0 && (span.offset & 3) == 0 &&
                            (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    // This function is inlined once per m-tile of the caller's unrolled
+    // epilogue, so the straight-line part below must stay small: identity and
+    // ReLU are a compare + select there; the transcendental activations are
+    // applied in place on the LDS patch by a rolled loop first.
+    const bool plain = act <= EMPH_ACT_RELU;
+    if (!plain) {
+#pragma unroll 1
+        for (int index = lane; index < 16 * NB * 16; index += 64) {
+            const int row = index / (NB * 16);
+            float* cell = patch + row * stride + (index - row * (NB * 16));
+            *cell = activate(*cell + bias[row], act);
+        }
+        wave_lds_fence();
+    }
+    const bool relu = act == EMPH_ACT_RELU;
     // all LDS reads of the patch first (independent), then the stores
     constexpr int kQuads = (NB * 4 + 15) / 16;
     float4 value[4][kQuads];
@@ -178,7 +193,7 @@ __device__ __forceinline__ void store_patch(const float* patch, float* __restric
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int row = 4 * pass + kk;
-        b[pass] = bias[row];
+        b[pass] = plain ? bias[row] : 0.f;
 #pragma unroll
         for (int q = 0; q < kQuads; ++q) {
             const int quad = min(col + 16 * q, NB * 4 - 1);
@@ -186,21 +201,27 @@ __device__ __forceinline__ void store_patch(const float* patch, float* __restric
                 *reinterpret_cast<const float4*>(patch + row * stride + 4 * quad);
         }
     }
+    auto finish = [&](float v, float add) {
+        v += add;
+        return (relu && v < 0.f) ? 0.f : v;       // NaN stays NaN, as torch.relu
+    };
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int row = 4 * pass + kk;
         const int channel = channel0 + row;
-        if (channel >= c_out) continue;
 #pragma unroll
         for (int q = 0; q < kQuads; ++q) {
             const int quad = col + 16 * q;
             const int t = t0 + 4 * quad;
-            if (quad >= NB * 4 || t >= span.count) continue;
             float4 v = value[pass][q];
-            v.x = activate(v.x + b[pass], act);
-            v.y = activate(v.y + b[pass], act);
-            v.z = activate(v.z + b[pass], act);
-            v.w = activate(v.w + b[pass], act);
+            v.x = finish(v.x, b[pass]);
+            v.y = finish(v.y, b[pass]);
+            v.z = finish(v.z, b[pass]);
+            v.w = finish(v.w, b[pass]);
+            if (channel >= c_out || quad >= NB * 4 || t >= span.count) continue;
+#ifdef EMPH_NO_STORE
+            if (ldy > 0) continue;     // experiment: everything but the global stores
+#endif
             float* out = y + static_cast<int64_t>(channel) * ldy + span.offset + t;
             if (vector_ok && t + 3 < span.count) {
                 *reinterpret_cast<float4*>(out) = v;
@@ -514,14 +535,13 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_kernel(
 // fragments as one unaligned 16-byte run per lane, one-iteration pipeline.
 // pack[m_block][group][j][m][lane] = G_j[(m_block*MB + m)*16 + (lane & 15)]
 //                                       [4*group + (lane >> 4)]
-template <int MB, int NB>
-__global__ __launch_bounds__(256) void conv1d_winograd_kernel(
+template <int MB, int NB, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void conv1d_winograd_kernel(
     const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
     const float* __restrict__ pack, const float* __restrict__ bias, int c_in,
     int c_out, int act, const int32_t* __restrict__ tiles, int n_tiles,
     int patch_offset) {
     EMPH_STAMP(0);
-    constexpr int WAVES = 4;
     constexpr int THREADS = 64 * WAVES;
     constexpr int kPatchStride = patch_stride(2 * NB);
     extern __shared__ __align__(16) float weights[];   // [groups][4][MB][64]
@@ -657,26 +677,71 @@ __global__ __launch_bounds__(256) void conv1d_winograd_kernel(
         }
 
         EMPH_STAMP(3);
-        // ---- output transform + epilogue through the LDS patch:
-        // pair p of pair-tile n -> positions 32 n + 2 col (+1)
+        // ---- output transform + epilogue.  Lane (kk, col) holds rows 4 kk + r
+        // of pair `col` of pair-tile n, i.e. positions 32 n + 2 col (+1): for
+        // identity / ReLU it stores them straight from registers as 8-byte
+        // pairs (16 lanes = one 128-byte run per row; measured: the LDS patch
+        // round trip below costs 0.45 us per m-tile of fences and latency).
+        const bool plain = act <= EMPH_ACT_RELU && (ldy & 1) == 0 &&
+                           (reinterpret_cast<uintptr_t>(y) & 7) == 0;
+        if (plain) {
+            const bool relu = act == EMPH_ACT_RELU;
+            float add[MB][4];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            if (m_first + m >= m_tiles) break;
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int n = 0; n < NB; ++n)
+                for (int r = 0; r < 4; ++r) add[m][r] = bias_lds[16 * m + 4 * kk + r];
+            float* row_base = y + static_cast<int64_t>(m_first * 16 + 4 * kk) * ldy +
+                              span.offset + t0 + 2 * col;
+            bool both[NB], first[NB];
+#pragma unroll
+            for (int n = 0; n < NB; ++n) {
+                const int t = t0 + 32 * n + 2 * col;
+                both[n] = t + 1 < span.count;
+                first[n] = t < span.count;
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                if (m_first + m >= m_tiles) break;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float m1 = acc[1][m][n][r], m2 = acc[2][m][n][r];
-                    float2 pair;
-                    pair.x = acc[0][m][n][r] + m1 + m2;
-                    pair.y = m1 - m2 - acc[3][m][n][r];
-                    *reinterpret_cast<float2*>(
-                        patch + (4 * kk + r) * kPatchStride + 32 * n + 2 * col) = pair;
+                    const bool row_ok = (m_first + m) * 16 + 4 * kk + r < c_out;
+                    float* out = row_base + static_cast<int64_t>(16 * m + r) * ldy;
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        const float m1 = acc[1][m][n][r], m2 = acc[2][m][n][r];
+                        float even = acc[0][m][n][r] + m1 + m2 + add[m][r];
+                        float odd = m1 - m2 - acc[3][m][n][r] + add[m][r];
+                        even = (relu && even < 0.f) ? 0.f : even;
+                        odd = (relu && odd < 0.f) ? 0.f : odd;
+                        if (row_ok && both[n])
+                            *reinterpret_cast<float2*>(out + 32 * n) = make_float2(even, odd);
+                        else if (row_ok && first[n])
+                            out[32 * n] = even;
+                    }
                 }
-            wave_lds_fence();
-            store_patch<2 * NB>(patch, y, ldy, bias_lds + 16 * m, (m_first + m) * 16, c_out,
-                                act, span, 0);
-            wave_lds_fence();
+            }
+        } else {
+            // through the LDS patch (transcendental activations, odd strides)
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                if (m_first + m >= m_tiles) break;
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m1 = acc[1][m][n][r], m2 = acc[2][m][n][r];
+                        float2 pair;
+                        pair.x = acc[0][m][n][r] + m1 + m2;
+                        pair.y = m1 - m2 - acc[3][m][n][r];
+                        *reinterpret_cast<float2*>(
+                            patch + (4 * kk + r) * kPatchStride + 32 * n + 2 * col) = pair;
+                    }
+                wave_lds_fence();
+                store_patch<2 * NB>(patch, y, ldy, bias_lds + 16 * m, (m_first + m) * 16,
+                                    c_out, act, span, 0);
+                wave_lds_fence();
+            }
         }
         EMPH_STAMP(4);
     }
@@ -759,16 +824,17 @@ int launch_conv_nb(int tile_n, int n_tiles, int m_blocks, size_t weight_bytes,
     }
 }
 
-template <int MB, int NB>
+template <int MB, int NB, int WAVES>
 static int launch_winograd(const float* x, int64_t ldx, float* y, int64_t ldy,
                            const float* pack, const float* bias, int c_in, int c_out,
                            int act, const int32_t* tiles, int n_tiles, int m_blocks,
                            hipStream_t s) {
     const size_t weight_bytes = static_cast<size_t>((c_in + 3) / 4) * 4 * MB * 64 * sizeof(float);
-    const size_t lds = weight_bytes + (4 * 16 * patch_stride(2 * NB) + MB * 16) * sizeof(float);
+    const size_t lds =
+        weight_bytes + (WAVES * 16 * patch_stride(2 * NB) + MB * 16) * sizeof(float);
     EMPH_REQUIRE(lds <= 160 * 1024, EMPH_ERANGE,
                  "emph_conv1d_winograd: %zu bytes of LDS needed (c_in too large)", lds);
-    auto kernel = conv1d_winograd_kernel<MB, NB>;
+    auto kernel = conv1d_winograd_kernel<MB, NB, WAVES>;
     static size_t reserved = 64 * 1024;
     if (lds > reserved) {
         hipError_t status = hipFuncSetAttribute(
@@ -781,9 +847,9 @@ static int launch_winograd(const float* x, int64_t ldx, float* y, int64_t ldy,
         }
         reserved = lds;
     }
-    const int groups_of_tiles = (n_tiles + 3) / 4;
+    const int groups_of_tiles = (n_tiles + WAVES - 1) / WAVES;
     dim3 grid(groups_of_tiles < 256 ? groups_of_tiles : 256, m_blocks);
-    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, s, x, ldx, y, ldy, pack, bias, c_in,
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * WAVES), lds, s, x, ldx, y, ldy, pack, bias, c_in,
                        c_out, act, tiles, n_tiles,
                        static_cast<int>(weight_bytes / sizeof(float)));
     return check_launch("emph_conv1d_winograd");
@@ -894,15 +960,20 @@ int emph_conv1d_winograd(const float* x, int64_t ldx, float* y, int64_t ldy,
     const int mb = conv_m_block(c_out);
     const int m_blocks = (m_tiles + mb - 1) / mb;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (mb == 5)
-        return tile_n == 64 ? launch_winograd<5, 2>(x, ldx, y, ldy, pack, bias, c_in, c_out,
-                                                    activation, tiles, n_tiles, m_blocks, s)
-                            : launch_winograd<5, 1>(x, ldx, y, ldy, pack, bias, c_in, c_out,
-                                                    activation, tiles, n_tiles, m_blocks, s);
-    return tile_n == 64 ? launch_winograd<4, 2>(x, ldx, y, ldy, pack, bias, c_in, c_out,
-                                                activation, tiles, n_tiles, m_blocks, s)
-                        : launch_winograd<4, 1>(x, ldx, y, ldy, pack, bias, c_in, c_out,
-                                                activation, tiles, n_tiles, m_blocks, s);
+    // 32-position tiles run two waves per SIMD (the second hides the first's
+    // LDS / global latencies: 24.5 us vs 26.7 us with one 64-position wave)
+    static const bool eight =
+        !(getenv("EMPH_WINO_WAVES") && atoi(getenv("EMPH_WINO_WAVES")) == 4);
+#define EMPH_WINOGRAD(MB, NB, WAVES)                                                      \
+    launch_winograd<MB, NB, WAVES>(x, ldx, y, ldy, pack, bias, c_in, c_out, activation, \
+                                   tiles, n_tiles, m_blocks, s)
+    if (mb == 5) {
+        if (tile_n == 64) return EMPH_WINOGRAD(5, 2, 4);
+        return eight ? EMPH_WINOGRAD(5, 1, 8) : EMPH_WINOGRAD(5, 1, 4);
+    }
+    if (tile_n == 64) return EMPH_WINOGRAD(4, 2, 4);
+    return eight ? EMPH_WINOGRAD(4, 1, 8) : EMPH_WINOGRAD(4, 1, 4);
+#undef EMPH_WINOGRAD
 }
 
 int emph_conv1d(const float* x, int64_t ldx, float* y, int64_t ldy,

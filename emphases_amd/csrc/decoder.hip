@@ -14,16 +14,21 @@
 // one segment: `block` output words plus a halo of `halo` words on either side
 // (the receptive field of the remaining layers), recomputed per tile; a segment
 // of at most 64 words is one tile with no halo.  Per layer the [C x 64] output
-// is C/16 x 4 MFMA tiles (fp32 v_mfma_f32_16x16x4_f32): wave (m, h) owns m-tile
-// m and n-tiles {2h, 2h+1}.  The packed weights stream through a two-slot LDS
-// ring by LDS-DMA, one chunk (about half a layer) ahead of the MFMAs, so each
-// weight is read from L2 once per workgroup and never waited for; B fragments
+// is C/16 x 4 MFMA tiles (fp32 v_mfma_f32_16x16x4_f32) shared by eight waves:
+// wave w owns n-tile w & 3 and the lower (w < 4) or upper half of the m-tiles,
+// so the two waves of a SIMD carry C/16 tiles between them whatever C is (a
+// wave per m-tile put 3 waves on two SIMDs and 2 on the others: +20%).  The
+// packed weights stream through a two-slot LDS ring by LDS-DMA, requested by a
+// ninth wave one chunk (a third of a layer) ahead of the MFMAs, so each weight
+// is read from L2 once per workgroup and never waited for; B fragments
 // come from the LDS-resident activations, whose row stride of 80 floats keeps
 // the four k-rows of a fragment on disjoint banks.
 // Every layer re-applies the segment's own zero halo, so ragged batches keep
 // the reference's B=1 edge semantics.
 #include <math.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -49,13 +54,20 @@ __device__ __forceinline__ float activate_word(float x, int act) {
     }
 }
 
-// block = 128 * m_tiles threads (wave = (m-tile, n-half)); grid = n_tiles.
-// MAX_M (5 or 8 m-tiles) bounds the block size and with it the register budget.
-template <int KS, int MAX_M>
-__global__ __launch_bounds__(128 * MAX_M) void word_decoder_kernel(
+// block = 576 threads: eight MFMA waves + one loader wave; grid = n_tiles.
+// MT = m-tiles per MFMA wave (half of C/16, rounded up).
+//
+// The loader wave: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read
+// that follows an LDS-DMA in program order (it cannot tell which LDS bytes the
+// DMA writes), so a wave that both requests chunk q+1 and reads chunk q from
+// LDS waits for q+1 to land first - the DMA latency (1.1 us per chunk,
+// measured) ends up in series with the MFMAs instead of under them.  The MFMA
+// waves never have a DMA in flight, so their waits are free.
+template <int KS, int MT>
+__global__ __launch_bounds__(576) void word_decoder_kernel(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ tiles,
     int block, int halo, int channels, const float* __restrict__ packs,
-    const float* __restrict__ biases, int layers, int act, int chunk_steps,
+    const float* __restrict__ biases, int layers, int act, int chunk_trips,
     const float* __restrict__ out_weight, const float* __restrict__ out_bias,
     int out_kernel, int post, float* __restrict__ logits, float* __restrict__ scores) {
     extern __shared__ __align__(16) float lds[];
@@ -63,16 +75,16 @@ __global__ __launch_bounds__(128 * MAX_M) void word_decoder_kernel(
     const int m_tiles = channels >> 4;
     const int threads = blockDim.x;
     const int waves = threads >> 6;
+    const int compute_waves = waves - 1;
     // (the two activation buffers are addressed as lds + index * size: a runtime-
     // indexed array of pointers would decay to flat addressing)
     const int buffer_floats = channels * kActStride;
     float* partial = lds + 2 * channels * kActStride;   // [waves][kWindow]
     float* bias_lds = partial + waves * kWindow;        // [layers][channels]
     float* out_lds = bias_lds + layers * channels;      // [channels][out_kernel] + 1
-    // two weight chunks of chunk_steps k-steps each, 16-byte aligned
+    // two weight chunks of chunk_trips trips each, 16-byte aligned
     float* ring = lds + ((2 * channels * kActStride + waves * kWindow + layers * channels +
                           channels * out_kernel + 1 + 3) & ~3);
-    const int chunk_floats = chunk_steps * m_tiles * 64;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kk = lane >> 4;
@@ -88,33 +100,31 @@ __global__ __launch_bounds__(128 * MAX_M) void word_decoder_kernel(
     // every wave then owns ONE of them and the per-layer MFMA work halves
     const bool narrow = single && span.count <= 32;
 
-    // Weight stream: the decoder's packs, layer after layer, cut into chunks of
-    // chunk_steps k-steps.  Chunk q is copied by LDS-DMA into ring[q & 1] while
-    // chunk q-1 is being consumed.
+    // Weight stream: the decoder's packs (emph_word_decoder_pack), layer after
+    // layer, cut into chunks of chunk_trips trips (a trip = four 4-row groups of
+    // input channels x KS taps).  Chunk q is copied by LDS-DMA into ring[q & 1]
+    // while chunk q-1 is being consumed.
     constexpr int HALO = (KS - 1) / 2;
-    const int groups_k = KS == 1 ? (((channels + 15) & ~15) >> 2) : (((channels + 7) & ~7) >> 2);
-    const int steps = groups_k * KS;                  // k-steps per layer
-    const int chunks_per_layer = (steps + chunk_steps - 1) / chunk_steps;
+    constexpr int kTripFloats = 4 * KS;               // per lane, m-tile and trip
+    const int trips = channels >> 4;                  // per layer: C/4 groups / 4
+    const int trip_floats = m_tiles * 64 * kTripFloats;
+    const int chunks_per_layer = (trips + chunk_trips - 1) / chunk_trips;
     const int total_chunks = layers * chunks_per_layer;
-    auto request = [&](int q) {
+    const int chunk_floats = chunk_trips * trip_floats;
+    auto request = [&](int q) {                       // loader wave only
         const int layer = q / chunks_per_layer;
-        const int first = (q - layer * chunks_per_layer) * chunk_steps;
-        const int quads = min(chunk_steps, steps - first) * m_tiles * 16;
+        const int first = (q - layer * chunks_per_layer) * chunk_trips;
+        const int quads = min(chunk_trips, trips - first) * (trip_floats >> 2);
         const float* source =
-            packs + (static_cast<int64_t>(layer) * steps + first) * m_tiles * 64;
+            packs + (static_cast<int64_t>(layer) * trips + first) * trip_floats;
         float* target = ring + (q & 1) * chunk_floats;
-        for (int base = wave * 64; base < quads; base += threads) {
-            if (base + 64 <= quads) {
-                __builtin_amdgcn_global_load_lds(
-                    (const __attribute__((address_space(1))) void*)(source + 4 * (base + lane)),
-                    (__attribute__((address_space(3))) void*)(target + 4 * base), 16, 0, 0);
-            } else if (base + lane < quads) {
-                reinterpret_cast<float4*>(target)[base + lane] =
-                    reinterpret_cast<const float4*>(source)[base + lane];
-            }
-        }
+        for (int base = 0; base < quads; base += 64)  // trip_floats % 256 == 0
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(source + 4 * (base + lane)),
+                (__attribute__((address_space(3))) void*)(target + 4 * base), 16, 0, 0);
     };
-    if (total_chunks > 0) request(0);
+    const bool loader = wave == waves - 1;
+    if (total_chunks > 0 && loader) request(0);
 
     // Everything else the stages need comes into LDS in the same round trip
     // (a dependent global load costs 1-2 us on this chip): the window of word
@@ -147,75 +157,163 @@ __global__ __launch_bounds__(128 * MAX_M) void word_decoder_kernel(
         out_lds[index] = index < channels * out_kernel ? out_weight[index] : out_bias[0];
     EMPH_STAMP(1);
 
-    // ---- decoder layers: wave (m, half) owns m-tile m, n-tiles 2*half, 2*half+1
-    const int m = wave % m_tiles;
-    const int half = wave / m_tiles;
-    int current = 0;
-    for (int layer = 0; layer < layers; ++layer) {
-        const float* source = lds + current * buffer_floats;
-        float* target = lds + (current ^ 1) * buffer_floats;
-        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-        for (int piece = 0; piece < chunks_per_layer; ++piece) {
-            const int q = layer * chunks_per_layer + piece;
-            __builtin_amdgcn_s_waitcnt(0x0F70);       // my DMA pieces of chunk q landed
-            __syncthreads();                          // everyone's did; ring[(q+1)&1] is free
+    if (loader) {
+        // one barrier per chunk, in step with the MFMA waves below: chunk q has
+        // landed -> barrier (everyone is also done with chunk q-1, whose slot
+        // chunk q+1 overwrites) -> request chunk q+1
+        for (int q = 0; q < total_chunks; ++q) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
 #ifdef EMPH_DECODER_SKIP
-            if (!(EMPH_DECODER_SKIP & 1))
+            if (EMPH_DECODER_SKIP & 1) continue;
 #endif
             if (q + 1 < total_chunks) request(q + 1);
-            const float* fragment = ring + (q & 1) * chunk_floats + (m << 6) + lane;
-            const int first = piece * chunk_steps;            // multiple of KS
-            const int groups_here = min(chunk_steps, steps - first) / KS;
-            const float* b_base = source + (4 * (first / KS) + kk) * kActStride +
-                                  kLeadCols + (narrow ? 16 : 32) * half + col - HALO;
-            // kTrip 4-row groups per trip: their 3*KS*kTrip LDS reads are issued
-            // together (one exposed LDS latency per trip instead of one per
-            // group), then the MFMAs run back to back
-            constexpr int kTrip = 4;
-            for (int g = 0; g < groups_here; g += kTrip) {
-                float a[kTrip][KS], b[kTrip][KS][2];
-#pragma unroll
-                for (int i = 0; i < kTrip; ++i) {
-                    const int gi = min(g + i, groups_here - 1);
-#pragma unroll
-                    for (int tap = 0; tap < KS; ++tap) {
-                        a[i][tap] = fragment[(gi * KS + tap) * m_tiles * 64];
-                        b[i][tap][0] = b_base[4 * gi * kActStride + tap];
-                        b[i][tap][1] = b_base[4 * gi * kActStride + tap + 16];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < kTrip; ++i) {
-                    if (g + i >= groups_here) break;          // wave-uniform
-#pragma unroll
-                    for (int tap = 0; tap < KS; ++tap) {
-                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                            a[i][tap], b[i][tap][0], acc[0], 0, 0, 0);
-                        if (!narrow)
-                            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                a[i][tap], b[i][tap][1], acc[1], 0, 0, 0);
-                    }
-                }
-            }
         }
-        // bias + activation; re-apply the segment's zero halo
-        const float* bias = bias_lds + layer * channels;
+    }
+
+    // ---- decoder layers
+    const int n_tile = narrow ? (wave & 1) : (wave & 3);
+    const int part = narrow ? (wave >> 1) : (wave >> 2);
+    const int split = (m_tiles + 1) >> 1;
+    const int m_begin = narrow ? (m_tiles * part + 3) >> 2 : (part ? split : 0);
+    const int m_end = narrow ? (m_tiles * (part + 1) + 3) >> 2 : (part ? m_tiles : split);
+    const int m_count = m_end - m_begin;              // wave-uniform, <= MT
+    // One instantiation of the layer loop per number of m-tiles a wave can own:
+    // the accumulators stay plain registers (a wave-uniform `if (i < m_count)`
+    // around each MFMA made hipcc copy them through temporaries with s_nop
+    // padding: 19 us per layer instead of 5).
+    auto run_layers = [&](auto count_tag) {
+        constexpr int COUNT = decltype(count_tag)::value;
+        int buffer = 0;
+        for (int layer = 0; layer < layers; ++layer) {
+            const float* source = lds + buffer * buffer_floats;
+            float* target = lds + (buffer ^ 1) * buffer_floats;
+            f32x4 acc[COUNT];
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            if (narrow && n == 1) break;
-            const int p = (narrow ? 16 : 32) * half + 16 * n + col;
+            for (int i = 0; i < COUNT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // The layer is a sequence of trips (16 input channels x KS taps, i.e.
+            // 4 KS MFMAs per m-tile).  The LDS reads of trip i+1 - KS 16-byte
+            // reads per m-tile for A, the taps of four activation rows for B -
+            // are threaded between the MFMAs of trip i: a wave can have only 15
+            // LDS instructions in flight, so a block of reads in front of a
+            // block of MFMAs leaves the matrix pipe idle while the reads drain
+            // (measured 3.2 us of LDS time + 4.6 us of MFMA time per layer, in
+            // series), and every wave of the workgroup leaves the chunk barrier
+            // in the same phase.
+            // Two register sets, read and consumed alternately (copying one set
+            // into the other cost 48 v_mov per trip, in lockstep on both waves
+            // of a SIMD, with the matrix pipe idle meanwhile).
+            f32x4 a_set[2][COUNT][KS];
+            float b_set[2][4][KS];
+            auto issue = [&](f32x4 (&a_out)[COUNT][KS], float (&b_out)[4][KS], int trip) {
+                const int piece = trip / chunk_trips;
+                const int q = layer * chunks_per_layer + piece;
+                const float* fragment = ring + (q & 1) * chunk_floats +
+                                        (trip - piece * chunk_trips) * trip_floats +
+                                        (m_begin * 64 + lane) * kTripFloats;
+                const float* b_base = source + (16 * trip + kk) * kActStride + kLeadCols +
+                                      16 * n_tile + col - HALO;
+#pragma unroll
+                for (int i = 0; i < COUNT; ++i)
+#pragma unroll
+                    for (int v = 0; v < KS; ++v)
+                        a_out[i][v] = *reinterpret_cast<const f32x4*>(
+                            fragment + i * 64 * kTripFloats + 4 * v);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int tap = 0; tap < KS; ++tap)
+                        b_out[t][tap] = b_base[4 * t * kActStride + tap];
+            };
+            auto step = [&](f32x4 (&a)[COUNT][KS], float (&b)[4][KS],
+                            f32x4 (&a_out)[COUNT][KS], float (&b_out)[4][KS], int trip) {
+                const int next = min(trip + 1, trips - 1);
+                if (trip + 1 < trips && (trip + 1) % chunk_trips == 0)
+                    __syncthreads();                  // the next chunk has landed
+                __builtin_amdgcn_sched_barrier(0);
+                issue(a_out, b_out, next);            // (the last trip re-reads itself)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int tap = 0; tap < KS; ++tap)
+#pragma unroll
+                        for (int i = 0; i < COUNT; ++i) {
+#ifdef EMPH_DECODER_SKIP
+                            if (EMPH_DECODER_SKIP & 2) {
+                                acc[i][0] += a[i][(t * KS + tap) >> 2][(t * KS + tap) & 3] +
+                                             b[t][tap];
+                                continue;
+                            }
+#endif
+                            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                a[i][(t * KS + tap) >> 2][(t * KS + tap) & 3], b[t][tap],
+                                acc[i], 0, 0, 0);
+                        }
+                // (COUNT + 4) KS reads behind the first MFMAs, one per MFMA, so
+                // that the last of them has the rest of the trip to land
+#pragma unroll
+                for (int k = 0; k < (COUNT + 4) * KS; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (layer == 1 && trip < 5) EMPH_STAMP(11 + trip);
+            };
+            __syncthreads();                          // chunk (layer, 0) is in the ring
+            if (layer == 1) EMPH_STAMP(10);
+            issue(a_set[0], b_set[0], 0);
+            for (int trip = 0; trip < trips; trip += 2) {
+                step(a_set[0], b_set[0], a_set[1], b_set[1], trip);
+                if (trip + 1 < trips) step(a_set[1], b_set[1], a_set[0], b_set[0], trip + 1);
+            }
+            // bias + activation; re-apply the segment's zero halo.  All bias
+            // reads first, the activation switch outside the element loops (an
+            // LDS read, a wait and a branch ladder per element took 1.2 us)
+            const float* bias = bias_lds + layer * channels + 16 * m_begin + 4 * kk;
+            const int p = 16 * n_tile + col;
             const int word = start + p;
             const bool inside = word >= 0 && word < span.count;
+            f32x4 value[COUNT];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 16 * m + 4 * kk + r;
-                target[c * kActStride + kLeadCols + p] =
-                    inside ? activate_word(acc[n][r] + bias[c], act) : 0.f;
-            }
+            for (int i = 0; i < COUNT; ++i)
+                value[i] = acc[i] + *reinterpret_cast<const f32x4*>(bias + 16 * i);
+#define EMPH_APPLY(EXPRESSION)                                   \
+    _Pragma("unroll") for (int i = 0; i < COUNT; ++i)            \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {          \
+            const float v = value[i][r];                         \
+            value[i][r] = (EXPRESSION);                          \
         }
-        EMPH_STAMP(3 + layer);
-        current ^= 1;
+            switch (act) {
+                case EMPH_ACT_RELU: EMPH_APPLY(v < 0.f ? 0.f : v); break;
+                case EMPH_ACT_GELU:
+                    EMPH_APPLY(0.5f * v * (1.f + erff(v * 0.70710678118654752440f)));
+                    break;
+                case EMPH_ACT_SILU: EMPH_APPLY(v / (1.f + expf(-v))); break;
+                case EMPH_ACT_LEAKY_RELU: EMPH_APPLY(v > 0.f ? v : 0.01f * v); break;
+                default: break;
+            }
+#undef EMPH_APPLY
+#pragma unroll
+            for (int i = 0; i < COUNT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 16 * (m_begin + i) + 4 * kk + r;
+                    target[c * kActStride + kLeadCols + p] = inside ? value[i][r] : 0.f;
+                }
+            EMPH_STAMP(3 + layer);
+            buffer ^= 1;
+        }
+    };
+    if (!loader) {
+        // (a wave with no m-tile still has to keep step with the barriers)
+        if (m_count >= 4 && MT >= 4) run_layers(std::integral_constant<int, MT >= 4 ? 4 : 1>{});
+        else if (m_count == 3) run_layers(std::integral_constant<int, 3>{});
+        else if (m_count == 2) run_layers(std::integral_constant<int, 2>{});
+        else if (m_count == 1) run_layers(std::integral_constant<int, 1>{});
+        else
+            for (int q = 0; q < total_chunks; ++q) __syncthreads();
     }
+    int current = layers & 1;
     __syncthreads();
 
     // ---- output projection: channels are split over the waves, then summed
@@ -223,7 +321,7 @@ __global__ __launch_bounds__(128 * MAX_M) void word_decoder_kernel(
         const float* source = lds + current * buffer_floats;
         const int halo_out = (out_kernel - 1) / 2;
         float sum = 0.f;
-        for (int c = wave; c < channels; c += waves)
+        for (int c = wave; c < channels && !loader; c += compute_waves)
             for (int tap = 0; tap < out_kernel; ++tap)
                 sum = fmaf(out_lds[c * out_kernel + tap],
                            source[c * kActStride + kLeadCols + lane + tap - halo_out], sum);
@@ -231,7 +329,7 @@ __global__ __launch_bounds__(128 * MAX_M) void word_decoder_kernel(
         __syncthreads();
         if (wave == 0) {
             float total = out_lds[channels * out_kernel];
-            for (int w = 0; w < waves; ++w) total += partial[w * kWindow + lane];
+            for (int w = 0; w < compute_waves; ++w) total += partial[w * kWindow + lane];
             const int word = start + lane;
             if (word >= first_out && word < last_out) {
                 const int64_t column = span.offset + word;
@@ -253,6 +351,38 @@ __global__ __launch_bounds__(128 * MAX_M) void word_decoder_kernel(
 using namespace emph;
 
 extern "C" {
+
+int64_t emph_word_decoder_pack_size(int32_t channels, int32_t kernel_size) {
+    return static_cast<int64_t>(channels) * channels * kernel_size;
+}
+
+// pack[trip][m][lane][4 t + tap... as (t * KS + tap)] =
+//     weight[16 m + (lane & 15)][16 trip + 4 t + (lane >> 4)][tap]
+int emph_word_decoder_pack(const float* host_weight, int32_t channels, int32_t kernel_size,
+                           float* host_pack) {
+    EMPH_REQUIRE(host_weight && host_pack, EMPH_EINVAL,
+                 "emph_word_decoder_pack: null pointer");
+    EMPH_REQUIRE(channels >= 16 && channels <= 128 && channels % 16 == 0, EMPH_ERANGE,
+                 "emph_word_decoder_pack: channels %d not a multiple of 16 in 16..128",
+                 channels);
+    EMPH_REQUIRE(kernel_size == 1 || kernel_size == 3 || kernel_size == 5, EMPH_ERANGE,
+                 "emph_word_decoder_pack: kernel_size %d not in {1,3,5}", kernel_size);
+    const int m_tiles = channels / 16, trips = channels / 16;
+    for (int trip = 0; trip < trips; ++trip)
+        for (int m = 0; m < m_tiles; ++m)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int t = 0; t < 4; ++t)
+                    for (int tap = 0; tap < kernel_size; ++tap) {
+                        const int co = 16 * m + (lane & 15);
+                        const int ci = 16 * trip + 4 * t + (lane >> 4);
+                        host_pack[((static_cast<int64_t>(trip) * m_tiles + m) * 64 + lane) *
+                                      (4 * kernel_size) +
+                                  t * kernel_size + tap] =
+                            host_weight[(static_cast<int64_t>(co) * channels + ci) * kernel_size +
+                                        tap];
+                    }
+    return EMPH_OK;
+}
 
 int32_t emph_word_decoder_block(int32_t layers, int32_t kernel_size,
                                 int32_t out_kernel_size) {
@@ -285,34 +415,30 @@ int emph_word_decoder(const float* x, int64_t ldx, const int32_t* tiles,
                  "emph_word_decoder: receptive field too wide for a 64-word window");
     const int halo = (kWindow - block) / 2;
     const int m_tiles = channels / 16;
-    const int threads = 128 * m_tiles;
-    // two weight chunks of about 36 KB each, less when the activations of a
-    // wide model leave less LDS
-    const size_t fixed_bytes = ((2 * channels * kActStride + (threads / 64) * kWindow +
-                                 layers * channels + channels * out_kernel_size + 1 + 3) & ~3) *
-                               sizeof(float);
-    size_t ring_budget = 156 * 1024 - fixed_bytes;
-    if (ring_budget > 72 * 1024) ring_budget = 72 * 1024;
-    const int groups_k = kernel_size == 1 ? (((channels + 15) & ~15) >> 2)
-                                          : (((channels + 7) & ~7) >> 2);
-    // whole 4-row groups per chunk, split evenly over the layer
-    int chunk_groups = static_cast<int>(ring_budget / 2) / (m_tiles * 256) / kernel_size;
-    if (chunk_groups < 1) chunk_groups = 1;
-    if (chunk_groups > groups_k) chunk_groups = groups_k;
-    const int pieces = (groups_k + chunk_groups - 1) / chunk_groups;
-    chunk_groups = (groups_k + pieces - 1) / pieces;
-    const int chunk_steps = chunk_groups * kernel_size;
-    const size_t floats = ((2 * channels * kActStride + (threads / 64) * kWindow +
-                            layers * channels + channels * out_kernel_size + 1 + 3) & ~3) +
-                          2 * static_cast<size_t>(chunk_steps) * m_tiles * 64;
-    const size_t lds = floats * sizeof(float);
+    const int threads = 576;              // 8 MFMA waves + the loader wave
+    // two weight chunks of whole trips in whatever LDS the activations leave
+    // (80 channels: 3 + 2 trips per layer, i.e. one chunk barrier per layer;
+    // each barrier costs about 0.3 us)
+    const size_t fixed_floats = (2 * channels * kActStride + (threads / 64) * kWindow +
+                                 layers * channels + channels * out_kernel_size + 1 + 3) & ~3;
+    size_t ring_budget = 156 * 1024 - fixed_floats * sizeof(float);
+    const int trips = channels / 16;
+    const size_t trip_bytes = static_cast<size_t>(m_tiles) * 64 * 4 * kernel_size * sizeof(float);
+    int chunk_trips = static_cast<int>(ring_budget / 2 / trip_bytes);
+    EMPH_REQUIRE(chunk_trips >= 1, EMPH_ERANGE,
+                 "emph_word_decoder: no LDS left for the weight ring (%d channels, %d layers)",
+                 channels, layers);
+    if (chunk_trips > trips) chunk_trips = trips;
+    const int pieces = (trips + chunk_trips - 1) / chunk_trips;
+    chunk_trips = (trips + pieces - 1) / pieces;
+    const size_t lds = fixed_floats * sizeof(float) + 2 * chunk_trips * trip_bytes;
     hipStream_t s = static_cast<hipStream_t>(stream);
 #define EMPH_WORDS(KS)                                                              \
     do {                                                                            \
-        auto kernel = m_tiles <= 5 ? word_decoder_kernel<KS, 5>                     \
-                                   : word_decoder_kernel<KS, 8>;                    \
+        auto kernel = m_tiles <= 6 ? word_decoder_kernel<KS, 3>                     \
+                                   : word_decoder_kernel<KS, 4>;                    \
         static size_t reserved[2] = {64 * 1024, 64 * 1024};                         \
-        if (lds > reserved[m_tiles <= 5]) {                                         \
+        if (lds > reserved[m_tiles <= 6]) {                                         \
             hipError_t status = hipFuncSetAttribute(                                \
                 reinterpret_cast<const void*>(kernel),                              \
                 hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
@@ -320,11 +446,11 @@ int emph_word_decoder(const float* x, int64_t ldx, const int32_t* tiles,
                 set_error("emph_word_decoder: cannot reserve %zu bytes of LDS", lds); \
                 return static_cast<int>(status);                                    \
             }                                                                       \
-            reserved[m_tiles <= 5] = lds;                                           \
+            reserved[m_tiles <= 6] = lds;                                           \
         }                                                                           \
         hipLaunchKernelGGL(kernel, dim3(n_tiles), dim3(threads), lds, s, x, ldx,     \
                            tiles, block, halo, channels, packs, biases, layers,      \
-                           activation, chunk_steps, out_weight, out_bias,            \
+                           activation, chunk_trips, out_weight, out_bias,            \
                            out_kernel_size, post, logits, scores);                   \
     } while (0)
     switch (kernel_size) {

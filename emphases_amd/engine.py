@@ -54,6 +54,7 @@ class _Conv:
         if weight.ndim == 2:
             weight = weight[:, :, None]
         self.c_out, self.c_in, self.kernel_size = weight.shape
+        self.weight = weight
         self.pack = torch.from_numpy(runtime.conv_pack(weight)).to(device)
         # Winograd F(2,3) form for the frame-rate k=3 layers whose transformed
         # weights fit in one CU's LDS next to the output patches
@@ -112,7 +113,8 @@ class Engine:
         if self.fused_words:
             layers = self.word_decoder if config.has_decoder else []
             self.decoder_layers = len(layers)
-            self.decoder_packs = torch.cat([l.pack for l in layers]) \
+            self.decoder_packs = torch.from_numpy(np.concatenate([
+                runtime.word_decoder_pack(l.weight) for l in layers])).to(dev) \
                 if layers else None
             self.decoder_biases = torch.cat([l.bias for l in layers]) \
                 if layers else None
@@ -159,20 +161,25 @@ class Engine:
     ###########################################################################
 
     def frame_tile(self, plan):
-        """Positions per conv wave on the frame axis.  One workgroup is four
-        waves and the chip runs 256 workgroups at a time, so a launch costs
-        (trips over the 256 CUs) x (time of one tile): pick the tile that
-        minimises it.  Relative tile times measured on the 80x80 k=3 layer:
-        64 Winograd 1.0, 32 Winograd 0.62, 16 direct 0.40 (64/32 direct: 1.3 /
-        0.62)."""
+        """Positions per conv wave on the frame axis.  The chip runs 256
+        workgroups at a time (one per CU: the weights fill most of the LDS) of
+        4 waves (64-position tiles) or 8 waves (16 / 32), so a launch costs
+        (trips over the 256 CUs) x (time of one trip): pick the tile that
+        minimises it.  Microseconds per trip measured on the 80x80 k=3 layer
+        (tools/micro/conv_bench.hip): Winograd 32: 24.5, Winograd 64: 26.7,
+        direct 64: 33.2, direct 32: 32.9, direct 16: 18.5."""
         if self.conv_tile is not None:
             return self.conv_tile
         frames = [segment.frames for segment in plan.segments]
-        cost = {64: 1.0 if self.winograd else 1.3, 32: 0.62, 16: 0.40}
+        if self.winograd:
+            cost = {64: 26.7, 32: 24.5, 16: 18.5}
+        else:
+            cost = {64: 33.2, 32: 32.9, 16: 18.5}
         best = None
-        for tile in (64, 32, 16):
+        for tile in (32, 64, 16):
             tiles = sum(-(-count // tile) for count in frames)
-            trips = -(-(-(-tiles // 4)) // 256)
+            groups = -(-tiles // (4 if tile == 64 else 8))
+            trips = -(-groups // 256)
             if best is None or trips * cost[tile] < best[0]:
                 best = (trips * cost[tile], tile)
         return best[1]

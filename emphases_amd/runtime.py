@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -57,6 +57,8 @@ SIGNATURES = {
         _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _i64, _i32, _i32,
         _ptr, _ptr, _ptr]),
     'emph_word_decoder_block': (_i32, [_i32, _i32, _i32]),
+    'emph_word_decoder_pack_size': (_i64, [_i32, _i32]),
+    'emph_word_decoder_pack': (_c.c_int, [_ptr, _i32, _i32, _ptr]),
     'emph_word_decoder': (_c.c_int, [
         _ptr, _i64, _ptr, _i32, _i32, _ptr, _ptr, _i32, _i32, _i32, _ptr, _ptr,
         _i32, _i32, _ptr, _ptr, _ptr]),
@@ -148,6 +150,21 @@ def frontend_table():
     check(lib.emph_frontend_table_fill(table.ctypes.data),
           'emph_frontend_table_fill')
     return table
+
+
+def word_decoder_pack(weight):
+    """emph_word_decoder's layout of one [channels, channels, k] weight."""
+    lib = library()
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    channels, c_in, kernel_size = weight.shape
+    assert channels == c_in
+    pack = np.zeros(
+        lib.emph_word_decoder_pack_size(channels, kernel_size),
+        dtype=np.float32)
+    check(lib.emph_word_decoder_pack(
+        weight.ctypes.data, channels, kernel_size, pack.ctypes.data),
+        'emph_word_decoder_pack')
+    return pack
 
 
 def conv_winograd_lds_bytes(c_out, c_in):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 5
+#define EMPH_ABI_VERSION 6
 
 /* Segment-table fields */
 enum {
@@ -246,6 +246,14 @@ int emph_output_layer(const float* x, int64_t ldx, const float* weight,
 int32_t emph_word_decoder_block(int32_t layers, int32_t kernel_size,
                                 int32_t out_kernel_size);
 
+/* Host-side repack of one decoder layer's Conv1d weight [channels][channels]
+ * [kernel_size] for emph_word_decoder: channels^2 * kernel_size floats, ordered
+ * so that a lane reads the weights of sixteen input channels x kernel_size taps
+ * as kernel_size 16-byte LDS reads. */
+int64_t emph_word_decoder_pack_size(int32_t channels, int32_t kernel_size);
+int emph_word_decoder_pack(const float* host_weight, int32_t channels,
+                           int32_t kernel_size, float* host_pack);
+
 /* `layers` x [Conv1d 'same' + activation] at word rate -> Conv1d(channels, 1)
  * -> postprocess, in one launch with the word activations resident in LDS and
  * the weights streamed through LDS by LDS-DMA.
@@ -259,8 +267,8 @@ int32_t emph_word_decoder_block(int32_t layers, int32_t kernel_size,
  *                                        output of emph_segment_reduce
  *   tiles       int32 [n_tiles][4]       word-axis tile table, block =
  *                                        emph_word_decoder_block(...)
- *   packs       float32                  emph_conv_pack of every decoder layer,
- *                                        back to back
+ *   packs       float32                  emph_word_decoder_pack of every
+ *                                        decoder layer, back to back
  *   biases      float32 [layers][channels]
  *   out_weight  float32 [1][channels][out_kernel_size], out_bias float32 [1]
  *   logits, scores  float32 [ldx] (either may be NULL)

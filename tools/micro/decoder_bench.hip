@@ -1,4 +1,4 @@
-// Standalone timeline of emph_word_decoder on the C2 layout (64 x 1000 frames, ~30 words each).
+// Standalone timeline of emph_word_decoder on the C2 layout (64 x 1000 frames, `words` words each).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,10 +15,12 @@ __device__ unsigned long long* g_stamps = nullptr;
 #include "../../emphases_amd/csrc/conv.hip"
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-int main() {
-    const int segments = 64, frames = 1000, c = 80, ks = 3, layers = 6, words = 32;
+int main(int argc, char** argv) {
+    const int segments = 64, frames = 1000, c = 80, ks = 3, layers = 6;
+    const int words = argc > 1 ? atoi(argv[1]) : 197;      // per utterance (C2: ~197)
+    const int wstride = (words + 15) / 16 * 16;
     const int64_t ld = 16 + static_cast<int64_t>(segments) * 1008 + 128;
-    const int64_t ldw = 16 + segments * 32 + 128;
+    const int64_t ldw = 16 + segments * wstride + 128;
     std::vector<float> hx(c * ld, 0.25f);
     std::vector<int32_t> hbounds(2 * ldw, 0);
     std::vector<int64_t> hseg(segments * 8, 0);
@@ -26,17 +28,17 @@ int main() {
     const int block = emph_word_decoder_block(layers, ks, ks);
     for (int s = 0; s < segments; ++s) {
         hseg[s * 8 + 4] = 16 + s * 1008; hseg[s * 8 + 5] = frames;
-        hseg[s * 8 + 6] = 16 + s * 32; hseg[s * 8 + 7] = words;
+        hseg[s * 8 + 6] = 16 + s * wstride; hseg[s * 8 + 7] = words;
         for (int w = 0; w < words; ++w) {
-            hbounds[16 + s * 32 + w] = w * frames / words;
-            hbounds[ldw + 16 + s * 32 + w] = (w + 1) * frames / words;
+            hbounds[16 + s * wstride + w] = w * frames / words;
+            hbounds[ldw + 16 + s * wstride + w] = (w + 1) * frames / words;
         }
         for (int t = 0; t < words; t += block) {
-            tiles.push_back(s); tiles.push_back(t); tiles.push_back(16 + s * 32); tiles.push_back(words);
+            tiles.push_back(s); tiles.push_back(t); tiles.push_back(16 + s * wstride); tiles.push_back(words);
         }
     }
-    std::vector<float> hw(c * c * ks, 0.01f), hpack(emph_conv_pack_size(c, c, ks));
-    emph_conv_pack(hw.data(), c, c, ks, hpack.data());
+    std::vector<float> hw(c * c * ks, 0.01f), hpack(emph_word_decoder_pack_size(c, ks));
+    emph_word_decoder_pack(hw.data(), c, ks, hpack.data());
     std::vector<float> hpacks;
     for (int l = 0; l < layers; ++l) hpacks.insert(hpacks.end(), hpack.begin(), hpack.end());
     std::vector<float> hbias(layers * c, 0.1f), how(c * ks, 0.01f), hob(1, 0.f);
@@ -72,8 +74,8 @@ int main() {
     CHECK(hipMemcpy(host.data(), stamps, slots * 8, hipMemcpyDeviceToHost));
     unsigned long long first = ~0ull;
     for (size_t i = 0; i < slots; i += 16) if (host[i]) first = std::min(first, host[i]);
-    const char* names[16] = {"start", "tables", "-", "layer1", "layer2", "layer3", "layer4", "layer5", "layer6", "output", "", "", "", "", "", ""};
-    for (int slot = 0; slot < 10; ++slot) {
+    const char* names[16] = {"start", "tables", "-", "layer1", "layer2", "layer3", "layer4", "layer5", "layer6", "output", "L2 open", "L2 trip0", "L2 trip1", "L2 trip2", "L2 trip3", "L2 trip4"};
+    for (int slot = 0; slot < 16; ++slot) {
         std::vector<double> values;
         for (size_t i = 0; i < slots; i += 16) if (host[i] && host[i + slot]) values.push_back((host[i + slot] - first) * 0.01);
         if (values.empty()) continue;
