@@ -46,7 +46,7 @@ constexpr int kStage = kHop * (kBlockFrames - 1) + kFft;       // 5984 samples
 constexpr int kExRow = 72;                                     // complex per exchange row
 constexpr int kExFloats = 2 * 8 * kExRow;                      // 1152 floats per wave
 constexpr int kOutStride = kBlockFrames + 1;
-constexpr int kMagFloats = 520;                                 // 513 magnitudes per wave
+constexpr int kMagFloats = 560;      // 513 magnitudes per wave + zero tail for the runs
 constexpr int kRunA = 20;    // longest run of bins among filterbank rows 0..63
 constexpr int kRunB = 10;    // a quarter of the longest run among rows 64..79
 
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     const int32_t* __restrict__ mel_offset, const float* __restrict__ mel_values,
     int mel_nnz, float* __restrict__ out, int64_t ld, int mel_row, int loud_row,
     float* __restrict__ seg_peak, const float* __restrict__ a_weights,
-    int normalize) {
+    int normalize, int n_tiles) {
     constexpr bool kMel = MODE == 0 || MODE == 2;
     constexpr bool kLoud = MODE == 2 || MODE == 3;
     constexpr bool kPeak = MODE == 1;
@@ -134,45 +134,14 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     const int lane = tid & 63;
     const int wave = tid >> 6;
 
-    const int segment = tiles[EMPH_TILE_FIELDS * blockIdx.x];
-    const int frame0 = tiles[EMPH_TILE_FIELDS * blockIdx.x + 1];
-    const int64_t* row = seg + static_cast<int64_t>(segment) * EMPH_SEG_FIELDS;
-    const int64_t audio_off = row[EMPH_SEG_AUDIO_OFF];
-    const int64_t audio_len = row[EMPH_SEG_AUDIO_LEN];
-    const int64_t start = row[EMPH_SEG_START];
-    const int64_t length = row[EMPH_SEG_LENGTH];
-    const int64_t frame_off = row[EMPH_SEG_FRAME_OFF];
-    const int frames = static_cast<int>(row[EMPH_SEG_FRAMES]);
-
-    // ---- stage the block's samples: zero pad + slice + reflect in one pass.
-    // Every load is unconditional (clamped address, masked value) and the loop
-    // is fully unrolled, so a thread's 24 requests are in flight together; a
-    // predicated, rolled loop pays one 1-2 us memory round trip per sample.
-    const int64_t first = static_cast<int64_t>(frame0) * kHop - kPad;
-    {
-        constexpr int kPerThread = (kStage + 255) / 256;
-        float value[kPerThread];
-        bool live[kPerThread];
-        const float* source = audio + audio_off;
-#pragma unroll
-        for (int j = 0; j < kPerThread; ++j) {
-            int64_t r = first + tid + 256 * j;     // position in the chunk
-            if (r < 0) r = -r;                     // reflect (no edge repeat)
-            if (r >= length) r = 2 * (length - 1) - r;
-            const int64_t a = start + r - kPad;    // undo the 432 zero pad
-            live[j] = r >= 0 && r < length && a >= 0 && a < audio_len;
-            const int64_t clamped = a < 0 ? 0 : (a >= audio_len ? audio_len - 1 : a);
-            value[j] = source[audio_len > 0 ? clamped : 0];
-        }
-#pragma unroll
-        for (int j = 0; j < kPerThread; ++j) {
-            const int index = tid + 256 * j;
-            if (index < kStage) stage[index] = live[j] ? value[j] : 0.f;
-        }
-    }
     if (kLoud)
         for (int index = tid; index < kBins; index += 256)
             weights[index] = a_weights[index];
+    if (kMel)   // zero tail of each wave's magnitude row: the fixed-length mel
+                // runs read up to kMagPad bins past the last one (weight 0)
+        for (int index = tid; index < 4 * (kMagFloats - kBins); index += 256)
+            mel_sums[(index / (kMagFloats - kBins)) * kMagFloats + kBins +
+                     index % (kMagFloats - kBins)] = 0.f;
 
     // ---- per-lane constants
     const int p = lane;              // pass-1 position
@@ -218,11 +187,77 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         }
     }
 
+    // ---- persistent loop over this workgroup's blocks of 32 frames: the
+    // per-lane tables above are loaded once (96 global loads per lane)
+    cf* ex = reinterpret_cast<cf*>(exchange + wave * kExFloats);
+    float peak = 0.f;
+    int peak_segment = -1;
+    for (int block = blockIdx.x; block < n_tiles; block += gridDim.x) {
+    const int segment = tiles[EMPH_TILE_FIELDS * block];
+    const int frame0 = tiles[EMPH_TILE_FIELDS * block + 1];
+    const int64_t* row = seg + static_cast<int64_t>(segment) * EMPH_SEG_FIELDS;
+    const int64_t audio_off = row[EMPH_SEG_AUDIO_OFF];
+    const int64_t audio_len = row[EMPH_SEG_AUDIO_LEN];
+    const int64_t start = row[EMPH_SEG_START];
+    const int64_t length = row[EMPH_SEG_LENGTH];
+    const int64_t frame_off = row[EMPH_SEG_FRAME_OFF];
+    const int frames = static_cast<int>(row[EMPH_SEG_FRAMES]);
+    if (kPeak && segment != peak_segment) {
+        // a new chunk: publish the running peak of the previous one
+        if (peak_segment >= 0) {
+            const float total = wave_max(peak);
+            if (lane == 0)
+                atomicMax(reinterpret_cast<unsigned int*>(seg_peak + peak_segment),
+                          __float_as_uint(total));
+        }
+        peak = 0.f;
+        peak_segment = segment;
+    }
+
+    // ---- stage the block's samples: zero pad + slice + reflect in one pass.
+    // Every load is unconditional (clamped address, masked value) and the loop
+    // is fully unrolled, so a thread's 24 requests are in flight together; a
+    // predicated, rolled loop pays one 1-2 us memory round trip per sample.
+    const int64_t first = static_cast<int64_t>(frame0) * kHop - kPad;
+    __syncthreads();          // the previous block is done with `stage` and `tile`
+    {
+        constexpr int kPerThread = (kStage + 255) / 256;
+        float value[kPerThread];
+        const float* source = audio + audio_off;
+        const int64_t base = start + first - kPad;      // audio index of stage[0]
+        if (first >= 0 && first + kStage <= length && base >= 0 &&
+            base + kStage <= audio_len) {
+            // interior block (all but the first and last of an utterance): a
+            // straight copy, no per-sample index arithmetic
+            const float* from = source + base + tid;
+#pragma unroll
+            for (int j = 0; j < kPerThread; ++j)
+                value[j] = from[tid + 256 * j < kStage ? 256 * j : 0];
+#pragma unroll
+            for (int j = 0; j < kPerThread; ++j)
+                if (tid + 256 * j < kStage) stage[tid + 256 * j] = value[j];
+        } else {
+            bool live[kPerThread];
+#pragma unroll
+            for (int j = 0; j < kPerThread; ++j) {
+                int64_t r = first + tid + 256 * j;     // position in the chunk
+                if (r < 0) r = -r;                     // reflect (no edge repeat)
+                if (r >= length) r = 2 * (length - 1) - r;
+                const int64_t a = start + r - kPad;    // undo the 432 zero pad
+                live[j] = r >= 0 && r < length && a >= 0 && a < audio_len;
+                const int64_t clamped = a < 0 ? 0 : (a >= audio_len ? audio_len - 1 : a);
+                value[j] = source[audio_len > 0 ? clamped : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < kPerThread; ++j) {
+                const int index = tid + 256 * j;
+                if (index < kStage) stage[index] = live[j] ? value[j] : 0.f;
+            }
+        }
+    }
     __syncthreads();
     EMPH_STAMP(1);
 
-    cf* ex = reinterpret_cast<cf*>(exchange + wave * kExFloats);
-    float peak = 0.f;
     float floor_db = 0.f;
     if (kLoud) {
         // librosa.amplitude_to_db: max(D) - top_db with D = 10 log10(max(amin^2, S^2))
@@ -283,11 +318,12 @@ __global__ __launch_bounds__(256) void frontend_kernel(
             const int k = lane + 64 * j;
             const cf zk = ex[k];
             const cf zm = ex[(512 - k) & 511];
-            const cf even = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
-            const cf odd = {0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};
+            // X[k] = (E + W^k O) / 2: the halves are folded into the power
+            const cf even = {zk.x + zm.x, zk.y - zm.y};
+            const cf odd = {zk.y + zm.y, zm.x - zk.x};
             const cf rot = cmul(tw3[j], odd);
             const float re = even.x + rot.x, im = even.y + rot.y;
-            power[j] = re * re + im * im;
+            power[j] = 0.25f * (re * re + im * im);
         }
         {
             const cf z0 = ex[0];
@@ -330,20 +366,23 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         if (kMel) {
             float* mag = mel_sums + wave * kMagFloats;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) mag[lane + 64 * j] = sqrtf(power[j] + 1e-6f);
-            if (lane == 0) mag[512] = sqrtf(power[8] + 1e-6f);
+            // v_sqrt_f32 (1 ulp; the argument is >= 1e-6, never denormal): the
+            // correctly rounded sqrtf is ten more instructions per bin
+            for (int j = 0; j < 8; ++j)
+                mag[lane + 64 * j] = __builtin_amdgcn_sqrtf(power[j] + 1e-6f);
+            if (lane == 0) mag[512] = __builtin_amdgcn_sqrtf(power[8] + 1e-6f);
             wave_lds_fence();
             float acc = 0.f;
 #pragma unroll
             for (int j = 0; j < kRunA; ++j)
-                acc = fmaf(weight_a[j], mag[min(start_a + j, kBins - 1)], acc);
+                acc = fmaf(weight_a[j], mag[start_a + j], acc);
             float value = logf(fmaxf(acc, 1e-5f));
             if (normalize) value = (value + 10.f) / 10.f;
             tile[lane * kOutStride + local] = value;
             acc = 0.f;
 #pragma unroll
             for (int j = 0; j < kRunB; ++j)
-                acc = fmaf(weight_b[j], mag[min(start_b + 4 * j, kBins - 1)], acc);
+                acc = fmaf(weight_b[j], mag[start_b + 4 * j], acc);
             acc += __shfl_xor(acc, 1);
             acc += __shfl_xor(acc, 2);
             if ((lane & 3) == 0) {
@@ -357,30 +396,35 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     }
     EMPH_STAMP(8);
 
-    if (kPeak) {
+    if (!kPeak) {
+        __syncthreads();
+        const int valid = min(kBlockFrames, frames - frame0);
+        if (kMel) {
+            // 80 rows x 32 frames: 8 rows per pass, 128-byte segments
+            const int column = tid & 31;
+            for (int m = tid >> 5; m < kMels; m += 8)
+                if (column < valid)
+                    out[static_cast<int64_t>(mel_row + m) * ld + frame_off + frame0 +
+                        column] = tile[m * kOutStride + column];
+        }
+        if (kLoud && tid < valid)
+            out[static_cast<int64_t>(loud_row) * ld + frame_off + frame0 + tid] =
+                loud_tile[tid];
+    }
+    EMPH_STAMP(9);
+    }   // blocks
+
+    if (kPeak && peak_segment >= 0) {
         peak = wave_max(peak);
         // non-negative floats order like their bit patterns
         if (lane == 0)
-            atomicMax(reinterpret_cast<unsigned int*>(seg_peak + segment),
+            atomicMax(reinterpret_cast<unsigned int*>(seg_peak + peak_segment),
                       __float_as_uint(peak));
-        return;
     }
-
-    __syncthreads();
-    const int valid = min(kBlockFrames, frames - frame0);
-    if (kMel) {
-        // 80 rows x 32 frames: 8 rows per pass, 128-byte segments
-        const int column = tid & 31;
-        for (int m = tid >> 5; m < kMels; m += 8)
-            if (column < valid)
-                out[static_cast<int64_t>(mel_row + m) * ld + frame_off + frame0 +
-                    column] = tile[m * kOutStride + column];
-    }
-    if (kLoud && tid < valid)
-        out[static_cast<int64_t>(loud_row) * ld + frame_off + frame0 + tid] =
-            loud_tile[tid];
-    EMPH_STAMP(9);
 }
+
+// two workgroups per CU (LDS), each looping over its share of the blocks
+inline int frontend_grid(int n_tiles) { return n_tiles < 512 ? n_tiles : 512; }
 
 size_t frontend_lds_bytes(bool loud) {
     size_t floats = kStage + 4 * kExFloats + kMels * kOutStride + kBlockFrames +
@@ -451,10 +495,10 @@ int emph_logmel(const float* audio, const int64_t* seg, const int32_t* tiles,
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* peak = const_cast<float*>(seg_peak);
 #define EMPH_LAUNCH(MODE)                                                      \
-    hipLaunchKernelGGL(frontend_kernel<MODE>, dim3(n_tiles), dim3(256), lds, s, \
-                       audio, seg, tiles, table, mel_start, mel_count,         \
-                       mel_offset, mel_values, mel_nnz, out, ld, mel_row,      \
-                       loud_row, peak, a_weights, normalize)
+    hipLaunchKernelGGL(frontend_kernel<MODE>, dim3(frontend_grid(n_tiles)),    \
+                       dim3(256), lds, s, audio, seg, tiles, table, mel_start, \
+                       mel_count, mel_offset, mel_values, mel_nnz, out, ld,    \
+                       mel_row, loud_row, peak, a_weights, normalize, n_tiles)
     if (mel && loud) {
         EMPH_LAUNCH(2);
     } else if (mel) {
@@ -476,9 +520,9 @@ int emph_frontend_peak(const float* audio, const int64_t* seg,
     const int32_t* none_i = nullptr;
     const float* none_f = nullptr;
     float* none_o = nullptr;
-    hipLaunchKernelGGL(frontend_kernel<1>, dim3(n_tiles), dim3(256), lds, s,
-                       audio, seg, tiles, table, none_i, none_i, none_i, none_f,
-                       0, none_o, int64_t{0}, -1, -1, seg_peak, none_f, 0);
+    hipLaunchKernelGGL(frontend_kernel<1>, dim3(frontend_grid(n_tiles)), dim3(256), lds,
+                       s, audio, seg, tiles, table, none_i, none_i, none_i, none_f, 0,
+                       none_o, int64_t{0}, -1, -1, seg_peak, none_f, 0, n_tiles);
     return check_launch("emph_frontend_peak");
 }
 #undef EMPH_LAUNCH
