@@ -156,6 +156,7 @@ class Plan:
         self.bounds = bounds
         self.word_segment = word_segment
         self._tiles = {}
+        self._pieces = {}
 
     def tiles(self, axis, block):
         key = (axis, block)
@@ -165,6 +166,15 @@ class Plan:
             else:
                 self._tiles[key] = _tiles(self.words, self.word_off, block)
         return self._tiles[key]
+
+    def pieces(self, method):
+        """Layout for DOWNSAMPLE_LOCATION = 'input' (`model/core.py:41-87`,
+        `core.py:552-586`): every word of a chunk becomes its own sequence,
+        zero-padded to the longest word of that chunk, encoded on its own and
+        pooled over the PADDED axis.  Returns a `Pieces`."""
+        if method not in self._pieces:
+            self._pieces[method] = Pieces(self, method)
+        return self._pieces[method]
 
     def word_columns(self):
         """Packed word-axis column of every word, in segment order."""
@@ -194,3 +204,49 @@ class Plan:
             chunks.append(chunk)
             cursor += padded
         return np.concatenate(chunks), offsets
+
+
+class Pieces:
+    """Word pieces of a Plan: `plan` is the packed layout of the pieces (one
+    segment per word, frames = the chunk's longest word), `gather` the int64
+    [n, 4] table of emph_gather_columns, and `bounds` / `word_piece` the
+    emph_segment_reduce tables that pool piece p into the ORIGINAL word column
+    of its word."""
+
+    def __init__(self, parent, method):
+        segments, sources = [], []
+        for index, segment in enumerate(parent.segments):
+            starts, ends = segment.bounds[0], segment.bounds[1]
+            if not starts.size:
+                continue
+            if (starts < 0).any() or (ends > segment.frames).any() or \
+                    (ends < starts).any():
+                # the reference's slice assignment raises here too
+                raise ValueError(
+                    'word bounds outside the chunk are not supported with '
+                    "DOWNSAMPLE_LOCATION='input'")
+            longest = int((ends - starts).max())
+            if longest < 1:
+                raise ValueError('no word of the chunk covers a frame')
+            for j in range(starts.size):
+                length = int(ends[j] - starts[j])
+                # center: embedding[:, length // 2]; otherwise the whole
+                # padded axis (mean divides by `longest`)
+                end = length if method == 'center' else longest
+                segments.append(Segment(
+                    0, 0, 1, 0, 0, longest,
+                    np.array([[0], [end]], dtype=np.int64)))
+                sources.append((
+                    int(parent.frame_off[index]) + int(starts[j]), length,
+                    int(parent.word_off[index]) + j))
+        self.plan = Plan(segments, [0], [0])
+        count = len(segments)
+        self.gather = np.zeros((count, 4), dtype=np.int64)
+        self.bounds = np.zeros((2, parent.ld_words), dtype=np.int32)
+        self.word_piece = np.full(parent.ld_words, -1, dtype=np.int32)
+        for piece, (source, length, column) in enumerate(sources):
+            self.gather[piece] = (
+                source, length, self.plan.frame_off[piece],
+                self.plan.frames[piece])
+            self.bounds[:, column] = segments[piece].bounds[:, 0]
+            self.word_piece[column] = piece

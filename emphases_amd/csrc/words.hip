@@ -97,6 +97,23 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(
     }
 }
 
+// One workgroup per piece: copy `length` columns of every row, zero the rest
+// of the piece's `padded` columns.
+__global__ __launch_bounds__(256) void gather_columns_kernel(
+    const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+    int channels, const int64_t* __restrict__ pieces) {
+    const int64_t* piece = pieces + static_cast<int64_t>(blockIdx.x) * 4;
+    const int64_t source = piece[0], target = piece[2];
+    const int length = static_cast<int>(piece[1]);
+    const int padded = static_cast<int>(piece[3]);
+    for (int index = threadIdx.x; index < channels * padded; index += 256) {
+        const int c = index / padded;
+        const int t = index - c * padded;
+        y[static_cast<int64_t>(c) * ldy + target + t] =
+            t < length ? x[static_cast<int64_t>(c) * ldx + source + t] : 0.f;
+    }
+}
+
 // one thread per position of the packed axis
 __global__ __launch_bounds__(256) void output_layer_kernel(
     const float* __restrict__ x, int64_t ldx, const float* __restrict__ weight,
@@ -165,6 +182,18 @@ int emph_segment_reduce(const float* x, int64_t ldx, const int32_t* bounds,
                            ldx, bounds, out, ldw, channels, seg, word_segment,
                            total_words, mode);
     return check_launch("emph_segment_reduce");
+}
+
+int emph_gather_columns(const float* x, int64_t ldx, float* y, int64_t ldy,
+                        int32_t channels, const int64_t* pieces, int32_t n_pieces,
+                        void* stream) {
+    if (n_pieces == 0) return EMPH_OK;
+    EMPH_REQUIRE(x && y && pieces, EMPH_EINVAL, "emph_gather_columns: null pointer");
+    EMPH_REQUIRE(channels > 0 && n_pieces > 0, EMPH_EINVAL,
+                 "emph_gather_columns: bad shape");
+    hipLaunchKernelGGL(gather_columns_kernel, dim3(n_pieces), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, ldx, y, ldy, channels, pieces);
+    return check_launch("emph_gather_columns");
 }
 
 int emph_output_layer(const float* x, int64_t ldx, const float* weight,

@@ -204,6 +204,25 @@ class Engine:
                  'positions': (plan.total_frames, plan.total_words)}
         for name, (start, size) in offsets.items():
             views[name] = (device_buffer[start:start + size], size)
+        if self.config.downsample_location == 'input' and len(plan.segments):
+            # every word is its own padded sequence: a second packed layout
+            pieces = plan.pieces(self.config.downsample_method)
+            nested = Engine.upload(
+                _PiecesView(self), pieces.plan,
+                self.frame_tile(pieces.plan))
+            extra = torch.from_numpy(np.concatenate([
+                pieces.gather.view(np.int32).ravel(),
+                pieces.bounds.ravel(), pieces.word_piece]))
+            if self.device.type == 'cuda':
+                extra = extra.pin_memory()
+            extra = extra.to(self.device, non_blocking=True)
+            cut = pieces.gather.size * 2
+            nested['gather'] = extra[:cut]
+            nested['piece_bounds'] = extra[cut:cut + pieces.bounds.size]
+            nested['word_piece'] = extra[cut + pieces.bounds.size:]
+            nested['plan'] = pieces.plan
+            nested['_extra'] = extra
+            views['pieces'] = nested
         return views
 
     ###########################################################################
@@ -384,10 +403,6 @@ class Engine:
         undefined).  The tensors are workspace buffers: they are overwritten
         by the next forward() of this engine."""
         config = self.config
-        if config.downsample_location == 'input':
-            raise NotImplementedError(
-                "DOWNSAMPLE_LOCATION='input' (model/core.py:41-87) is not "
-                'built yet')
         meta = meta or self.upload(plan)
         block = meta['tile']
         channels = config.channels
@@ -395,31 +410,68 @@ class Engine:
         frames, words = runtime.AXIS_FRAMES, runtime.AXIS_WORDS
         if features is None:
             features = self.features(audio, plan, meta, extra_rows=extra_rows)
-        a = self._buffer('frames_a', channels, ld_f)
-        b = self._buffer('frames_b', channels, ld_f)
-        self._conv(self.input_layer, features, ld_f, a, ld_f, meta, frames,
-                   block, None)
-        if stages is not None:
-            stages['features'] = features.clone()
-            stages['input_layer'] = a.clone()
-        encoded = self._stack_forward(
-            self.frame_encoder, a, b, ld_f, plan, meta, frames, block,
-            'frames')
-        if stages is not None:
-            stages['encoder'] = encoded.clone()
-
-        check_bounds(plan, config.downsample_method)
         table = meta['table'][0]
         logits = self._buffer('logits', ld_w)
         scores = self._buffer('scores', ld_w)
         wa = self._buffer('words_a', channels, ld_w)
-        with self._timed('segment_reduce'):
-            runtime.check(self.lib.emph_segment_reduce(
-                encoded.data_ptr(), ld_f, meta['bounds'][0].data_ptr(),
-                wa.data_ptr(), ld_w, channels, table.data_ptr(),
-                meta['word_segment'][0].data_ptr(), ld_w,
-                runtime.REDUCTIONS[config.downsample_method],
-                runtime.stream()), 'emph_segment_reduce')
+        if config.downsample_location == 'input':
+            # model/core.py:41-87: gather every word into its own zero-padded
+            # piece, encode the pieces as independent sequences, pool each
+            # over its padded length into the word's column
+            if config.architecture != 'convolution':
+                raise NotImplementedError(
+                    "DOWNSAMPLE_LOCATION='input' is built for the "
+                    'convolutional encoder only')
+            if stages is not None:
+                stages['features'] = features.clone()
+            piece_meta = meta['pieces']
+            piece_plan = piece_meta['plan']
+            ld_p = piece_plan.ld_frames
+            gathered = self._buffer(
+                'piece_features', config.num_features, ld_p)
+            with self._timed('gather_columns'):
+                runtime.check(self.lib.emph_gather_columns(
+                    features.data_ptr(), ld_f, gathered.data_ptr(), ld_p,
+                    config.num_features, piece_meta['gather'].data_ptr(),
+                    len(piece_plan.segments), runtime.stream()),
+                    'emph_gather_columns')
+            a = self._buffer('frames_a', channels, ld_p)
+            b = self._buffer('frames_b', channels, ld_p)
+            self._conv(self.input_layer, gathered, ld_p, a, ld_p, piece_meta,
+                       frames, piece_meta['tile'], None)
+            encoded = self._stack_forward(
+                self.frame_encoder, a, b, ld_p, piece_plan, piece_meta,
+                frames, piece_meta['tile'], 'frames')
+            with self._timed('segment_reduce'):
+                runtime.check(self.lib.emph_segment_reduce(
+                    encoded.data_ptr(), ld_p,
+                    piece_meta['piece_bounds'].data_ptr(), wa.data_ptr(),
+                    ld_w, channels, piece_meta['table'][0].data_ptr(),
+                    piece_meta['word_piece'].data_ptr(), ld_w,
+                    runtime.REDUCTIONS[config.downsample_method],
+                    runtime.stream()), 'emph_segment_reduce')
+        else:
+            a = self._buffer('frames_a', channels, ld_f)
+            b = self._buffer('frames_b', channels, ld_f)
+            self._conv(self.input_layer, features, ld_f, a, ld_f, meta,
+                       frames, block, None)
+            if stages is not None:
+                stages['features'] = features.clone()
+                stages['input_layer'] = a.clone()
+            encoded = self._stack_forward(
+                self.frame_encoder, a, b, ld_f, plan, meta, frames, block,
+                'frames')
+            if stages is not None:
+                stages['encoder'] = encoded.clone()
+
+            check_bounds(plan, config.downsample_method)
+            with self._timed('segment_reduce'):
+                runtime.check(self.lib.emph_segment_reduce(
+                    encoded.data_ptr(), ld_f, meta['bounds'][0].data_ptr(),
+                    wa.data_ptr(), ld_w, channels, table.data_ptr(),
+                    meta['word_segment'][0].data_ptr(), ld_w,
+                    runtime.REDUCTIONS[config.downsample_method],
+                    runtime.stream()), 'emph_segment_reduce')
         if stages is not None:
             stages['downsampled'] = wa.clone()
         if self.fused_words:
@@ -475,6 +527,17 @@ class Engine:
         with torch.cuda.graph(graph):
             scores, logits = self.forward(audio, plan, meta)
         return graph.replay, scores, logits
+
+
+class _PiecesView:
+    """The parts of an Engine that `upload` needs, for the nested layout of
+    the word pieces (frame-axis tiles only; a plain convolutional config)."""
+
+    def __init__(self, engine):
+        self.device = engine.device
+        self.word_block = engine.word_block
+        self.frame_tile = engine.frame_tile
+        self.config = cfg.DEFAULT
 
 
 def check_bounds(plan, method):

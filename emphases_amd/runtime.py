@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -56,6 +56,8 @@ SIGNATURES = {
     'emph_output_layer': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _i64, _i32, _i32,
         _ptr, _ptr, _ptr]),
+    'emph_gather_columns': (_c.c_int, [
+        _ptr, _i64, _ptr, _i64, _i32, _ptr, _i32, _ptr]),
     'emph_word_decoder_block': (_i32, [_i32, _i32, _i32]),
     'emph_word_decoder_pack_size': (_i64, [_i32, _i32]),
     'emph_word_decoder_pack': (_c.c_int, [_ptr, _i32, _i32, _ptr]),

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 6
+#define EMPH_ABI_VERSION 7
 
 /* Segment-table fields */
 enum {
@@ -234,6 +234,16 @@ int emph_output_layer(const float* x, int64_t ldx, const float* weight,
                       const int32_t* position_segment, int64_t total,
                       int32_t axis, int32_t post, float* logits,
                       float* scores, void* stream);
+
+/* Word pieces for DOWNSAMPLE_LOCATION = 'input' (emphases/model/core.py:41-87
+ * with emphases/core.py:552-586): every word becomes its own zero-padded
+ * sequence.  Piece p copies `length` columns of every row of x starting at
+ * column `source` to columns target .. target + length of y and zeroes columns
+ * target + length .. target + padded.
+ *   pieces  int64 [n_pieces][4] = (source, length, target, padded) */
+int emph_gather_columns(const float* x, int64_t ldx, float* y, int64_t ldy,
+                        int32_t channels, const int64_t* pieces,
+                        int32_t n_pieces, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Fused word stage of the convolutional model                               */

@@ -48,6 +48,29 @@ def spans(plan, axis):
 
 
 ###############################################################################
+# word pieces
+###############################################################################
+
+
+def test_gather_columns():
+    lib = runtime.library()
+    x = torch.from_numpy(synth.weights(3, (81, 300), 1.0))
+    table = np.array([[16, 5, 32, 21], [40, 21, 64, 21], [299, 1, 16, 3],
+                      [100, 0, 96, 7]], dtype=np.int64)
+    y = torch.full((81, 128), 9.0, device=DEVICE)
+    x_dev, table_dev = x.to(DEVICE), torch.from_numpy(table).to(DEVICE)
+    runtime.check(lib.emph_gather_columns(
+        x_dev.data_ptr(), 300, y.data_ptr(), 128, 81, table_dev.data_ptr(),
+        len(table), None), 'emph_gather_columns')
+    y = y.cpu()
+    want = torch.full((81, 128), 9.0)
+    for source, length, target, padded in table:
+        want[:, target:target + padded] = 0.
+        want[:, target:target + length] = x[:, source:source + length]
+    assert torch.equal(y, want)
+
+
+###############################################################################
 # conv1d
 ###############################################################################
 

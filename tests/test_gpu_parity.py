@@ -138,8 +138,6 @@ def test_variant_matrix(variants):
     checked = 0
     for name in variants['names']:
         config, _ = variant_config(name)
-        if config.downsample_location == 'input':
-            continue                    # not built yet
         engine = engine_module.Engine(
             config, weights.random_state(config, seed=7), 0)
         plan, scores, logits = run_case(engine, audio, bounds, None)
@@ -152,7 +150,7 @@ def test_variant_matrix(variants):
         assert np.abs(scores.cpu().numpy()[columns] -
                       variants[f'{name}/scores']).max() < SCORE_TOLERANCE, name
         checked += 1
-    assert checked == 29
+    assert checked == 33
 
 
 def test_loudness_row(variants):

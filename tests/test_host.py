@@ -349,3 +349,33 @@ def test_product_does_not_import_the_oracle():
                 source = open(os.path.join(directory, file)).read()
                 assert not re.search(
                     r'^\s*(from|import)\s+oracle', source, flags=re.M), file
+
+
+def test_word_pieces_layout():
+    """DOWNSAMPLE_LOCATION='input': one padded piece per word, pooled back
+    into the word's own column (`model/core.py:41-87`)."""
+    bounds_a = np.array([[0, 5, 9], [5, 9, 30]], dtype=np.int64)
+    bounds_b = np.array([[2], [7]], dtype=np.int64)
+    plan = batch.Plan(
+        [batch.Segment(0, 0, 3, 0, 0, 30, bounds_a),
+         batch.Segment(1, 0, 1, 0, 0, 12, bounds_b)], [0, 0], [0, 0])
+    pieces = plan.pieces('sum')
+    assert pieces is plan.pieces('sum')
+    assert pieces.plan.frames.tolist() == [21, 21, 21, 5]
+    lengths = [5, 4, 21, 5]
+    for piece, length in enumerate(lengths):
+        source, count, target, padded = pieces.gather[piece]
+        assert count == length and padded == pieces.plan.frames[piece]
+        assert target == pieces.plan.frame_off[piece]
+    assert pieces.gather[1, 0] == plan.frame_off[0] + 5
+    assert pieces.gather[3, 0] == plan.frame_off[1] + 2
+    columns = plan.word_columns()
+    assert pieces.word_piece[columns].tolist() == [0, 1, 2, 3]
+    assert (np.delete(pieces.word_piece, columns) == -1).all()
+    assert pieces.bounds[:, columns].tolist() == [[0] * 4, [21, 21, 21, 5]]
+    center = plan.pieces('center')
+    assert center.bounds[:, columns].tolist() == [[0] * 4, lengths]
+    bad = batch.Plan(
+        [batch.Segment(0, 0, 1, 0, 0, 10, np.array([[4], [12]]))], [0], [0])
+    with pytest.raises(ValueError):
+        bad.pieces('sum')
