@@ -17,8 +17,10 @@
 
 namespace emph {
 
-// grid.x = blocks of 4 words over the packed word axis; block = 256 (one wave
-// per word).  CGROUPS = channel groups of 4 held in registers.
+// grid.x = blocks of 4 words over the packed word axis, grid.y = slices of
+// CGROUPS channel groups of 4; block = 256 (one wave per word and slice).  A
+// 10 s utterance has ~30 words, so a wave per word alone leaves most of the
+// chip without a wave: the channel slices give 4-5x as many.
 template <int CGROUPS>
 __global__ __launch_bounds__(256) void segment_reduce_kernel(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ bounds,
@@ -41,10 +43,11 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(
 
     const int fr = lane & 15;
     const int cg = lane >> 4;
+    const int group0 = blockIdx.y * CGROUPS;
     if (mode == EMPH_REDUCE_CENTER) {
         // gather at (start + end) // 2 of the UNclamped bounds (core.py:459-466)
         const int center = (raw_start + raw_end) >> 1;
-        for (int c = lane; c < channels; c += 64)
+        for (int c = 4 * group0 + lane; c < min(channels, 4 * (group0 + CGROUPS)); c += 64)
             out[static_cast<int64_t>(c) * ldw + word] =
                 (center >= 0 && center < frames)
                     ? x[static_cast<int64_t>(c) * ldx + frame_off + center]
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(
             const int t = min(t0 + 16 * half + fr, max(end - 1, 0));
 #pragma unroll
             for (int g = 0; g < CGROUPS; ++g) {
-                const int c = min(4 * min(g, groups - 1) + cg, channels - 1);
+                const int c = min(4 * min(group0 + g, groups - 1) + cg, channels - 1);
                 value[half][g] = base[static_cast<int64_t>(c) * ldx + t];
             }
         }
@@ -91,8 +94,8 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(
         }
         if (mode == EMPH_REDUCE_AVERAGE)
             value = value / static_cast<float>(end - start);   // 0/0 = NaN
-        const int c = 4 * g + cg;
-        if (fr == 0 && g < groups && c < channels)
+        const int c = 4 * (group0 + g) + cg;
+        if (fr == 0 && group0 + g < groups && c < channels)
             out[static_cast<int64_t>(c) * ldw + word] = value;
     }
 }
@@ -173,14 +176,9 @@ int emph_segment_reduce(const float* x, int64_t ldx, const int32_t* bounds,
                  "emph_segment_reduce: channels %d > 128", channels);
     const unsigned blocks = static_cast<unsigned>((total_words + 3) / 4);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (channels <= 80)
-        hipLaunchKernelGGL(segment_reduce_kernel<20>, dim3(blocks), dim3(256), 0, s, x,
-                           ldx, bounds, out, ldw, channels, seg, word_segment,
-                           total_words, mode);
-    else
-        hipLaunchKernelGGL(segment_reduce_kernel<32>, dim3(blocks), dim3(256), 0, s, x,
-                           ldx, bounds, out, ldw, channels, seg, word_segment,
-                           total_words, mode);
+    const unsigned slices = static_cast<unsigned>(((channels + 3) / 4 + 4) / 5);
+    hipLaunchKernelGGL(segment_reduce_kernel<5>, dim3(blocks, slices), dim3(256), 0, s, x, ldx,
+                       bounds, out, ldw, channels, seg, word_segment, total_words, mode);
     return check_launch("emph_segment_reduce");
 }
 

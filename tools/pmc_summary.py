@@ -1,0 +1,70 @@
+"""Per-launch HBM traffic of the bench kernels from the two rocprofv3 --pmc
+passes (FETCH_SIZE, WRITE_SIZE; KiB per dispatch) -> profiles/<tag>_pmc_summary.json
+
+    python tools/pmc_summary.py profiles r1
+"""
+import collections
+import csv
+import json
+import sys
+
+FRAMES, WORDS, CHANNELS = 64000, 1882, 80
+KERNELS = {
+    # kernel function substring -> (bench.py name, algorithmic bytes per launch)
+    'conv1d_winograd_kernel': (
+        'conv1d_winograd_frames_80x80_k3',
+        2 * CHANNELS * FRAMES * 4 + 102400),
+    'conv1d_kernel': (
+        'conv1d_frames_80x80_k3', 2 * CHANNELS * FRAMES * 4 + 76800),
+    'frontend_kernel': (
+        'frontend_logmel', FRAMES * 160 * 4 + CHANNELS * FRAMES * 4),
+    'segment_reduce_kernel': (
+        'segment_reduce', CHANNELS * FRAMES * 4 + CHANNELS * WORDS * 4),
+    'word_decoder_kernel': (
+        'word_decoder', CHANNELS * WORDS * 4 + 6 * 76800 + 2 * WORDS * 4),
+}
+
+
+def means(path):
+    total = collections.defaultdict(float)
+    count = collections.Counter()
+    for row in csv.DictReader(open(path)):
+        for key in KERNELS:
+            if key in row['Kernel_Name']:
+                total[key] += float(row['Counter_Value'])
+                count[key] += 1
+                break
+    return {key: total[key] / count[key] for key in total}
+
+
+def main():
+    directory, tag = sys.argv[1], sys.argv[2]
+    fetch = means(f'{directory}/{tag}_bench_pmc_fetch_size.csv')
+    write = means(f'{directory}/{tag}_bench_pmc_write_size.csv')
+    summary = {'_comment': (
+        'HBM traffic per launch on BASELINE configs[1] (64 x 10 s, conv '
+        'config) from rocprofv3 --pmc, one counter per pass '
+        f'(profiles/{tag}_bench_pmc_fetch_size.csv, _write_size.csv; bench.py '
+        '--streams 1). FETCH_SIZE/WRITE_SIZE are in KiB. On gfx950 FETCH_SIZE '
+        'tallies 128-byte requests at 64 bytes for wide streaming reads '
+        '(MI355X_MICROARCH.md, HBM); the conv kernel reads 16 bytes per lane '
+        'at 8-byte granularity, for which the factor is uncalibrated, so both '
+        'the raw and the doubled figure are kept and `traffic_bytes` uses the '
+        'doubled (upper) one.')}
+    for key, (name, algorithmic) in KERNELS.items():
+        if key not in fetch:
+            continue
+        raw = (fetch[key] + write.get(key, 0.)) * 1024
+        summary[name] = {
+            'fetch_size_kib': round(fetch[key], 1),
+            'write_size_kib': round(write.get(key, 0.), 1),
+            'traffic_bytes_raw': int(raw),
+            'traffic_bytes': int((2 * fetch[key] + write.get(key, 0.)) * 1024),
+            'algorithmic_bytes': algorithmic}
+    with open(f'{directory}/{tag}_pmc_summary.json', 'w') as file:
+        json.dump(summary, file, indent=2)
+    print(json.dumps(summary, indent=2))
+
+
+if __name__ == '__main__':
+    main()
