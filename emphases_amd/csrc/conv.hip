@@ -591,7 +591,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_winograd_kernel(
             for (int m = 0; m < MB; ++m) a[j][m] = fragment[(j * MB + m) << 6];
     };
 
-    Run<4> b0[NB];
+    Run<4> b0[NB], b1[NB];
     float a0[4][MB];
     const int groups_of_tiles = (n_tiles + WAVES - 1) / WAVES;
     open_tile(blockIdx.x);
@@ -615,6 +615,10 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_winograd_kernel(
 
     for (int group = blockIdx.x; group < groups_of_tiles; group += gridDim.x) {
         if (group != static_cast<int>(blockIdx.x)) {
+            // drain the previous tile's stores: with stores and loads both in
+            // flight hipcc waits for vmcnt(0) at every use of a loaded value,
+            // which would serialise the two requests the K loop keeps in flight
+            __builtin_amdgcn_s_waitcnt(0x0F70);
             open_tile(group);
             if (active) load_b(b0, 0);
         }
@@ -630,17 +634,21 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_winograd_kernel(
         float av[4][MB], v[4][NB];
         load_a(a0, 0);
         EMPH_STAMP(2);
-#pragma unroll 1
-        for (int iteration = 0; iteration < iterations; ++iteration) {
-            // input transform of the fragments that have landed (masked to the
-            // segment's zero halo first), and the A copies
+        // One K iteration (4 input channels): transform the B fragments that
+        // have landed, request the ones TWO iterations ahead into the registers
+        // just freed, then the 4 MB NB MFMAs with the next A fragments' LDS
+        // reads between them.  One iteration of MFMAs (0.6 us for the two
+        // waves of a SIMD) does not cover an L2 round trip on a busy chip
+        // (0.7-1 us): with a single request in flight every iteration began
+        // with a stall on vmcnt(0) (37.6 cycles per MFMA instead of 32).
+        auto step = [&](Run<4> (&b)[NB], int iteration, int ahead) {
             const bool row_inside = 4 * iteration + kk < c_in;
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
                 float d[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    d[i] = (inside[i][n] && row_inside) ? b0[n].get(i) : 0.f;
+                    d[i] = (inside[i][n] && row_inside) ? b[n].get(i) : 0.f;
                 v[0][n] = d[0] - d[2];
                 v[1][n] = d[1] + d[2];
                 v[2][n] = d[2] - d[1];
@@ -651,9 +659,8 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_winograd_kernel(
 #pragma unroll
                 for (int m = 0; m < MB; ++m) av[j][m] = a0[j][m];
             __builtin_amdgcn_sched_barrier(0);
-            const int next = min(iteration + 1, iterations - 1);
-            load_b(b0, next);
-            load_a(a0, next);
+            load_b(b, min(iteration + ahead, iterations - 1));
+            load_a(a0, min(iteration + 1, iterations - 1));
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -674,6 +681,25 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_winograd_kernel(
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
             }
             __builtin_amdgcn_sched_barrier(0);
+        };
+        if (NB == 1) {
+            // (whole pairs in the loop, the odd iteration after it: a
+            // conditional second half would merge into a vmcnt(0) at the loop
+            // head)
+            load_b(b1, min(1, iterations - 1));
+            int iteration = 0;
+#pragma unroll 1
+            for (; iteration + 1 < iterations; iteration += 2) {
+                step(b0, iteration, 2);
+                step(b1, iteration + 1, 2);
+            }
+            if (iteration < iterations) step(b0, iteration, 2);
+        } else {
+            // 64-position tiles: 40 MFMAs per iteration cover the round trip,
+            // and a second fragment set does not fit the register file
+#pragma unroll 1
+            for (int iteration = 0; iteration < iterations; ++iteration)
+                step(b0, iteration, 1);
         }
 
         EMPH_STAMP(3);
