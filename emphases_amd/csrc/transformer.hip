@@ -40,36 +40,56 @@ __global__ __launch_bounds__(256) void add_position_kernel(
     }
 }
 
-// one thread per column; y = LayerNorm(x + r) over channels
+// y = LayerNorm(x + r) over channels.  A workgroup is 64 columns x 4 channel
+// slices (wave w owns channels w, w + 4, ...: 256-byte row segments); the two
+// reductions (mean, then centred squares, as torch does) cross the waves
+// through LDS.  One thread per column left a 64 x 1000-frame batch with one
+// wave per SIMD and 160 loads per lane: 33 us for 61 MB.
 template <int CMAX>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(
     const float* x, const float* __restrict__ r, float* y,
     int64_t ld, int channels, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, int64_t first, int64_t count) {
-    const int64_t index = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
-    if (index >= count) return;
-    const int64_t column = first + index;
-    float v[CMAX];
+    constexpr int PER = (CMAX + 3) / 4;
+    __shared__ float partial[2][4][64];
+    const int lane = threadIdx.x & 63;
+    const int slice = threadIdx.x >> 6;
+    const int64_t index = static_cast<int64_t>(blockIdx.x) * 64 + lane;
+    const bool live = index < count;
+    const int64_t column = first + (live ? index : count - 1);
+    float v[PER];
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c) {
+    for (int j = 0; j < PER; ++j) {
+        const int c = 4 * j + slice;
+        v[j] = 0.f;
         if (c < channels) {
-            v[c] = x[static_cast<int64_t>(c) * ld + column] +
+            v[j] = x[static_cast<int64_t>(c) * ld + column] +
                    r[static_cast<int64_t>(c) * ld + column];
-            sum += v[c];
+            sum += v[j];
         }
     }
-    const float mean = sum / static_cast<float>(channels);
+    partial[0][slice][lane] = sum;
+    __syncthreads();
+    const float mean = (partial[0][0][lane] + partial[0][1][lane] + partial[0][2][lane] +
+                        partial[0][3][lane]) / static_cast<float>(channels);
     float square = 0.f;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-        if (c < channels) square = fmaf(v[c] - mean, v[c] - mean, square);
-    const float rstd = 1.f / sqrtf(square / static_cast<float>(channels) + eps);
+    for (int j = 0; j < PER; ++j)
+        if (4 * j + slice < channels) square = fmaf(v[j] - mean, v[j] - mean, square);
+    partial[1][slice][lane] = square;
+    __syncthreads();
+    const float variance = (partial[1][0][lane] + partial[1][1][lane] + partial[1][2][lane] +
+                            partial[1][3][lane]) / static_cast<float>(channels);
+    const float rstd = 1.f / sqrtf(variance + eps);
+    if (!live) return;
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
+    for (int j = 0; j < PER; ++j) {
+        const int c = 4 * j + slice;
         if (c < channels)
             y[static_cast<int64_t>(c) * ld + column] =
-                (v[c] - mean) * rstd * gamma[c] + beta[c];
+                (v[j] - mean) * rstd * gamma[c] + beta[c];
+    }
 }
 
 // grid = (n_tiles, heads); block = 64 (one wave = 64 queries of one head)
@@ -88,7 +108,8 @@ __global__ __launch_bounds__(64) void attention_kernel(
     const Tile span = load_tile(tiles, blockIdx.x);
     const int q0 = span.first;
     const int length = span.count;
-    const float scale = 1.f / sqrtf(static_cast<float>(D));
+    // softmax in base 2: log2(e) rides on the query scale, exp is v_exp_f32
+    const float scale = 1.44269504088896340736f / sqrtf(static_cast<float>(D));
 
     const float* q_rows = qk + static_cast<int64_t>(head * D) * ld + span.offset;
     const float* k_rows =
@@ -116,25 +137,39 @@ __global__ __launch_bounds__(64) void attention_kernel(
         for (int m = 0; m < MT; ++m) o[t][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    for (int key0 = 0; key0 < length; key0 += 16) {
-        // K fragment: A[i = key][k = d]
-        float ak[KSTEPS];
-        const int key = key0 + col;
+    // K fragment: A[i = key][k = d]; V fragment for k-step r: A[i = d][k] =
+    // V[key0 + 4*kk + r][d].  The fragments of block i+1 are requested before
+    // the MFMAs of block i (clamped addresses, masked values).
+    float ak_next[KSTEPS], av_next[4][MT];
+    auto request = [&](int key0) {
+        const int key = min(key0 + col, length - 1);
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s)
-            ak[s] = key < length ? k_rows[static_cast<int64_t>(4 * s + kk) * ld + key]
-                                 : 0.f;
-        // V fragment for k-step r: A[i = d][k] = V[key0 + 4*kk + r][d]
-        float av[4][MT];
+            ak_next[s] = k_rows[static_cast<int64_t>(4 * s + kk) * ld + key];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int vkey = key0 + 4 * kk + r;
+            const int vkey = min(key0 + 4 * kk + r, length - 1);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
-                av[r][m] = (vkey < length && 16 * m + col < D)
-                               ? v_rows[static_cast<int64_t>(vkey) * channels + 16 * m + col]
-                               : 0.f;
+                av_next[r][m] =
+                    v_rows[static_cast<int64_t>(vkey) * channels + min(16 * m + col, D - 1)];
         }
+    };
+    if (length > 0) request(0);
+    for (int key0 = 0; key0 < length; key0 += 16) {
+        float ak[KSTEPS];
+        float av[4][MT];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) ak[s] = key0 + col < length ? ak_next[s] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                av[r][m] = (key0 + 4 * kk + r < length && 16 * m + col < D) ? av_next[r][m]
+                                                                           : 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        request(min(key0 + 16, length - 1));
+        __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
@@ -152,11 +187,11 @@ __global__ __launch_bounds__(64) void attention_kernel(
             local = fmaxf(local, __shfl_xor(local, 16));
             local = fmaxf(local, __shfl_xor(local, 32));
             const float new_max = fmaxf(row_max[t], local);
-            const float alpha = expf(row_max[t] - new_max);
+            const float alpha = __builtin_amdgcn_exp2f(row_max[t] - new_max);
             float partial = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s4[r] = expf(s4[r] - new_max);
+                s4[r] = __builtin_amdgcn_exp2f(s4[r] - new_max);
                 partial += s4[r];
             }
             partial += __shfl_xor(partial, 16);
@@ -220,7 +255,7 @@ int emph_add_layernorm(const float* x, const float* r, float* y, int64_t ld,
                  "emph_add_layernorm: null pointer");
     EMPH_REQUIRE(channels > 0 && channels <= 128, EMPH_ERANGE,
                  "emph_add_layernorm: channels %d not in 1..128", channels);
-    const unsigned blocks = static_cast<unsigned>((columns + 255) / 256);
+    const unsigned blocks = static_cast<unsigned>((columns + 63) / 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (channels <= 80)
         hipLaunchKernelGGL(add_layernorm_kernel<80>, dim3(blocks), dim3(256), 0, s, x,
