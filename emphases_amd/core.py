@@ -85,10 +85,8 @@ def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
     results = [torch.zeros((1, 0)) for _ in audios]
     if segments:
         plan = batch.Plan(segments, offsets, lengths)
-        packed = torch.cat([
-            audio.to(torch.float32) for audio in audios]).contiguous()
-        packed = packed.to(device, non_blocking=True)
         with torch.cuda.device(device):
+            packed = engine.pack_audio(audios)
             scores, _ = engine.forward(packed, plan)
         # forward() returns workspace buffers: detach the result from them
         scores = scores.clone() if gpu is not None else scores.cpu()
