@@ -17,6 +17,8 @@
 //   column (lane & 15) in both products.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace emph {
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
 
 // grid = (n_tiles, heads); block = 64 (one wave = 64 queries of one head)
 template <int D>
-__global__ __launch_bounds__(64) void attention_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_kernel(
     const float* __restrict__ qk, const float* __restrict__ v,
     float* __restrict__ out, int64_t ld, int channels,
     const int32_t* __restrict__ tiles) {
@@ -156,17 +158,21 @@ __global__ __launch_bounds__(64) void attention_kernel(
         }
     };
     if (length > 0) request(0);
-    for (int key0 = 0; key0 < length; key0 += 16) {
+    // One block of 16 keys.  The fragments need no masks: the loads are
+    // clamped to valid rows, a key past the segment only feeds score rows that
+    // are set to -inf below (probability exactly 0, times a finite V), and the
+    // rows d >= D of a partial V^T tile only feed output rows that are never
+    // stored.  Only the last, partial block masks its scores.
+    auto block = [&](int key0, auto masked_tag) {
+        constexpr bool kMasked = decltype(masked_tag)::value;
         float ak[KSTEPS];
         float av[4][MT];
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) ak[s] = key0 + col < length ? ak_next[s] : 0.f;
+        for (int s = 0; s < KSTEPS; ++s) ak[s] = ak_next[s];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-                av[r][m] = (key0 + 4 * kk + r < length && 16 * m + col < D) ? av_next[r][m]
-                                                                           : 0.f;
+            for (int m = 0; m < MT; ++m) av[r][m] = av_next[r][m];
         __builtin_amdgcn_sched_barrier(0);
         request(min(key0 + 16, length - 1));
         __builtin_amdgcn_sched_barrier(0);
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(64) void attention_kernel(
             float local = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (key0 + 4 * kk + r >= length) s4[r] = -INFINITY;
+                if (kMasked && key0 + 4 * kk + r >= length) s4[r] = -INFINITY;
                 local = fmaxf(local, s4[r]);
             }
             local = fmaxf(local, __shfl_xor(local, 16));
@@ -207,7 +213,10 @@ __global__ __launch_bounds__(64) void attention_kernel(
                         av[r][m], s4[r], o[t][m], 0, 0, 0);
             }
         }
-    }
+    };
+    const int full = length & ~15;
+    for (int key0 = 0; key0 < full; key0 += 16) block(key0, std::false_type{});
+    if (full < length) block(full, std::true_type{});
 
     // O^T[d = 16 m + 4 kk + r][query col]
     float* o_rows = out + static_cast<int64_t>(head * D) * ld + span.offset;
