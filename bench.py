@@ -34,6 +34,10 @@ from emphases_amd import batch, config as cfg, runtime, synth  # noqa: E402
 UTTERANCES = 64
 FRAMES = 1000                 # 10 s at 100 frames/s
 PEAK_FP32_MFMA = 157.3        # TFLOP/s, MI355X_MICROARCH.md (dense, f32 in)
+PEAK_HBM = 8.0e12             # B/s, same guide
+# compulsory traffic and algorithmic flops of the conv path
+BYTES_PER_FRAME = 641.
+FLOPS_PER_FRAME, FLOPS_PER_WORD = 0.2968e6, 0.2309e6
 
 
 def parse_args():
@@ -80,6 +84,17 @@ def build_plan(audios, alignments):
     return batch.Plan(segments, offsets, lengths)
 
 
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as file:
+            for line in file:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown CPU'
+
+
 def cpu_baseline(audios, bounds, seconds=12.0):
     """The CPU oracle (port of the reference's op sequence, B=1 loop exactly
     like `emphases/core.py:169-179`) on this box's host cores."""
@@ -105,7 +120,8 @@ def cpu_baseline(audios, bounds, seconds=12.0):
         'kind': 'port',
         'sample': f'{done} x 10 s utterances in {elapsed:.1f} s, one at a '
                   f'time (B=1) through oracle/prominence.py, torch CPU fp32, '
-                  f'{cores} threads'}
+                  f'{cores} threads of {os.cpu_count()} logical cores, '
+                  f'{cpu_model()}'}
 
 
 def main():
@@ -256,6 +272,16 @@ def main():
                 # Winograd F(2,3) executes 2/3 of the direct form's MFMA work
                 'executed_mfma_flops_per_launch': flops / launches * (
                     2. / 3. if 'winograd' in dominant else 1.)},
+            # the whole path against both ceilings (per GPU).
+            # The conv path is MFMA-bound: its compulsory HBM traffic is only
+            # 641 B per frame.
+            'end_to_end': {
+                'mfma_frac': (plan.total_frames * FLOPS_PER_FRAME +
+                              plan.total_words * FLOPS_PER_WORD) * args.steps /
+                             elapsed / (PEAK_FP32_MFMA * 1e12),
+                'hbm_frac_compulsory': plan.total_frames * BYTES_PER_FRAME *
+                                       args.steps / elapsed / PEAK_HBM,
+                'binds': 'mfma'} if args.config == 'conv' else None,
             'kernels_us_per_step': {
                 name: value[1] / min(args.steps, 10) * 1e6
                 for name, value in kernels.items()},

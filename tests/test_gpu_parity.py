@@ -268,6 +268,42 @@ def test_transformer_position_limit():
         engine.forward(torch.zeros(frames * 160, device=engine.device), plan)
 
 
+def test_mixed_corpus_and_long_form(default_engine):
+    """The shapes of BASELINE configs[3] and [4] at reduced count: a corpus
+    of mixed 2-30 s utterances as ONE ragged batch, and a 5-minute utterance
+    chunked at batch_size = 3000 frames."""
+    state = {k: torch.from_numpy(v) for k, v in weights.load().items()}
+    lengths = [200 + (2801 * (7 * i + 3)) % 2801 for i in range(48)]
+    assert min(lengths) >= 200 and max(lengths) <= 3000
+    audios = [torch.from_numpy(synth.audio(100 + i, n))
+              for i, n in enumerate(lengths)]
+    aligns = [emphases_amd.Alignment.from_frames(synth.word_frames(100 + i, n))
+              for i, n in enumerate(lengths)]
+    scores = emphases_amd.from_alignments_and_audios(aligns, audios)
+    again = emphases_amd.from_alignments_and_audios(aligns[::-1], audios[::-1])
+    for index, (a, b) in enumerate(zip(scores, again[::-1])):
+        assert a.shape == (1, len(aligns[index]))
+        assert torch.isfinite(a).all()
+        # an utterance's scores do not depend on its neighbours in the batch
+        assert np.abs(a.numpy() - b.numpy()).max() < 1e-6
+        if index % 12 == 5:
+            times = [(w.start(), w.end()) for w in aligns[index]]
+            want = oracle.from_alignment_and_audio(
+                times, audios[index], state)
+            assert np.abs(a.numpy() - want.numpy()).max() < SCORE_TOLERANCE
+
+    frames = 30000
+    audio = torch.from_numpy(synth.audio(77, frames))
+    bounds = synth.word_frames(77, frames)
+    words = emphases_amd.Alignment.from_frames(bounds)
+    got = emphases_amd.from_alignment_and_audio(
+        words, audio, 16000, batch_size=3000)
+    want = oracle.from_alignment_and_audio(
+        seconds(bounds), audio, state, batch_size=3000)
+    assert got.shape == want.shape and got.shape[1] > 500
+    assert np.abs(got.numpy() - want.numpy()).max() < SCORE_TOLERANCE
+
+
 def test_many_words_per_segment(default_engine):
     """Segments far longer than the 64-word window of the fused word stage
     (halo recompute across word tiles), incl. 1-frame words."""
