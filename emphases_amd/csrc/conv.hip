@@ -219,9 +219,6 @@ __device__ __forceinline__ void store_patch(float* patch, float* __restrict__ y,
             v.z = finish(v.z, b[pass]);
             v.w = finish(v.w, b[pass]);
             if (channel >= c_out || quad >= NB * 4 || t >= span.count) continue;
-#ifdef EMPH_NO_STORE
-            if (ldy > 0) continue;     // experiment: everything but the global stores
-#endif
             float* out = y + static_cast<int64_t>(channel) * ldy + span.offset + t;
             if (vector_ok && t + 3 < span.count) {
                 *reinterpret_cast<float4*>(out) = v;
@@ -375,18 +372,16 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_kernel(
     const int groups_of_tiles = (n_tiles + WAVES - 1) / WAVES;
     open_tile(blockIdx.x);
     if (chunks == 1) {
-        if (!(transpose_out & 2)) stage_issue(0, iterations, 0);
+        stage_issue(0, iterations, 0);
         if (active) load_b(b0, 0);
         for (int index = threadIdx.x; index < MB * 16; index += THREADS) {
             const int channel = m_first * 16 + index;
             bias_lds[index] = (bias != nullptr && channel < c_out) ? bias[channel] : 0.f;
         }
-        if (!(transpose_out & 2)) {
-            stage_commit(iterations, 0);
-            for (int pass = 1; pass < stage_passes(iterations); ++pass) {
-                stage_issue(0, iterations, pass);
-                stage_commit(iterations, pass);
-            }
+        stage_commit(iterations, 0);
+        for (int pass = 1; pass < stage_passes(iterations); ++pass) {
+            stage_issue(0, iterations, pass);
+            stage_commit(iterations, pass);
         }
         __syncthreads();
     } else {
@@ -446,7 +441,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_kernel(
                 __syncthreads();
                 if (active) load_b(b0, first);
             }
-            if (!active || (transpose_out & 4)) continue;
+            if (!active) continue;
             // Software pipeline, one iteration deep: move the operands that
             // have landed into their MFMA registers (select_b masks B; A is
             // copied), immediately re-request the SAME registers for the next
@@ -812,13 +807,7 @@ int launch_conv(int n_tiles, int m_blocks, size_t weight_bytes, hipStream_t s,
                 const float* x, int64_t ldx, float* y, int64_t ldy,
                 const float* pack, const float* bias, int c_in, int c_out, int act,
                 const int32_t* tiles, int chunk_iterations, int transpose_out) {
-    // experiment knob EMPH_CONV_WAVES=4|8 (default: 4 for wide tiles, 8 otherwise)
-    static const int forced = [] {
-        const char* text = getenv("EMPH_CONV_WAVES");
-        return text ? atoi(text) : 0;
-    }();
-    const int waves = forced ? forced : conv_waves(NB);
-    if (waves == 4)
+    if (conv_waves(NB) == 4)
         return launch_conv_waves<KS, MB, NB, 4>(n_tiles, m_blocks, weight_bytes, s, x,
                                                 ldx, y, ldy, pack, bias, c_in, c_out,
                                                 act, tiles, chunk_iterations,
@@ -988,17 +977,15 @@ int emph_conv1d_winograd(const float* x, int64_t ldx, float* y, int64_t ldy,
     hipStream_t s = static_cast<hipStream_t>(stream);
     // 32-position tiles run two waves per SIMD (the second hides the first's
     // LDS / global latencies: 24.5 us vs 26.7 us with one 64-position wave)
-    static const bool eight =
-        !(getenv("EMPH_WINO_WAVES") && atoi(getenv("EMPH_WINO_WAVES")) == 4);
 #define EMPH_WINOGRAD(MB, NB, WAVES)                                                      \
     launch_winograd<MB, NB, WAVES>(x, ldx, y, ldy, pack, bias, c_in, c_out, activation, \
                                    tiles, n_tiles, m_blocks, s)
     if (mb == 5) {
         if (tile_n == 64) return EMPH_WINOGRAD(5, 2, 4);
-        return eight ? EMPH_WINOGRAD(5, 1, 8) : EMPH_WINOGRAD(5, 1, 4);
+        return EMPH_WINOGRAD(5, 1, 8);
     }
     if (tile_n == 64) return EMPH_WINOGRAD(4, 2, 4);
-    return eight ? EMPH_WINOGRAD(4, 1, 8) : EMPH_WINOGRAD(4, 1, 4);
+    return EMPH_WINOGRAD(4, 1, 8);
 #undef EMPH_WINOGRAD
 }
 
@@ -1035,13 +1022,7 @@ int emph_conv1d(const float* x, int64_t ldx, float* y, int64_t ldy,
     const size_t weight_bytes = chunk_iterations * iteration_bytes;
     const int m_blocks = (m_tiles + mb - 1) / mb;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // experiment knob: EMPH_CONV_SKIP=2 skips weight staging, =4 skips the MFMA
-    // loop (results are wrong; timing only)
-    static const int skip = [] {
-        const char* text = getenv("EMPH_CONV_SKIP");
-        return text ? atoi(text) : 0;
-    }();
-    transpose_out = (transpose_out ? 1 : 0) | skip;
+    transpose_out = transpose_out ? 1 : 0;
 #define EMPH_CONV(KS)                                                             \
     return mb == 5                                                                \
                ? launch_conv_nb<KS, 5>(tile_n, n_tiles, m_blocks, weight_bytes, s, x, \

@@ -164,9 +164,6 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
         for (int q = 0; q < total_chunks; ++q) {
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
-#ifdef EMPH_DECODER_SKIP
-            if (EMPH_DECODER_SKIP & 1) continue;
-#endif
             if (q + 1 < total_chunks) request(q + 1);
         }
     }
@@ -238,13 +235,6 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
                     for (int tap = 0; tap < KS; ++tap)
 #pragma unroll
                         for (int i = 0; i < COUNT; ++i) {
-#ifdef EMPH_DECODER_SKIP
-                            if (EMPH_DECODER_SKIP & 2) {
-                                acc[i][0] += a[i][(t * KS + tap) >> 2][(t * KS + tap) & 3] +
-                                             b[t][tap];
-                                continue;
-                            }
-#endif
                             acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                 a[i][(t * KS + tap) >> 2][(t * KS + tap) & 3], b[t][tap],
                                 acc[i], 0, 0, 0);
