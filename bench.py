@@ -58,6 +58,10 @@ def parse_args():
     parser.add_argument('--no-winograd', action='store_true',
                         help='direct (3-tap) form of the frame-rate convs '
                              'instead of Winograd F(2,3)')
+    parser.add_argument('--backend', default='nccl',
+                        help="torch.distributed backend ('nccl' = RCCL; "
+                             "'gloo' only to rehearse the N > 1 path on a box "
+                             'with fewer GPUs than ranks)')
     parser.add_argument('--no-graph', action='store_true',
                         help='launch kernel by kernel instead of replaying '
                              'the captured HIP graph')
@@ -131,11 +135,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         torch.distributed.init_process_group(
-            'nccl', rank=rank, world_size=world, device_id=device)
+            args.backend, rank=rank, world_size=world,
+            device_id=device if args.backend == 'nccl' else None)
 
     config = cfg.DEFAULT if args.config == 'conv' else \
         cfg.Config(architecture='transformer')
@@ -169,7 +175,8 @@ def main():
             else torch.cuda.current_stream()
         with torch.cuda.stream(stream):
             send = torch.zeros(most_words, dtype=torch.float32, device=device)
-            gathered = [torch.empty_like(send) for _ in range(world)]
+            gathered = torch.empty(
+                world * most_words, dtype=torch.float32, device=device)
             if args.no_graph:
                 lanes.append((stream, lane_engine, None, None, send, gathered))
             else:
@@ -191,7 +198,7 @@ def main():
             if world > 1:
                 # the one exchange of the path: RCCL all_gather of word scores
                 send[:plan.total_words] = scores[columns]
-                torch.distributed.all_gather(gathered, send)
+                torch.distributed.all_gather_into_tensor(gathered, send)
         return scores
 
     def barrier():

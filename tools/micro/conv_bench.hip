@@ -37,7 +37,8 @@ static int conv(const float* x, int64_t ld, float* y, const float* pack, const f
 
 int main(int argc, char** argv) {
     g_wino = getenv("WINO") != nullptr;
-    const int segments = 64, frames = 1000, c = 80, ks = 3;
+    const int segments = 64, frames = 1000, c = 80;
+    const int ks = getenv("KS") ? atoi(getenv("KS")) : 3;
     const int64_t ld = 16 + static_cast<int64_t>(segments) * 1008 + 64;
     std::vector<float> hx(c * ld);
     for (size_t i = 0; i < hx.size(); ++i) hx[i] = (float)((i * 2654435761u) % 1000) / 1000.f - 0.5f;
