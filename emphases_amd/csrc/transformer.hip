@@ -94,6 +94,28 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     }
 }
 
+// Reductions over the four 16-lane rows of a wave (the k index of an MFMA
+// fragment) on gfx950's v_permlane16_swap / v_permlane32_swap: with both
+// operands equal, the swap leaves (row 0, row 0, row 2, row 2) in one register
+// and (row 1, row 1, row 3, row 3) in the other, so one VALU op combines rows
+// pairwise - no trip through the LDS crossbar (ds_bpermute) and its wait.
+__device__ __forceinline__ float rows_max(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false,
+                                              false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false,
+                                              false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false,
+                                              false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false,
+                                              false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // grid = (n_tiles, heads); block = 64 (one wave = 64 queries of one head)
 template <int D>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_kernel(
@@ -190,8 +212,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if (kMasked && key0 + 4 * kk + r >= length) s4[r] = -INFINITY;
                 local = fmaxf(local, s4[r]);
             }
-            local = fmaxf(local, __shfl_xor(local, 16));
-            local = fmaxf(local, __shfl_xor(local, 32));
+            local = rows_max(local);
             const float new_max = fmaxf(row_max[t], local);
             const float alpha = __builtin_amdgcn_exp2f(row_max[t] - new_max);
             float partial = 0.f;
@@ -200,8 +221,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 s4[r] = __builtin_amdgcn_exp2f(s4[r] - new_max);
                 partial += s4[r];
             }
-            partial += __shfl_xor(partial, 16);
-            partial += __shfl_xor(partial, 32);
+            partial = rows_sum(partial);
             row_sum[t] = row_sum[t] * alpha + partial;
             row_max[t] = new_max;
 #pragma unroll
