@@ -330,6 +330,43 @@ def test_host_side_abi_helpers():
     assert b'null' in library.emph_last_error()
 
 
+def test_winograd_and_decoder_packs():
+    """Host-side weight layouts of the Winograd conv and the word decoder,
+    checked entry by entry against their definition."""
+    library = runtime.library()
+    weight = synth.weights(9, (80, 81, 3), 1.0)
+    pack = runtime.conv_winograd_pack(weight)
+    groups, mb = 21, 5
+    assert pack.shape == (groups * 4 * mb * 64,)
+    image = pack.reshape(1, groups, 4, mb, 64)
+    wide = weight.astype(np.float64)
+    transformed = [
+        wide[:, :, 0], (wide[:, :, 0] + wide[:, :, 1] + wide[:, :, 2]) / 2,
+        (wide[:, :, 0] - wide[:, :, 1] + wide[:, :, 2]) / 2, wide[:, :, 2]]
+    for group, j, m, lane in [(0, 0, 0, 0), (3, 1, 2, 17), (20, 2, 4, 5),
+                              (20, 3, 4, 63), (7, 2, 1, 48)]:
+        row, column = 16 * m + (lane & 15), 4 * group + (lane >> 4)
+        want = transformed[j][row, column] if column < 81 else 0.
+        assert image[0, group, j, m, lane] == np.float32(want)
+    assert runtime.conv_winograd_lds_bytes(80, 80) < 160 * 1024 < \
+        runtime.conv_winograd_lds_bytes(80, 200)
+    # 128 output channels: two m-blocks of four tiles
+    assert runtime.conv_winograd_pack(
+        np.ones((128, 128, 3), dtype=np.float32)).size == 2 * 32 * 4 * 4 * 64
+
+    square = synth.weights(10, (80, 80, 3), 1.0)
+    packed = runtime.word_decoder_pack(square).reshape(5, 5, 64, 4, 3)
+    for trip, m, lane, t, tap in [(0, 0, 0, 0, 0), (4, 4, 63, 3, 2),
+                                  (2, 1, 37, 1, 1)]:
+        assert packed[trip, m, lane, t, tap] == square[
+            16 * m + (lane & 15), 16 * trip + 4 * t + (lane >> 4), tap]
+    assert library.emph_word_decoder_pack(None, 80, 3, None) == -1
+    scratch = np.zeros(8, dtype=np.float32)
+    assert library.emph_word_decoder_pack(
+        scratch.ctypes.data, 72, 3, scratch.ctypes.data) == -2
+    assert library.emph_conv_winograd_pack(None, 1, 1, None) == -1
+
+
 def test_no_silent_cpu_fallback():
     if torch.cuda.is_available():
         pytest.skip('GPU present')
