@@ -166,15 +166,15 @@ class Engine:
         4 waves (64-position tiles) or 8 waves (16 / 32), so a launch costs
         (trips over the 256 CUs) x (time of one trip): pick the tile that
         minimises it.  Microseconds per trip measured on the 80x80 k=3 layer
-        (tools/micro/conv_bench.hip): Winograd 32: 24.5, Winograd 64: 26.7,
-        direct 64: 33.2, direct 32: 32.9, direct 16: 18.5."""
+        (tools/micro/conv_bench.hip): Winograd 32: 24.0, Winograd 64: 26.7,
+        direct 64: 33.5, direct 32: 31.3, direct 16: 16.1."""
         if self.conv_tile is not None:
             return self.conv_tile
         frames = [segment.frames for segment in plan.segments]
         if self.winograd:
-            cost = {64: 26.7, 32: 24.5, 16: 18.5}
+            cost = {64: 26.7, 32: 24.0, 16: 16.1}
         else:
-            cost = {64: 33.2, 32: 32.9, 16: 18.5}
+            cost = {64: 33.5, 32: 31.3, 16: 16.1}
         best = None
         for tile in (32, 64, 16):
             tiles = sum(-(-count // tile) for count in frames)
