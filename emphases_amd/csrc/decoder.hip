@@ -200,8 +200,11 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
             // Two register sets, read and consumed alternately (copying one set
             // into the other cost 48 v_mov per trip, in lockstep on both waves
             // of a SIMD, with the matrix pipe idle meanwhile).
-            f32x4 a_set[2][COUNT][KS];
-            float b_set[2][4][KS];
+            // (kernel_size 5 with three or four m-tiles per wave does not fit two
+            // sets in 168 registers: it reads each trip right before using it)
+            constexpr bool kTwoSets = KS * COUNT <= 12;
+            f32x4 a_set[kTwoSets ? 2 : 1][COUNT][KS];
+            float b_set[kTwoSets ? 2 : 1][4][KS];
             auto issue = [&](f32x4 (&a_out)[COUNT][KS], float (&b_out)[4][KS], int trip) {
                 const int piece = trip / chunk_trips;
                 const int q = layer * chunks_per_layer + piece;
@@ -224,11 +227,16 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
             };
             auto step = [&](f32x4 (&a)[COUNT][KS], float (&b)[4][KS],
                             f32x4 (&a_out)[COUNT][KS], float (&b_out)[4][KS], int trip) {
-                const int next = min(trip + 1, trips - 1);
-                if (trip + 1 < trips && (trip + 1) % chunk_trips == 0)
-                    __syncthreads();                  // the next chunk has landed
-                __builtin_amdgcn_sched_barrier(0);
-                issue(a_out, b_out, next);            // (the last trip re-reads itself)
+                if (kTwoSets) {
+                    const int next = min(trip + 1, trips - 1);
+                    if (trip + 1 < trips && (trip + 1) % chunk_trips == 0)
+                        __syncthreads();              // the next chunk has landed
+                    __builtin_amdgcn_sched_barrier(0);
+                    issue(a_out, b_out, next);        // (the last trip re-reads itself)
+                } else {
+                    if (trip > 0 && trip % chunk_trips == 0) __syncthreads();
+                    issue(a_out, b_out, trip);        // a_out aliases a
+                }
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -251,10 +259,16 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
             };
             __syncthreads();                          // chunk (layer, 0) is in the ring
             if (layer == 1) EMPH_STAMP(10);
-            issue(a_set[0], b_set[0], 0);
-            for (int trip = 0; trip < trips; trip += 2) {
-                step(a_set[0], b_set[0], a_set[1], b_set[1], trip);
-                if (trip + 1 < trips) step(a_set[1], b_set[1], a_set[0], b_set[0], trip + 1);
+            if (kTwoSets) {
+                issue(a_set[0], b_set[0], 0);
+                for (int trip = 0; trip < trips; trip += 2) {
+                    step(a_set[0], b_set[0], a_set[kTwoSets], b_set[kTwoSets], trip);
+                    if (trip + 1 < trips)
+                        step(a_set[kTwoSets], b_set[kTwoSets], a_set[0], b_set[0], trip + 1);
+                }
+            } else {
+                for (int trip = 0; trip < trips; ++trip)
+                    step(a_set[0], b_set[0], a_set[0], b_set[0], trip);
             }
             // bias + activation; re-apply the segment's zero halo.  All bias
             // reads first, the activation switch outside the element loops (an
