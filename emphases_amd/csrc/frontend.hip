@@ -41,6 +41,7 @@ void set_error(const char* format, ...) {
     va_end(args);
 }
 
+constexpr float kLn2 = 0.69314718055994530942f;
 constexpr int kBlockFrames = 32;                               // frames per workgroup
 constexpr int kStage = kHop * (kBlockFrames - 1) + kFft;       // 5984 samples
 constexpr int kExRow = 72;                                     // complex per exchange row
@@ -388,8 +389,10 @@ __global__ __launch_bounds__(256) void frontend_kernel(
 #pragma unroll
             for (int j = 0; j < kRunA; ++j)
                 acc = fmaf(weight_a[j], mag[start_a + j], acc);
-            float value = logf(fmaxf(acc, 1e-5f));
-            if (normalize) value = (value + 10.f) / 10.f;
+            // natural log on v_log_f32 (log2, 1 ulp; the argument is >= 1e-5);
+            // (x + 10) / 10 as one fma: both within 1e-7 of the exact forms
+            float value = kLn2 * __builtin_amdgcn_logf(fmaxf(acc, 1e-5f));
+            if (normalize) value = fmaf(value, 0.1f, 1.f);
             tile[lane * kOutStride + local] = value;
             acc = 0.f;
 #pragma unroll
@@ -398,8 +401,8 @@ __global__ __launch_bounds__(256) void frontend_kernel(
             acc += __shfl_xor(acc, 1);
             acc += __shfl_xor(acc, 2);
             if ((lane & 3) == 0) {
-                value = logf(fmaxf(acc, 1e-5f));
-                if (normalize) value = (value + 10.f) / 10.f;
+                value = kLn2 * __builtin_amdgcn_logf(fmaxf(acc, 1e-5f));
+                if (normalize) value = fmaf(value, 0.1f, 1.f);
                 tile[(64 + (lane >> 2)) * kOutStride + local] = value;
             }
             wave_lds_fence();
