@@ -58,58 +58,78 @@ constexpr int kTabTw2 = kTabTw1 + 2 * 512;     // [8][8] complex   W64^(p0 t)
 constexpr int kTabTw3 = kTabTw2 + 2 * 64;      // [513] complex    W1024^k
 constexpr int kTabSize = kTabTw3 + 2 * 514;
 
-struct cf {
-    float x, y;
-};
+// A complex number is one 64-bit register pair, and every butterfly below is a
+// packed instruction on it: hipcc's own pairing of the scalar form mixed halves
+// of different values and spent 70 v_mov per frame splicing them (this kernel
+// is bound by VALU issue).  Rotations by -i ride on the operand-select / negate
+// modifiers of the add that consumes them.
+typedef float cf __attribute__((ext_vector_type(2)));
 
-// Complex product in two packed instructions: t = (a.y b.y, a.y b.x), then
-// (a.x b.x - t.x, a.x b.y + t.y) with the subtraction as a negate of the low
-// half only.  hipcc finds the packed multiply but then issues TWO packed fmas
-// (one per sign) and a v_mov to splice their halves: 4 instructions; there are
-// 22 complex products per frame in a kernel that is bound by VALU issue.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// a b: t = (a.y b.y, a.y b.x), then (a.x b.x - t.x, a.x b.y + t.y)
 __device__ __forceinline__ cf cmul(cf a, cf b) {
-    const f32x2 av = {a.x, a.y}, bv = {b.x, b.y};
-    f32x2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "v"(bv));
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(b));
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
         : "=v"(r)
-        : "v"(av), "v"(bv), "v"(t));
-    return {r.x, r.y};
+        : "v"(a), "v"(b), "v"(t));
+    return r;
 }
-__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
-// multiply by -i
-__device__ __forceinline__ cf mul_neg_i(cf a) { return {a.y, -a.x}; }
+// a + (-i) b = (a.x + b.y, a.y - b.x)
+__device__ __forceinline__ cf add_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]"
+        : "=v"(r)
+        : "v"(a), "v"(b));
+    return r;
+}
+// a - (-i) b = (a.x - b.y, a.y + b.x)
+__device__ __forceinline__ cf sub_mi(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+        : "=v"(r)
+        : "v"(a), "v"(b));
+    return r;
+}
+// a + conj(b) and a - conj(b)
+__device__ __forceinline__ cf add_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ cf sub_conj(cf a, cf b) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 // In-place forward DFT of 8 points, natural order in and out:
-// v[r] <- sum_q v[q] exp(-2 pi i q r / 8)
+// v[r] <- sum_q v[q] exp(-2 pi i q r / 8).  28 packed instructions.
 __device__ __forceinline__ void dft8(cf v[8]) {
     constexpr float kH = 0.70710678118654752440f;
-    cf a0 = cadd(v[0], v[4]), b0 = csub(v[0], v[4]);
-    cf a1 = cadd(v[1], v[5]), b1 = csub(v[1], v[5]);
-    cf a2 = cadd(v[2], v[6]), b2 = csub(v[2], v[6]);
-    cf a3 = cadd(v[3], v[7]), b3 = csub(v[3], v[7]);
-    // b_j *= W8^j
-    b1 = {kH * (b1.x + b1.y), kH * (b1.y - b1.x)};
-    b2 = mul_neg_i(b2);
-    b3 = {kH * (b3.y - b3.x), -kH * (b3.x + b3.y)};
+    const cf a0 = v[0] + v[4], b0 = v[0] - v[4];
+    const cf a1 = v[1] + v[5], d1 = v[1] - v[5];
+    const cf a2 = v[2] + v[6], b2 = v[2] - v[6];    // (b2 is used as -i b2 below)
+    const cf a3 = v[3] + v[7], d3 = v[3] - v[7];
+    // b1 = W8 d1 = kH (d1.x + d1.y, d1.y - d1.x); b3 = W8^3 d3 = -kH (d3.x - d3.y,
+    // d3.x + d3.y)
+    const cf b1 = add_mi(d1, d1) * kH;
+    const cf b3 = sub_mi(d3, d3) * -kH;
     // DFT-4 of a -> even outputs
-    cf e0 = cadd(a0, a2), e1 = csub(a0, a2);
-    cf o0 = cadd(a1, a3), o1 = mul_neg_i(csub(a1, a3));
-    v[0] = cadd(e0, o0);
-    v[2] = cadd(e1, o1);
-    v[4] = csub(e0, o0);
-    v[6] = csub(e1, o1);
-    // DFT-4 of b -> odd outputs
-    e0 = cadd(b0, b2);
-    e1 = csub(b0, b2);
-    o0 = cadd(b1, b3);
-    o1 = mul_neg_i(csub(b1, b3));
-    v[1] = cadd(e0, o0);
-    v[3] = cadd(e1, o1);
-    v[5] = csub(e0, o0);
-    v[7] = csub(e1, o1);
+    cf e0 = a0 + a2, e1 = a0 - a2;
+    cf o0 = a1 + a3, t = a1 - a3;
+    v[0] = e0 + o0;
+    v[4] = e0 - o0;
+    v[2] = add_mi(e1, t);
+    v[6] = sub_mi(e1, t);
+    // DFT-4 of (b0, b1, -i b2, b3) -> odd outputs
+    e0 = add_mi(b0, b2);
+    e1 = sub_mi(b0, b2);
+    o0 = b1 + b3;
+    t = b1 - b3;
+    v[1] = e0 + o0;
+    v[5] = e0 - o0;
+    v[3] = add_mi(e1, t);
+    v[7] = sub_mi(e1, t);
 }
 
 __device__ __forceinline__ float wave_max(float value) {
@@ -170,10 +190,10 @@ __global__ __launch_bounds__(256) void frontend_kernel(
                   table[kTabTw1 + 2 * (q * 64 + p) + 1]};
         tw2[q] = {table[kTabTw2 + 2 * (q * 8 + p0)],
                   table[kTabTw2 + 2 * (q * 8 + p0) + 1]};
-        tw3[q] = {table[kTabTw3 + 2 * (lane + 64 * q)],
-                  table[kTabTw3 + 2 * (lane + 64 * q) + 1]};
+        // -i W1024^k: the real-FFT split multiplies it with zk - conj(zm)
+        tw3[q] = {table[kTabTw3 + 2 * (lane + 64 * q) + 1],
+                  -table[kTabTw3 + 2 * (lane + 64 * q)]};
     }
-    const cf tw_nyquist = {table[kTabTw3 + 2 * 512], table[kTabTw3 + 2 * 512 + 1]};
 
     // Sparse mel projection: every filterbank row is a contiguous run of bins.
     // Rows 0..63 (runs of at most kRunA bins) get one lane each; rows 64..79
@@ -286,9 +306,8 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         cf v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float2 pair =
-                *reinterpret_cast<const float2*>(samples + 2 * (p + 64 * q));
-            v[q] = {pair.x * window[2 * q], pair.y * window[2 * q + 1]};
+            v[q] = *reinterpret_cast<const cf*>(samples + 2 * (p + 64 * q)) *
+                   cf{window[2 * q], window[2 * q + 1]};
         }
         if (local == wave) EMPH_STAMP(2);
         dft8(v);
@@ -331,18 +350,17 @@ __global__ __launch_bounds__(256) void frontend_kernel(
             const int k = lane + 64 * j;
             const cf zk = ex[k];
             const cf zm = ex[(512 - k) & 511];
-            // X[k] = (E + W^k O) / 2: the halves are folded into the power
-            const cf even = {zk.x + zm.x, zk.y - zm.y};
-            const cf odd = {zk.y + zm.y, zm.x - zk.x};
-            const cf rot = cmul(tw3[j], odd);
-            const float re = even.x + rot.x, im = even.y + rot.y;
-            power[j] = 0.25f * (re * re + im * im);
+            // X[k] = (E + W^k O) / 2 with E = zk + conj(zm), O = -i (zk -
+            // conj(zm)): the -i rides on the twiddle table, the halves on the
+            // power
+            const cf value = add_conj(zk, zm) + cmul(tw3[j], sub_conj(zk, zm));
+            power[j] = 0.25f * (value.x * value.x + value.y * value.y);
         }
         {
             const cf z0 = ex[0];
-            const cf rot = cmul(tw_nyquist, cf{z0.y, 0.f});
-            const float re = z0.x + rot.x, im = rot.y;
-            power[8] = re * re + im * im;
+            // k = 512: E = (2 z0.x, 0), O = (2 z0.y, 0), W = -1
+            const float re = z0.x - z0.y;
+            power[8] = re * re;
         }
         wave_lds_fence();
 
