@@ -47,35 +47,40 @@ def _word_times(alignment):
 
 
 def chunk_utterance(alignment, num_samples, batch_size=None, utterance=0):
-    """Chunk plan of one utterance; `alignment` follows the pypar protocol."""
+    """Chunk plan of one utterance; `alignment` follows the pypar protocol.
+
+    The reference's per-word Python loops (`core.py:361-400`) as float64 array
+    operations with the same IEEE steps: floor division, a sequential running
+    sum (`np.cumsum`), truncation."""
     times = alignment if isinstance(alignment, list) else \
         _word_times(alignment)
     padded = num_samples + 2 * cfg.PADDING
     total_frames = int(padded / cfg.HOPSIZE)                     # core.py:359
     limit = total_frames if batch_size is None else batch_size
     segments = []
-    start = 0
     count = len(times)
+    if not count:
+        return segments
+    table = np.asarray(times, dtype=np.float64).reshape(count, 2)
+    starts, ends = table[:, 0], table[:, 1]
+    word_frames = convert.seconds_to_frames(ends - starts)      # core.py:373
+    start_frames = (starts * cfg.SAMPLE_RATE / cfg.HOPSIZE).astype(np.int64)
+    end_frames = (ends * cfg.SAMPLE_RATE / cfg.HOPSIZE).astype(np.int64)
+    start = 0
     while start < count:
-        frames = 0.
-        end = start + 1
-        while end < count:
-            frames += convert.seconds_to_frames(
-                times[end - 1][1] - times[end - 1][0])           # core.py:373
-            if int(frames) > limit:
-                break
-            end += 1
-        first, last = times[start], times[end - 1]
-        origin = int(first[0] * cfg.SAMPLE_RATE / cfg.HOPSIZE)
-        bounds = np.array(
-            [[int(s * cfg.SAMPLE_RATE / cfg.HOPSIZE) - origin
-              for s, _ in times[start:end]],
-             [int(e * cfg.SAMPLE_RATE / cfg.HOPSIZE) - origin
-              for _, e in times[start:end]]], dtype=np.int64)
+        # the chunk grows word by word until the running frame count of the
+        # words it already holds exceeds the limit (the alignment's last word
+        # is never counted)
+        running = np.cumsum(word_frames[start:count - 1])
+        over = np.nonzero(running.astype(np.int64) > limit)[0]
+        end = start + 1 + int(over[0]) if over.size else count
+        origin = int(start_frames[start])
+        bounds = np.stack(
+            [start_frames[start:end], end_frames[start:end]]) - origin
         start_sample = int(convert.frames_to_samples(
-            int(convert.seconds_to_frames(first[0]))))           # core.py:395
+            int(convert.seconds_to_frames(float(starts[start])))))  # core.py:395
         end_sample = int(convert.frames_to_samples(
-            int(convert.seconds_to_frames(last[1]))))            # core.py:398
+            int(convert.seconds_to_frames(float(ends[end - 1])))))  # core.py:398
         start_sample = max(0, min(start_sample, padded))
         end_sample = max(0, min(end_sample, padded))   # slice clamps
         length = max(0, end_sample - start_sample)

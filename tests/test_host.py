@@ -67,6 +67,33 @@ def test_dropped_chunk_has_no_scores(chunk_goldens):
         [(0, 1), (2, 3), (3, 4)]
 
 
+def test_vectorised_chunking_equals_the_scalar_loops():
+    """batch.chunk_utterance (array form) against the oracle's word-by-word
+    restatement of `core.py:361-400` on random alignments with gaps, float
+    times that hit the floor-division quirk, and small batch sizes."""
+    from oracle import prominence as oracle
+    rng = np.random.default_rng(11)
+    for trial in range(300):
+        count = int(rng.integers(1, 60))
+        step = rng.choice([0.01, 0.013, 0.0803, 0.25])
+        lengths = rng.integers(1, 70, count) * step
+        gaps = rng.integers(0, 3, count) * step * (trial % 3 == 0)
+        starts = np.cumsum(lengths + gaps) - lengths
+        words = [(float(s), float(s + d)) for s, d in zip(starts, lengths)]
+        samples = int(words[-1][1] * 16000) + int(rng.integers(0, 400))
+        size = [None, 50, 200, 1000, 0][trial % 5]
+        want = [c for c in oracle.chunks(words, samples, size)
+                if not c['dropped']]
+        got = batch.chunk_utterance(list(words), samples, size)
+        assert len(got) == len(want), (trial, size)
+        for mine, theirs in zip(got, want):
+            assert (mine.start_word, mine.end_word, mine.start_sample) == (
+                theirs['start_word'], theirs['end_word'],
+                theirs['start_sample'])
+            assert mine.length == theirs['end_sample'] - theirs['start_sample']
+            assert np.array_equal(mine.bounds, theirs['bounds'])
+
+
 def test_float_floor_quirk():
     """convert.py:29-31 floor-divides in float64: 8.03 s is frame 802."""
     assert convert.seconds_to_frames(8.03) == 802.0
