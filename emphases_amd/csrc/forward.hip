@@ -1,0 +1,78 @@
+// The whole convolutional path behind one C call (SURVEY.md 8b's optional
+// `prominence_forward`): log-mel -> input conv -> encoder convs -> per-word
+// reduce -> word decoder -> scores, i.e. emphases/core.py:295-342 over
+// emphases/model/core.py:89-138 for the default configuration family
+// (ARCHITECTURE 'convolution', DOWNSAMPLE_LOCATION 'intermediate' /
+// 'inference' / 'loss', mel features, encoder kernel_size 3).
+//
+// Host code only: it enqueues the library's own kernels on `stream` in order,
+// allocates nothing and never synchronises, so it is hipGraph-capturable like
+// the entry points it calls.
+#include "common.h"
+
+using namespace emph;
+
+extern "C" {
+
+int64_t emph_prominence_workspace_floats(int32_t features, int32_t channels,
+                                         int64_t ld_frames, int64_t ld_words) {
+    return (static_cast<int64_t>(features) + 2 * channels) * ld_frames +
+           static_cast<int64_t>(channels) * ld_words;
+}
+
+int emph_prominence_forward(const emph_conv_model* model, const float* audio,
+                            const int64_t* seg, const int32_t* frontend_tiles,
+                            int32_t n_frontend_tiles, const int32_t* frame_tiles,
+                            int32_t n_frame_tiles, int32_t tile_n,
+                            const int32_t* word_tiles, int32_t n_word_tiles,
+                            const int32_t* bounds, const int32_t* word_segment,
+                            int64_t ld_frames, int64_t ld_words, float* workspace,
+                            float* logits, float* scores, void* stream) {
+    EMPH_REQUIRE(model != nullptr, EMPH_EINVAL, "emph_prominence_forward: model is null");
+    const emph_conv_model& m = *model;
+    EMPH_REQUIRE(audio && seg && workspace, EMPH_EINVAL,
+                 "emph_prominence_forward: null pointer");
+    EMPH_REQUIRE(m.features == kMels, EMPH_ERANGE,
+                 "emph_prominence_forward: %d feature rows (the fused path takes the 80 mel "
+                 "rows only)", m.features);
+    EMPH_REQUIRE(m.encoder_layers >= 0 && m.encoder_layers <= 16, EMPH_ERANGE,
+                 "emph_prominence_forward: %d encoder layers", m.encoder_layers);
+    EMPH_REQUIRE(emph_conv_winograd_lds_bytes(m.channels, m.channels) <= 160 * 1024 &&
+                     emph_conv_winograd_lds_bytes(m.channels, m.features) <= 160 * 1024,
+                 EMPH_ERANGE, "emph_prominence_forward: %d channels do not fit the Winograd "
+                 "kernel's LDS", m.channels);
+    const int c = m.channels;
+    float* features = workspace;
+    float* current = features + static_cast<int64_t>(m.features) * ld_frames;
+    float* other = current + static_cast<int64_t>(c) * ld_frames;
+    float* words = other + static_cast<int64_t>(c) * ld_frames;
+
+    int status = emph_logmel(audio, seg, frontend_tiles, n_frontend_tiles, m.table,
+                             m.mel_start, m.mel_count, m.mel_offset, m.mel_values, m.mel_nnz,
+                             features, ld_frames, 0, -1, nullptr, nullptr, m.normalize, stream);
+    if (status) return status;
+    status = emph_conv1d_winograd(features, ld_frames, current, ld_frames, m.input_pack,
+                                  m.input_bias, m.features, c, EMPH_ACT_NONE, frame_tiles,
+                                  n_frame_tiles, tile_n, stream);
+    if (status) return status;
+    const int64_t pack_floats = emph_conv_winograd_pack_size(c, c);
+    for (int layer = 0; layer < m.encoder_layers; ++layer) {
+        status = emph_conv1d_winograd(current, ld_frames, other, ld_frames,
+                                      m.encoder_packs + layer * pack_floats,
+                                      m.encoder_biases + static_cast<int64_t>(layer) * c, c, c,
+                                      m.activation, frame_tiles, n_frame_tiles, tile_n, stream);
+        if (status) return status;
+        float* swap = current;
+        current = other;
+        other = swap;
+    }
+    status = emph_segment_reduce(current, ld_frames, bounds, words, ld_words, c, seg,
+                                 word_segment, ld_words, m.reduction, stream);
+    if (status) return status;
+    return emph_word_decoder(words, ld_words, word_tiles, n_word_tiles, c, m.decoder_packs,
+                             m.decoder_biases, m.decoder_layers, m.decoder_kernel_size,
+                             m.activation, m.out_weight, m.out_bias, m.decoder_kernel_size,
+                             m.post, logits, scores, stream);
+}
+
+}  // extern "C"

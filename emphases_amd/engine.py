@@ -15,6 +15,7 @@ keeps its model on function attributes of `infer` (`core.py:298-315`); here the
 cache is an explicit object.
 """
 import contextlib
+import ctypes
 
 import numpy as np
 import torch
@@ -124,6 +125,47 @@ class Engine:
         if config.architecture == 'transformer':
             self.position = to(weights_module.positional_encoding(
                 cfg.MAX_POSITIONS, config.channels))
+        self.model = self._conv_model()
+
+    def _conv_model(self):
+        """`emph_conv_model` for emph_prominence_forward (the whole path in one
+        C call), or None when this configuration needs the step-by-step path:
+        Transformer, word pieces, extra feature rows, an encoder kernel other
+        than 3, or direct-form convs requested."""
+        config = self.config
+        layers = [self.input_layer] + (
+            self.frame_encoder if config.architecture == 'convolution' else [])
+        if config.architecture != 'convolution' or not self.winograd or \
+                config.downsample_location == 'input' or \
+                config.num_features != cfg.NUM_MELS or \
+                any(layer.winograd is None for layer in layers):
+            return None
+        encoder = self.frame_encoder
+        self._encoder_packs = torch.cat([l.winograd for l in encoder]) \
+            if encoder else torch.zeros(1, device=self.device)
+        self._encoder_biases = torch.cat([l.bias for l in encoder]) \
+            if encoder else torch.zeros(1, device=self.device)
+        pointer = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        return runtime.ConvModel(
+            channels=config.channels, features=config.num_features,
+            encoder_layers=len(encoder), decoder_layers=self.decoder_layers,
+            decoder_kernel_size=config.decoder_kernel_size,
+            activation=runtime.ACTIVATIONS[config.activation],
+            reduction=runtime.REDUCTIONS[config.downsample_method],
+            post=runtime.POSTPROCESS[config.loss],
+            normalize=int(config.normalize), mel_nnz=self.mel_nnz,
+            table=pointer(self.table), mel_start=pointer(self.mel_start),
+            mel_count=pointer(self.mel_count),
+            mel_offset=pointer(self.mel_offset),
+            mel_values=pointer(self.mel_values),
+            input_pack=pointer(self.input_layer.winograd),
+            input_bias=pointer(self.input_layer.bias),
+            encoder_packs=pointer(self._encoder_packs),
+            encoder_biases=pointer(self._encoder_biases),
+            decoder_packs=pointer(self.decoder_packs),
+            decoder_biases=pointer(self.decoder_biases),
+            out_weight=pointer(self.output_weight),
+            out_bias=pointer(self.output_bias))
 
     def _stack(self, prefix):
         config, state, dev = self.config, self.state, self.device
@@ -423,6 +465,31 @@ class Engine:
         channels = config.channels
         ld_f, ld_w = plan.ld_frames, plan.ld_words
         frames, words = runtime.AXIS_FRAMES, runtime.AXIS_WORDS
+        if self.model is not None and stages is None and features is None \
+                and self.timers is None and block in (32, 64) and \
+                len(plan.segments):
+            # the whole path behind one C call
+            check_bounds(plan, config.downsample_method)
+            logits = self._buffer('logits', ld_w)
+            scores = self._buffer('scores', ld_w)
+            floats = self.lib.emph_prominence_workspace_floats(
+                config.num_features, channels, ld_f, ld_w)
+            workspace = self._buffer('fused', int(floats))
+            frontend_tiles, frontend_size = meta[
+                ('tiles', frames, FRONTEND_BLOCK)]
+            frame_tiles, frame_size = meta[('tiles', frames, block)]
+            word_tiles, word_size = meta[('tiles', words, self.word_block)]
+            runtime.check(self.lib.emph_prominence_forward(
+                ctypes.byref(self.model), audio.data_ptr(),
+                meta['table'][0].data_ptr(), frontend_tiles.data_ptr(),
+                frontend_size // runtime.TILE_FIELDS, frame_tiles.data_ptr(),
+                frame_size // runtime.TILE_FIELDS, block,
+                word_tiles.data_ptr(), word_size // runtime.TILE_FIELDS,
+                meta['bounds'][0].data_ptr(),
+                meta['word_segment'][0].data_ptr(), ld_f, ld_w,
+                workspace.data_ptr(), logits.data_ptr(), scores.data_ptr(),
+                runtime.stream()), 'emph_prominence_forward')
+            return scores, logits
         if features is None:
             features = self.features(audio, plan, meta, extra_rows=extra_rows)
         table = meta['table'][0]

@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -56,6 +56,10 @@ SIGNATURES = {
     'emph_output_layer': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _i64, _i32, _i32,
         _ptr, _ptr, _ptr]),
+    'emph_prominence_workspace_floats': (_i64, [_i32, _i32, _i64, _i64]),
+    'emph_prominence_forward': (_c.c_int, [
+        _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _i32, _i32, _ptr, _i32, _ptr,
+        _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
     'emph_gather_columns': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _i32, _ptr, _i32, _ptr]),
     'emph_word_decoder_block': (_i32, [_i32, _i32, _i32]),
@@ -152,6 +156,17 @@ def frontend_table():
     check(lib.emph_frontend_table_fill(table.ctypes.data),
           'emph_frontend_table_fill')
     return table
+
+
+class ConvModel(_c.Structure):
+    """`emph_conv_model` of include/emphases_hip.h."""
+    _fields_ = [(name, _i32) for name in (
+        'channels', 'features', 'encoder_layers', 'decoder_layers',
+        'decoder_kernel_size', 'activation', 'reduction', 'post',
+        'normalize', 'mel_nnz')] + [(name, _ptr) for name in (
+            'table', 'mel_start', 'mel_count', 'mel_offset', 'mel_values',
+            'input_pack', 'input_bias', 'encoder_packs', 'encoder_biases',
+            'decoder_packs', 'decoder_biases', 'out_weight', 'out_bias')]
 
 
 def word_decoder_pack(weight):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 7
+#define EMPH_ABI_VERSION 8
 
 /* Segment-table fields */
 enum {
@@ -325,6 +325,61 @@ int emph_add_layernorm(const float* x, const float* r, float* y, int64_t ld,
                        int32_t channels, const float* gamma,
                        const float* beta, float eps, int64_t first_column,
                        int64_t columns, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* The whole convolutional path in one call                                  */
+/* ------------------------------------------------------------------------ */
+
+/* Device-side description of a convolutional model (every pointer is device
+ * memory prepared once per checkpoint). */
+typedef struct emph_conv_model {
+    int32_t channels;             /* multiple of 16, <= 128                    */
+    int32_t features;             /* input rows: the 80 mel rows               */
+    int32_t encoder_layers;       /* frame-rate layers after the input layer   */
+    int32_t decoder_layers;       /* word-rate layers (0: no decoder)          */
+    int32_t decoder_kernel_size;  /* also the output layer's kernel size       */
+    int32_t activation;           /* EMPH_ACT_*                                */
+    int32_t reduction;            /* EMPH_REDUCE_*                             */
+    int32_t post;                 /* EMPH_POST_*                               */
+    int32_t normalize;            /* emphases NORMALIZE                        */
+    int32_t mel_nnz;
+    const float* table;           /* emph_frontend_table_fill                  */
+    const int32_t* mel_start;
+    const int32_t* mel_count;
+    const int32_t* mel_offset;
+    const float* mel_values;
+    const float* input_pack;      /* emph_conv_winograd_pack [C][features][3]  */
+    const float* input_bias;      /* [C]                                       */
+    const float* encoder_packs;   /* encoder_layers Winograd packs [C][C][3]   */
+    const float* encoder_biases;  /* [encoder_layers][C]                       */
+    const float* decoder_packs;   /* emph_word_decoder_pack per layer          */
+    const float* decoder_biases;  /* [decoder_layers][C]                       */
+    const float* out_weight;      /* [1][C][decoder_kernel_size]               */
+    const float* out_bias;        /* [1]                                       */
+} emph_conv_model;
+
+/* Floats of scratch emph_prominence_forward needs (features, two activation
+ * buffers on the frame axis, the word embeddings). */
+int64_t emph_prominence_workspace_floats(int32_t features, int32_t channels,
+                                         int64_t ld_frames, int64_t ld_words);
+
+/* log-mel -> input conv -> encoder convs -> per-word reduce -> word decoder ->
+ * scores for a whole ragged batch: emphases.infer + emphases.postprocess
+ * (emphases/core.py:295-342) over emphases.Model.forward (emphases/model/
+ * core.py:89-138) of the convolutional configurations with encoder
+ * kernel_size 3 and mel features.  The tables are those of the individual
+ * entry points: `frontend_tiles` with 32-frame blocks, `frame_tiles` with
+ * block `tile_n` (32 or 64), `word_tiles` with block
+ * emph_word_decoder_block(...).  Enqueues on `stream`; allocates nothing. */
+int emph_prominence_forward(const emph_conv_model* model, const float* audio,
+                            const int64_t* seg, const int32_t* frontend_tiles,
+                            int32_t n_frontend_tiles,
+                            const int32_t* frame_tiles, int32_t n_frame_tiles,
+                            int32_t tile_n, const int32_t* word_tiles,
+                            int32_t n_word_tiles, const int32_t* bounds,
+                            const int32_t* word_segment, int64_t ld_frames,
+                            int64_t ld_words, float* workspace, float* logits,
+                            float* scores, void* stream);
 
 #ifdef __cplusplus
 }

@@ -304,6 +304,31 @@ def test_mixed_corpus_and_long_form(default_engine):
     assert np.abs(got.numpy() - want.numpy()).max() < SCORE_TOLERANCE
 
 
+def test_fused_forward_equals_step_by_step(cases, default_engine):
+    """emph_prominence_forward (one C call) against the same kernels enqueued
+    one by one from Python (the path taken when per-kernel timers or stage
+    dumps are requested): identical bits."""
+    audio, bounds, _ = case_inputs(cases, 'utt_10s')
+    assert default_engine.model is not None
+    plan, fused, fused_logits = run_case(default_engine, audio, bounds, None)
+    fused, fused_logits = fused.clone(), fused_logits.clone()
+    default_engine.timers = []
+    try:
+        _, stepped, stepped_logits = run_case(
+            default_engine, audio, bounds, None)
+    finally:
+        names = {name for name, *_ in default_engine.timers}
+        default_engine.timers = None
+    assert 'word_decoder' in names and 'segment_reduce' in names
+    columns = plan.word_columns()
+    assert torch.equal(fused[columns], stepped[columns])
+    assert torch.equal(fused_logits[columns], stepped_logits[columns])
+    library = runtime.library()
+    assert library.emph_prominence_forward(
+        None, 0, 0, None, 0, None, 0, 32, None, 0, None, None, 0, 0, 0, None,
+        None, None) == -1
+
+
 def test_many_words_per_segment(default_engine):
     """Segments far longer than the 64-word window of the fused word stage
     (halo recompute across word tiles), incl. 1-frame words."""
