@@ -199,40 +199,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         request(min(key0 + 16, length - 1));
         __builtin_amdgcn_sched_barrier(0);
 
+        // Three phases over the four query tiles rather than tile by tile: the
+        // ten QK^T MFMAs of a tile form a dependent chain, so the four chains
+        // are issued interleaved; the softmax of all tiles then runs under the
+        // tail of those MFMAs, and the PV products follow back to back.
+        f32x4 s4[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) s4[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+                s4[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[s], bq[t][s], s4[t], 0, 0, 0);
+        float alpha[QT];
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s)
-                s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(ak[s], bq[t][s], s4, 0, 0, 0);
-            // s4[r] = score(key0 + 4*kk + r, query col)
+            // s4[t][r] = score(key0 + 4*kk + r, query col)
             float local = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                if (kMasked && key0 + 4 * kk + r >= length) s4[r] = -INFINITY;
-                local = fmaxf(local, s4[r]);
+                if (kMasked && key0 + 4 * kk + r >= length) s4[t][r] = -INFINITY;
+                local = fmaxf(local, s4[t][r]);
             }
             local = rows_max(local);
             const float new_max = fmaxf(row_max[t], local);
-            const float alpha = __builtin_amdgcn_exp2f(row_max[t] - new_max);
+            alpha[t] = __builtin_amdgcn_exp2f(row_max[t] - new_max);
             float partial = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s4[r] = __builtin_amdgcn_exp2f(s4[r] - new_max);
-                partial += s4[r];
+                s4[t][r] = __builtin_amdgcn_exp2f(s4[t][r] - new_max);
+                partial += s4[t][r];
             }
             partial = rows_sum(partial);
-            row_sum[t] = row_sum[t] * alpha + partial;
+            row_sum[t] = row_sum[t] * alpha[t] + partial;
             row_max[t] = new_max;
+        }
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                o[t][m] *= alpha;
+                o[t][m] *= alpha[t];
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     o[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                        av[r][m], s4[r], o[t][m], 0, 0, 0);
+                        av[r][m], s4[t][r], o[t][m], 0, 0, 0);
             }
-        }
     };
     const int full = length & ~15;
     for (int key0 = 0; key0 < full; key0 += 16) block(key0, std::false_type{});
