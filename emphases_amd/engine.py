@@ -183,7 +183,28 @@ class Engine:
             p = f'{prefix}.model.layers.{i}.'
             in_w = state[p + 'self_attn.in_proj_weight']
             in_b = state[p + 'self_attn.in_proj_bias']
+            block = None
+            square = (channels, channels)
+            if channels in (64, 80) and all(
+                    tuple(state[p + name].shape) == square for name in (
+                        'self_attn.out_proj.weight', 'linear1.weight',
+                        'linear2.weight')):
+                # the position-wise half of the layer as one launch
+                block = (
+                    to(np.concatenate([
+                        runtime.linear_chain_pack(
+                            state[p + 'self_attn.out_proj.weight'], True),
+                        runtime.linear_chain_pack(
+                            state[p + 'linear1.weight'], False),
+                        runtime.linear_chain_pack(
+                            state[p + 'linear2.weight'], False)])),
+                    to(np.concatenate([
+                        state[p + name].astype(np.float32) for name in (
+                            'self_attn.out_proj.bias', 'norm1.weight',
+                            'norm1.bias', 'linear1.bias', 'linear2.bias',
+                            'norm2.weight', 'norm2.bias')])))
             layers.append(dict(
+                block=block,
                 qk=_Conv(in_w[:2 * channels], in_b[:2 * channels], dev),
                 v=_Conv(in_w[2 * channels:], in_b[2 * channels:], dev),
                 out=_Conv(state[p + 'self_attn.out_proj.weight'],
@@ -423,6 +444,18 @@ class Engine:
                     qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld,
                     channels, config.heads, att_tiles.data_ptr(), att_count,
                     runtime.stream()), 'emph_attention')
+            if layer['block'] is not None and block <= 32:
+                packs, vectors = layer['block']
+                tiles, size = meta[('tiles', axis, block)]
+                with self._timed('transformer_block', 6. * channels *
+                                 channels * meta['positions'][axis]):
+                    runtime.check(self.lib.emph_transformer_block(
+                        attended.data_ptr(), x.data_ptr(), ld, channels,
+                        packs.data_ptr(), vectors.data_ptr(),
+                        config.layer_norm_eps, runtime.ACTIVATIONS['relu'],
+                        tiles.data_ptr(), size // runtime.TILE_FIELDS, block,
+                        runtime.stream()), 'emph_transformer_block')
+                continue
             self._conv(layer['out'], attended, ld, projected, ld, meta, axis,
                        block, None)
             add_layernorm(layer['norm1'])

@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -56,6 +56,11 @@ SIGNATURES = {
     'emph_output_layer': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _ptr, _i64, _i32, _i32,
         _ptr, _ptr, _ptr]),
+    'emph_linear_chain_pack_size': (_i64, [_i32]),
+    'emph_linear_chain_pack': (_c.c_int, [_ptr, _i32, _i32, _ptr]),
+    'emph_transformer_block': (_c.c_int, [
+        _ptr, _ptr, _i64, _i32, _ptr, _ptr, _c.c_float, _i32, _ptr, _i32,
+        _i32, _ptr]),
     'emph_prominence_workspace_floats': (_i64, [_i32, _i32, _i64, _i64]),
     'emph_prominence_forward': (_c.c_int, [
         _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _i32, _i32, _ptr, _i32, _ptr,
@@ -156,6 +161,20 @@ def frontend_table():
     check(lib.emph_frontend_table_fill(table.ctypes.data),
           'emph_frontend_table_fill')
     return table
+
+
+def linear_chain_pack(weight, natural):
+    """emph_transformer_block's layout of a square Linear weight [C, C]."""
+    lib = library()
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    channels = weight.shape[0]
+    assert weight.shape == (channels, channels)
+    pack = np.zeros(lib.emph_linear_chain_pack_size(channels),
+                    dtype=np.float32)
+    check(lib.emph_linear_chain_pack(
+        weight.ctypes.data, channels, int(natural), pack.ctypes.data),
+        'emph_linear_chain_pack')
+    return pack
 
 
 class ConvModel(_c.Structure):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 8
+#define EMPH_ABI_VERSION 9
 
 /* Segment-table fields */
 enum {
@@ -325,6 +325,29 @@ int emph_add_layernorm(const float* x, const float* r, float* y, int64_t ld,
                        int32_t channels, const float* gamma,
                        const float* beta, float eps, int64_t first_column,
                        int64_t columns, void* stream);
+
+/* The position-wise half of a post-LN Transformer encoder layer in one launch
+ * (nn.TransformerEncoderLayer, emphases/model/layers/transformer.py:18-23):
+ *     y = LayerNorm1(x + W_o attended + b_o)
+ *     x <- LayerNorm2(y + W_2 act(W_1 y + b_1) + b_2)
+ * for square layers (dim_feedforward == channels, as the reference builds them:
+ * transformer.py:20) of 64 or 80 channels (the three packs share the LDS); the
+ * three GEMMs chain through registers.
+ *   attended float32 [channels, ld]  output of emph_attention
+ *   x        float32 [channels, ld]  residual stream, updated in place
+ *   packs    three emph_linear_chain_pack images back to back: out_proj
+ *            (natural = 1), linear1 (natural = 0), linear2 (natural = 0)
+ *   vectors  float32 [7][channels]: b_o, gamma1, beta1, b_1, b_2, gamma2, beta2
+ *   activation  EMPH_ACT_RELU or EMPH_ACT_NONE
+ *   tiles    tile table of the walked axis, block = tile_n (16 or 32) */
+int64_t emph_linear_chain_pack_size(int32_t channels);
+int emph_linear_chain_pack(const float* host_weight, int32_t channels,
+                           int32_t natural, float* host_pack);
+int emph_transformer_block(const float* attended, float* x, int64_t ld,
+                           int32_t channels, const float* packs,
+                           const float* vectors, float eps, int32_t activation,
+                           const int32_t* tiles, int32_t n_tiles,
+                           int32_t tile_n, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* The whole convolutional path in one call                                  */

@@ -412,3 +412,52 @@ def test_add_layernorm_and_position():
         want = x[:, off:off + count] + table[:count].T
         assert float((z[:, off:off + count] - want).abs().max()) == 0.0
     assert torch.equal(z[:, :batch.LEAD], x[:, :batch.LEAD])
+
+
+###############################################################################
+# fused position-wise half of a Transformer layer
+###############################################################################
+
+
+@pytest.mark.parametrize('channels,tile', [(80, 32), (80, 16), (64, 32),
+                                           (64, 16)])
+def test_transformer_block(channels, tile):
+    lib = runtime.library()
+    plan = ragged_plan([200, 1, 17, 33, 64])
+    axis = runtime.AXIS_FRAMES
+    meta = Meta(plan, [(axis, tile)])
+    x = random_packed(channels, plan, axis, 21)
+    attended = random_packed(channels, plan, axis, 22)
+    x[:, :batch.LEAD] = float('nan')
+    names = ['out', 'l1', 'l2']
+    weight = {n: torch.from_numpy(synth.weights(30 + i, (channels, channels), 0.3))
+              for i, n in enumerate(names)}
+    vector = {n: torch.from_numpy(synth.weights(40 + i, (channels,), 0.5))
+              for i, n in enumerate(
+                  ['b_o', 'g1', 'be1', 'b_1', 'b_2', 'g2', 'be2'])}
+    vector['g1'] += 1.
+    vector['g2'] += 1.
+    packs = torch.from_numpy(np.concatenate([
+        runtime.linear_chain_pack(weight['out'].numpy(), True),
+        runtime.linear_chain_pack(weight['l1'].numpy(), False),
+        runtime.linear_chain_pack(weight['l2'].numpy(), False)])).to(DEVICE)
+    vectors = torch.cat([vector[n] for n in (
+        'b_o', 'g1', 'be1', 'b_1', 'b_2', 'g2', 'be2')]).to(DEVICE)
+    x_dev, attended_dev = x.to(DEVICE), attended.to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    runtime.check(lib.emph_transformer_block(
+        attended_dev.data_ptr(), x_dev.data_ptr(), plan.ld_frames, channels,
+        packs.data_ptr(), vectors.data_ptr(), 1e-5, 1, tiles.data_ptr(),
+        size // 4, tile, None), 'emph_transformer_block')
+    got = x_dev.cpu()
+    norm = torch.nn.functional.layer_norm
+    for off, count in spans(plan, axis):
+        xs = x[:, off:off + count].T
+        a = attended[:, off:off + count].T
+        y = norm(xs + a @ weight['out'].T + vector['b_o'], (channels,),
+                 vector['g1'], vector['be1'], 1e-5)
+        h = torch.relu(y @ weight['l1'].T + vector['b_1'])
+        want = norm(y + h @ weight['l2'].T + vector['b_2'], (channels,),
+                    vector['g2'], vector['be2'], 1e-5).T
+        assert float((got[:, off:off + count] - want).abs().max()) < 5e-5
+    assert torch.isnan(got[:, :batch.LEAD]).all()   # padding untouched

@@ -387,6 +387,16 @@ def test_winograd_and_decoder_packs():
                                   (2, 1, 37, 1, 1)]:
         assert packed[trip, m, lane, t, tap] == square[
             16 * m + (lane & 15), 16 * trip + 4 * t + (lane >> 4), tap]
+    linear = synth.weights(12, (80, 80), 1.0)
+    natural = runtime.linear_chain_pack(linear, True).reshape(20, 5, 64)
+    chained = runtime.linear_chain_pack(linear, False).reshape(20, 5, 64)
+    for step, m, lane in [(0, 0, 0), (19, 4, 63), (7, 2, 21)]:
+        row, k = 16 * m + (lane & 15), lane >> 4
+        assert natural[step, m, lane] == linear[row, 4 * step + k]
+        # k-step 4 m' + r multiplies the channels an accumulator register r of
+        # m-tile m' holds: 16 m' + 4 k + r
+        assert chained[step, m, lane] == linear[
+            row, 16 * (step >> 2) + 4 * k + (step & 3)]
     assert library.emph_word_decoder_pack(None, 80, 3, None) == -1
     scratch = np.zeros(8, dtype=np.float32)
     assert library.emph_word_decoder_pack(
