@@ -203,6 +203,103 @@ __global__ __launch_bounds__(512) void transformer_block_kernel(
     }
 }
 
+// Q, K and V projections of self-attention (in_proj of nn.MultiheadAttention,
+// transformer.py:18-23) in one launch: x is read once as B fragments, Q and K
+// are written channel-major for emph_attention's S^T = K Q^T, V position-major
+// (a lane's accumulator register is four consecutive channels of one position:
+// one 16-byte store).  As three kernel_size-1 convs this was 65 us per layer on
+// 64 x 10 s.
+template <int MB, int NB>
+__global__ __launch_bounds__(512) void qkv_kernel(
+    const float* __restrict__ x, int64_t ld, float* __restrict__ qk, float* __restrict__ v,
+    const float* __restrict__ packs /* q | k | v, natural order */,
+    const float* __restrict__ bias /* [3][C] */, const int32_t* __restrict__ tiles,
+    int n_tiles) {
+    constexpr int C = 16 * MB;
+    constexpr int STEPS = 4 * MB;
+    constexpr int PACK = STEPS * MB * 64;
+    extern __shared__ __align__(16) float lds[];
+    float* vec = lds + 3 * PACK;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kk = lane >> 4;
+    const int col = lane & 15;
+    for (int base = wave * 64; base < 3 * PACK / 4; base += 512)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(packs + 4 * (base + lane)),
+            (__attribute__((address_space(3))) void*)(lds + 4 * base), 16, 0, 0);
+    for (int index = threadIdx.x; index < 3 * C; index += 512) vec[index] = bias[index];
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+
+    for (int tile = blockIdx.x * 8 + wave; tile < n_tiles; tile += gridDim.x * 8) {
+        const Tile span = load_tile(tiles, tile);
+        const int t0 = span.first;
+        bool live[NB];
+        int64_t column[NB];
+        uint32_t lane_offset[NB], operand_offset[NB];
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+            live[n] = t0 + 16 * n + col < span.count;
+            column[n] = span.offset + min(t0 + 16 * n + col, span.count - 1);
+            lane_offset[n] = static_cast<uint32_t>(4 * kk * ld + column[n]);
+            operand_offset[n] = static_cast<uint32_t>(kk * ld + column[n]);
+        }
+        float b0[STEPS][NB];
+#pragma unroll
+        for (int g = 0; g < STEPS; ++g)
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+                b0[g][n] = (x + static_cast<int64_t>(4 * g) * ld)[operand_offset[n]];
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+            f32x4 acc[MB][NB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const f32x4 add =
+                    *reinterpret_cast<const f32x4*>(vec + part * C + 16 * m + 4 * kk);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[m][n] = add;
+            }
+            const float* pack = lds + part * PACK;
+            float a[2][MB];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) a[0][m] = pack[(m << 6) + lane];
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < STEPS) {
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+                        a[(s + 1) & 1][m] = pack[(((s + 1) * MB + m) << 6) + lane];
+                }
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            a[s & 1][m], b0[s][n], acc[m][n], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int n = 0; n < NB; ++n) {
+                    if (!live[n]) continue;
+                    if (part < 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            (qk + static_cast<int64_t>(part * C + 16 * m + r) *
+                                      ld)[lane_offset[n]] = acc[m][n][r];
+                    } else {
+                        *reinterpret_cast<f32x4*>(v + column[n] * C + 16 * m + 4 * kk) =
+                            acc[m][n];
+                    }
+                }
+        }
+    }
+}
+
 }  // namespace emph
 
 using namespace emph;
@@ -279,6 +376,49 @@ int emph_transformer_block(const float* attended, float* x, int64_t ld, int32_t 
     }
 #undef EMPH_BLOCK
     return check_launch("emph_transformer_block");
+}
+
+int emph_qkv_projection(const float* x, int64_t ld, float* qk, float* v, int32_t channels,
+                        const float* packs, const float* bias, const int32_t* tiles,
+                        int32_t n_tiles, int32_t tile_n, void* stream) {
+    if (n_tiles == 0) return EMPH_OK;
+    EMPH_REQUIRE(x && qk && v && packs && bias && tiles, EMPH_EINVAL,
+                 "emph_qkv_projection: null pointer");
+    EMPH_REQUIRE(channels == 64 || channels == 80, EMPH_ERANGE,
+                 "emph_qkv_projection: channels %d not in {64, 80}", channels);
+    EMPH_REQUIRE(tile_n == 16 || tile_n == 32, EMPH_ERANGE,
+                 "emph_qkv_projection: tile_n %d not in {16, 32}", tile_n);
+    EMPH_REQUIRE((reinterpret_cast<uintptr_t>(v) & 15) == 0, EMPH_EINVAL,
+                 "emph_qkv_projection: v must be 16-byte aligned");
+    const size_t lds = (3 * static_cast<size_t>(channels) * channels + 3 * channels) *
+                       sizeof(float);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int groups = (n_tiles + 7) / 8;
+    dim3 grid(groups < 256 ? groups : 256);
+#define EMPH_QKV(MB, NB)                                                                \
+    do {                                                                                \
+        auto kernel = qkv_kernel<MB, NB>;                                               \
+        static size_t reserved = 64 * 1024;                                             \
+        if (lds > reserved) {                                                           \
+            hipError_t status = hipFuncSetAttribute(                                    \
+                reinterpret_cast<const void*>(kernel),                                  \
+                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));     \
+            if (status != hipSuccess) {                                                 \
+                set_error("emph_qkv_projection: cannot reserve %zu bytes of LDS", lds); \
+                return static_cast<int>(status);                                        \
+            }                                                                           \
+            reserved = lds;                                                             \
+        }                                                                               \
+        hipLaunchKernelGGL(kernel, grid, dim3(512), lds, s, x, ld, qk, v, packs, bias,  \
+                           tiles, n_tiles);                                             \
+    } while (0)
+    if (channels == 80) {
+        if (tile_n == 32) EMPH_QKV(5, 2); else EMPH_QKV(5, 1);
+    } else {
+        if (tile_n == 32) EMPH_QKV(4, 2); else EMPH_QKV(4, 1);
+    }
+#undef EMPH_QKV
+    return check_launch("emph_qkv_projection");
 }
 
 }  // extern "C"

@@ -203,8 +203,14 @@ class Engine:
                             'self_attn.out_proj.bias', 'norm1.weight',
                             'norm1.bias', 'linear1.bias', 'linear2.bias',
                             'norm2.weight', 'norm2.bias')])))
+            qkv = None
+            if channels in (64, 80):
+                qkv = (to(np.concatenate([
+                    runtime.linear_chain_pack(
+                        in_w[part * channels:(part + 1) * channels], True)
+                    for part in range(3)])), to(in_b.astype(np.float32)))
             layers.append(dict(
-                block=block,
+                block=block, qkv=qkv,
                 qk=_Conv(in_w[:2 * channels], in_b[:2 * channels], dev),
                 v=_Conv(in_w[2 * channels:], in_b[2 * channels:], dev),
                 out=_Conv(state[p + 'self_attn.out_proj.weight'],
@@ -436,9 +442,21 @@ class Engine:
                     'emph_add_layernorm')
 
         for layer in layers:
-            self._conv(layer['qk'], x, ld, qk, ld, meta, axis, block, None)
-            self._conv(layer['v'], x, ld, v, channels, meta, axis, block, None,
-                       transpose_out=True)
+            if layer['qkv'] is not None and block <= 32:
+                packs, bias = layer['qkv']
+                tiles, size = meta[('tiles', axis, block)]
+                with self._timed('qkv_projection', 6. * channels * channels *
+                                 meta['positions'][axis]):
+                    runtime.check(self.lib.emph_qkv_projection(
+                        x.data_ptr(), ld, qk.data_ptr(), v.data_ptr(),
+                        channels, packs.data_ptr(), bias.data_ptr(),
+                        tiles.data_ptr(), size // runtime.TILE_FIELDS, block,
+                        runtime.stream()), 'emph_qkv_projection')
+            else:
+                self._conv(layer['qk'], x, ld, qk, ld, meta, axis, block,
+                           None)
+                self._conv(layer['v'], x, ld, v, channels, meta, axis, block,
+                           None, transpose_out=True)
             with self._timed('attention', attention_flops):
                 runtime.check(self.lib.emph_attention(
                     qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld,

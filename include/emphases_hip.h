@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 9
+#define EMPH_ABI_VERSION 10
 
 /* Segment-table fields */
 enum {
@@ -348,6 +348,16 @@ int emph_transformer_block(const float* attended, float* x, int64_t ld,
                            const float* vectors, float eps, int32_t activation,
                            const int32_t* tiles, int32_t n_tiles,
                            int32_t tile_n, void* stream);
+
+/* Q, K, V projections of self-attention in one launch (in_proj of
+ * nn.MultiheadAttention, transformer.py:18-23) in the layouts emph_attention
+ * takes: qk float32 [2*channels, ld] (rows 0..c-1 = Q), v float32 [ld, channels]
+ * position-major.  packs = three emph_linear_chain_pack(natural = 1) images
+ * (W_q, W_k, W_v), bias float32 [3][channels]; channels 64 or 80; tile_n 16/32. */
+int emph_qkv_projection(const float* x, int64_t ld, float* qk, float* v,
+                        int32_t channels, const float* packs,
+                        const float* bias, const int32_t* tiles,
+                        int32_t n_tiles, int32_t tile_n, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* The whole convolutional path in one call                                  */

@@ -461,3 +461,35 @@ def test_transformer_block(channels, tile):
                     vector['g2'], vector['be2'], 1e-5).T
         assert float((got[:, off:off + count] - want).abs().max()) < 5e-5
     assert torch.isnan(got[:, :batch.LEAD]).all()   # padding untouched
+
+
+@pytest.mark.parametrize('channels,tile', [(80, 32), (64, 16)])
+def test_qkv_projection(channels, tile):
+    lib = runtime.library()
+    plan = ragged_plan([200, 1, 17, 33])
+    axis = runtime.AXIS_FRAMES
+    meta = Meta(plan, [(axis, tile)])
+    x = random_packed(channels, plan, axis, 5)
+    weight = torch.from_numpy(synth.weights(6, (3 * channels, channels), 0.3))
+    bias = torch.from_numpy(synth.weights(7, (3 * channels,), 0.5))
+    packs = torch.from_numpy(np.concatenate([
+        runtime.linear_chain_pack(
+            weight[part * channels:(part + 1) * channels].numpy(), True)
+        for part in range(3)])).to(DEVICE)
+    qk = torch.full((2 * channels, plan.ld_frames), 7.0, device=DEVICE)
+    v = torch.full((plan.ld_frames, channels), 7.0, device=DEVICE)
+    x_dev, bias_dev = x.to(DEVICE), bias.to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    runtime.check(lib.emph_qkv_projection(
+        x_dev.data_ptr(), plan.ld_frames, qk.data_ptr(), v.data_ptr(),
+        channels, packs.data_ptr(), bias_dev.data_ptr(), tiles.data_ptr(),
+        size // 4, tile, None), 'emph_qkv_projection')
+    qk, v = qk.cpu(), v.cpu()
+    for off, count in spans(plan, axis):
+        want = weight @ x[:, off:off + count] + bias[:, None]
+        assert float((qk[:, off:off + count] -
+                      want[:2 * channels]).abs().max()) < 2e-5
+        assert float((v[off:off + count].T -
+                      want[2 * channels:]).abs().max()) < 2e-5
+    assert float(qk[:, :batch.LEAD].min()) == 7.0
+    assert float(v[:batch.LEAD].min()) == 7.0
