@@ -237,13 +237,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int t = 0; t < QT; ++t)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                o[t][m] *= alpha[t];
+            for (int m = 0; m < MT; ++m) o[t][m] *= alpha[t];
+        // key sub-step outermost: consecutive MFMAs then write twelve different
+        // accumulators instead of the same one four times in a row
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < QT; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
                     o[t][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                         av[r][m], s4[t][r], o[t][m], 0, 0, 0);
-            }
     };
     const int full = length & ~15;
     for (int key0 = 0; key0 < full; key0 += 16) block(key0, std::false_type{});
