@@ -329,6 +329,39 @@ def test_fused_forward_equals_step_by_step(cases, default_engine):
         None, None) == -1
 
 
+def test_graph_replay_equals_eager(default_engine):
+    """Engine.capture (what bench.py replays): same bits as the eager launch
+    sequence, and a replay picks up audio written into the captured buffer."""
+    frames = [400, 1000, 130]
+    audios = [synth.audio(200 + i, n) for i, n in enumerate(frames)]
+    aligns = [emphases_amd.Alignment.from_frames(synth.word_frames(200 + i, n))
+              for i, n in enumerate(frames)]
+    lengths = [a.shape[1] for a in audios]
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64)
+    segments = []
+    for index, (words, length) in enumerate(zip(aligns, lengths)):
+        segments.extend(batch.chunk_utterance(words, length, None, index))
+    plan = batch.Plan(segments, offsets, lengths)
+    packed = torch.cat([torch.from_numpy(a).reshape(-1) for a in audios]).to(
+        default_engine.device)
+    meta = default_engine.upload(plan)
+    columns = plan.word_columns()
+    eager = default_engine.forward(packed, plan, meta)[0][columns].clone()
+    replay, scores, _ = default_engine.capture(packed, plan, meta)
+    replay()
+    torch.cuda.synchronize()
+    assert torch.equal(scores[columns], eager)
+    # new audio in the same buffer, same plan
+    other = torch.cat([torch.from_numpy(synth.audio(300 + i, n)).reshape(-1)
+                       for i, n in enumerate(frames)]).to(packed.device)
+    want = default_engine.forward(other, plan, meta)[0][columns].clone()
+    assert not torch.equal(want, eager)
+    packed.copy_(other)
+    replay()
+    torch.cuda.synchronize()
+    assert torch.equal(scores[columns], want)
+
+
 def test_many_words_per_segment(default_engine):
     """Segments far longer than the 64-word window of the fused word stage
     (halo recompute across word tiles), incl. 1-frame words."""
