@@ -657,7 +657,9 @@ class Engine:
                 self.forward(audio, plan, meta)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread-local capture: the RCCL watchdog thread of a multi-GPU run may
+        # query events while this thread captures
+        with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             scores, logits = self.forward(audio, plan, meta)
         return graph.replay, scores, logits
 
