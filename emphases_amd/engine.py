@@ -253,14 +253,15 @@ class Engine:
                 best = (trips * cost[tile], tile)
         return best[1]
 
-    def upload(self, plan, tile=None):
-        """One H2D copy of all integer metadata; returns device views."""
+    def upload(self, plan, tile=None, nested=False):
+        """One H2D copy of all integer metadata; returns device views.
+        (`nested`: the layout of the word pieces of another plan.)"""
         tile = tile or self.frame_tile(plan)
         requests = [
             (runtime.AXIS_FRAMES, FRONTEND_BLOCK),
             (runtime.AXIS_FRAMES, tile),
             (runtime.AXIS_WORDS, self.word_block)]
-        if self.config.architecture == 'transformer':
+        if self.config.architecture == 'transformer' and not nested:
             requests += [(runtime.AXIS_FRAMES, ATTENTION_BLOCK),
                          (runtime.AXIS_WORDS, ATTENTION_BLOCK)]
         requests = list(dict.fromkeys(requests))
@@ -273,12 +274,12 @@ class Engine:
                  'positions': (plan.total_frames, plan.total_words)}
         for name, (start, size) in offsets.items():
             views[name] = (device_buffer[start:start + size], size)
-        if self.config.downsample_location == 'input' and len(plan.segments):
+        if self.config.downsample_location == 'input' and not nested and \
+                len(plan.segments):
             # every word is its own padded sequence: a second packed layout
             pieces = plan.pieces(self.config.downsample_method)
-            nested = Engine.upload(
-                _PiecesView(self), pieces.plan,
-                self.frame_tile(pieces.plan))
+            piece_meta = self.upload(
+                pieces.plan, self.frame_tile(pieces.plan), nested=True)
             extra = torch.from_numpy(np.concatenate([
                 pieces.gather.view(np.int32).ravel(),
                 pieces.bounds.ravel(), pieces.word_piece]))
@@ -286,12 +287,12 @@ class Engine:
                 extra = extra.pin_memory()
             extra = extra.to(self.device, non_blocking=True)
             cut = pieces.gather.size * 2
-            nested['gather'] = extra[:cut]
-            nested['piece_bounds'] = extra[cut:cut + pieces.bounds.size]
-            nested['word_piece'] = extra[cut + pieces.bounds.size:]
-            nested['plan'] = pieces.plan
-            nested['_extra'] = extra
-            views['pieces'] = nested
+            piece_meta['gather'] = extra[:cut]
+            piece_meta['piece_bounds'] = extra[cut:cut + pieces.bounds.size]
+            piece_meta['word_piece'] = extra[cut + pieces.bounds.size:]
+            piece_meta['plan'] = pieces.plan
+            piece_meta['_extra'] = extra
+            views['pieces'] = piece_meta
         return views
 
     ###########################################################################
@@ -662,17 +663,6 @@ class Engine:
         with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             scores, logits = self.forward(audio, plan, meta)
         return graph.replay, scores, logits
-
-
-class _PiecesView:
-    """The parts of an Engine that `upload` needs, for the nested layout of
-    the word pieces (frame-axis tiles only; a plain convolutional config)."""
-
-    def __init__(self, engine):
-        self.device = engine.device
-        self.word_block = engine.word_block
-        self.frame_tile = engine.frame_tile
-        self.config = cfg.DEFAULT
 
 
 def check_bounds(plan, method):
