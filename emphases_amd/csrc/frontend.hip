@@ -45,7 +45,19 @@ constexpr float kLn2 = 0.69314718055994530942f;
 constexpr int kBlockFrames = 32;                               // frames per workgroup
 constexpr int kStage = kHop * (kBlockFrames - 1) + kFft;       // 5984 samples
 constexpr int kExRow = 72;                                     // complex per exchange row
-constexpr int kExFloats = 2 * 8 * kExRow;                      // 1152 floats per wave
+// Second exchange, C[r][t][p0] at r * kExRowB + t * kExStepB + p0: written by
+// lane (r, p0) for each t and read by lane (r, t) for each p0, 8 bytes each.
+// 2 * 88 = 48 (mod 64) puts the four r of a 32-lane group 16 banks apart and the
+// odd step 9 spreads t (or p0) over those 16: both directions are conflict free
+// (with rows of 8 the reads were 4-way conflicts: SQ_LDS_BANK_CONFLICT was 42 %
+// of the LDS-active cycles of this kernel).
+constexpr int kExRowB = 88;
+constexpr int kExStepB = 9;
+constexpr int kExFloats = 2 * 8 * kExRowB;                     // 1408 floats per wave
+// natural-order spectrum: 4 complex of padding after every 32 so that the
+// stride-8 writes of the last pass (lanes t and t + 4 used to collide) and the
+// contiguous reads of the real-FFT split are both conflict free
+__device__ __forceinline__ int spectrum_slot(int k) { return k + 4 * (k >> 5); }
 constexpr int kOutStride = kBlockFrames + 1;
 constexpr int kMagFloats = 560;      // 513 magnitudes per wave + zero tail for the runs
 constexpr int kRunA = 20;    // longest run of bins among filterbank rows 0..63
@@ -327,19 +339,19 @@ __global__ __launch_bounds__(256) void frontend_kernel(
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             if (t) v[t] = cmul(v[t], tw2[t]);
-            ex[r1 * kExRow + t * 8 + p0] = v[t];     // [r][t][p0]
+            ex[r1 * kExRowB + t * kExStepB + p0] = v[t];     // C[r][t][p0]
         }
         wave_lds_fence();
 
         if (local == wave) EMPH_STAMP(4);
         // pass 3: lane (r, t) takes C[r][p0][t], radix-8 over p0
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = ex[r1 * kExRow + p0 * 8 + q];
+        for (int q = 0; q < 8; ++q) v[q] = ex[r1 * kExRowB + p0 * kExStepB + q];
         wave_lds_fence();
         dft8(v);
         // Z[r + 8 t + 64 u] = v[u]; natural-order spectrum into LDS
 #pragma unroll
-        for (int u = 0; u < 8; ++u) ex[r1 + 8 * p0 + 64 * u] = v[u];
+        for (int u = 0; u < 8; ++u) ex[spectrum_slot(r1 + 8 * p0 + 64 * u)] = v[u];
         wave_lds_fence();
 
         if (local == wave) EMPH_STAMP(5);
@@ -348,8 +360,8 @@ __global__ __launch_bounds__(256) void frontend_kernel(
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = lane + 64 * j;
-            const cf zk = ex[k];
-            const cf zm = ex[(512 - k) & 511];
+            const cf zk = ex[spectrum_slot(k)];
+            const cf zm = ex[spectrum_slot((512 - k) & 511)];
             // X[k] = (E + W^k O) / 2 with E = zk + conj(zm), O = -i (zk -
             // conj(zm)): the -i rides on the twiddle table, the halves on the
             // power
