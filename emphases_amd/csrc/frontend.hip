@@ -60,8 +60,14 @@ constexpr int kExFloats = 2 * 8 * kExRowB;                     // 1408 floats pe
 __device__ __forceinline__ int spectrum_slot(int k) { return k + 4 * (k >> 5); }
 constexpr int kOutStride = kBlockFrames + 1;
 constexpr int kMagFloats = 560;      // 513 magnitudes per wave + zero tail for the runs
-constexpr int kRunA = 20;    // longest run of bins among filterbank rows 0..63
-constexpr int kRunB = 10;    // a quarter of the longest run among rows 64..79
+// Filterbank runs are read from LDS as 16-byte pieces from a start rounded down
+// to a multiple of four bins: rows 0..63 (at most 20 bins + 3 of alignment) as
+// six pieces by one lane each, rows 64..79 (at most 40 + 3) as three pieces by
+// each of four lanes.  (Dword reads from per-lane starts cost twice the LDS
+// cycles per byte and collide on banks: 30 % of this kernel's LDS-active
+// cycles were still bank conflicts after the exchange layouts were fixed.)
+constexpr int kRunA = 24;
+constexpr int kRunB = 12;
 
 // Table layout (floats)
 constexpr int kTabWindow = 0;                  // [1024]
@@ -215,20 +221,28 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     float weight_a[kRunA], weight_b[kRunB];
     int start_a = 0, start_b = 0;
     if (kMel) {
-        start_a = mel_start[lane];
+        const int first_a = mel_start[lane];
         const int count_a = mel_count[lane];
         const int offset_a = mel_offset[lane];
+        start_a = first_a & ~3;
 #pragma unroll
-        for (int j = 0; j < kRunA; ++j)
-            weight_a[j] = j < count_a ? mel_values[min(offset_a + j, mel_nnz - 1)] : 0.f;
+        for (int j = 0; j < kRunA; ++j) {
+            const int index = start_a + j - first_a;        // position in the run
+            weight_a[j] = (index >= 0 && index < count_a)
+                              ? mel_values[min(max(offset_a + index, 0), mel_nnz - 1)]
+                              : 0.f;
+        }
         const int row_b = 64 + (lane >> 2);
-        start_b = mel_start[row_b] + (lane & 3);
+        const int first_b = mel_start[row_b];
         const int count_b = mel_count[row_b];
         const int offset_b = mel_offset[row_b];
+        start_b = (first_b & ~3) + kRunB * (lane & 3);
 #pragma unroll
         for (int j = 0; j < kRunB; ++j) {
-            const int index = (lane & 3) + 4 * j;
-            weight_b[j] = index < count_b ? mel_values[min(offset_b + index, mel_nnz - 1)] : 0.f;
+            const int index = start_b + j - first_b;
+            weight_b[j] = (index >= 0 && index < count_b)
+                              ? mel_values[min(max(offset_b + index, 0), mel_nnz - 1)]
+                              : 0.f;
         }
     }
 
@@ -417,8 +431,13 @@ __global__ __launch_bounds__(256) void frontend_kernel(
             wave_lds_fence();
             float acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < kRunA; ++j)
-                acc = fmaf(weight_a[j], mag[start_a + j], acc);
+            for (int piece = 0; piece < kRunA / 4; ++piece) {
+                const float4 four = *reinterpret_cast<const float4*>(mag + start_a + 4 * piece);
+                acc = fmaf(weight_a[4 * piece], four.x, acc);
+                acc = fmaf(weight_a[4 * piece + 1], four.y, acc);
+                acc = fmaf(weight_a[4 * piece + 2], four.z, acc);
+                acc = fmaf(weight_a[4 * piece + 3], four.w, acc);
+            }
             // natural log on v_log_f32 (log2, 1 ulp; the argument is >= 1e-5);
             // (x + 10) / 10 as one fma: both within 1e-7 of the exact forms
             float value = kLn2 * __builtin_amdgcn_logf(fmaxf(acc, 1e-5f));
@@ -426,8 +445,13 @@ __global__ __launch_bounds__(256) void frontend_kernel(
             tile[lane * kOutStride + local] = value;
             acc = 0.f;
 #pragma unroll
-            for (int j = 0; j < kRunB; ++j)
-                acc = fmaf(weight_b[j], mag[start_b + 4 * j], acc);
+            for (int piece = 0; piece < kRunB / 4; ++piece) {
+                const float4 four = *reinterpret_cast<const float4*>(mag + start_b + 4 * piece);
+                acc = fmaf(weight_b[4 * piece], four.x, acc);
+                acc = fmaf(weight_b[4 * piece + 1], four.y, acc);
+                acc = fmaf(weight_b[4 * piece + 2], four.z, acc);
+                acc = fmaf(weight_b[4 * piece + 3], four.w, acc);
+            }
             acc += __shfl_xor(acc, 1);
             acc += __shfl_xor(acc, 2);
             if ((lane & 3) == 0) {
