@@ -345,6 +345,9 @@ int emph_transformer_block(const float* attended, float* x, int64_t ld, int32_t 
                  "must fit in LDS)", channels, channels, channels);
     EMPH_REQUIRE(tile_n == 16 || tile_n == 32, EMPH_ERANGE,
                  "emph_transformer_block: tile_n %d not in {16, 32}", tile_n);
+    EMPH_REQUIRE(ld > 0 && ld < (int64_t{1} << 28), EMPH_ERANGE,
+                 "emph_transformer_block: ld %lld outside the 32-bit lane offsets",
+                 static_cast<long long>(ld));
     EMPH_REQUIRE(activation == EMPH_ACT_RELU || activation == EMPH_ACT_NONE, EMPH_ERANGE,
                  "emph_transformer_block: activation %d (ReLU or none)", activation);
     const size_t lds = (3 * static_cast<size_t>(channels) * channels + 7 * channels) *
@@ -388,6 +391,9 @@ int emph_qkv_projection(const float* x, int64_t ld, float* qk, float* v, int32_t
                  "emph_qkv_projection: channels %d not in {64, 80}", channels);
     EMPH_REQUIRE(tile_n == 16 || tile_n == 32, EMPH_ERANGE,
                  "emph_qkv_projection: tile_n %d not in {16, 32}", tile_n);
+    EMPH_REQUIRE(ld > 0 && ld < (int64_t{1} << 28), EMPH_ERANGE,
+                 "emph_qkv_projection: ld %lld outside the 32-bit lane offsets",
+                 static_cast<long long>(ld));
     EMPH_REQUIRE((reinterpret_cast<uintptr_t>(v) & 15) == 0, EMPH_EINVAL,
                  "emph_qkv_projection: v must be 16-byte aligned");
     const size_t lds = (3 * static_cast<size_t>(channels) * channels + 3 * channels) *
