@@ -362,6 +362,39 @@ def test_graph_replay_equals_eager(default_engine):
     assert torch.equal(scores[columns], want)
 
 
+def test_public_api_edge_cases():
+    """Empty batches and alignments, a single word, a chunk the reference
+    drops (`core.py:403-415`), extra channels, resampling, device tensors."""
+    make = emphases_amd.Alignment.from_frames
+    assert emphases_amd.from_alignments_and_audios([], []) == []
+    empty = make(np.zeros((2, 0), dtype=np.int64))
+    assert emphases_amd.from_alignment_and_audio(
+        empty, torch.zeros(1, 16000), 16000).shape == (1, 0)
+    one = make(np.array([[0], [100]]))
+    audio_one = torch.from_numpy(synth.audio(1, 100))
+    single = emphases_amd.from_alignment_and_audio(one, audio_one, 16000)
+    assert single.shape == (1, 1) and 0. < float(single) < 1.
+    short = make(np.array([[0], [2]]))
+    assert emphases_amd.from_alignment_and_audio(
+        short, torch.zeros(1, 320), 16000).shape == (1, 0)
+    stereo = torch.from_numpy(np.repeat(synth.audio(2, 200), 2, axis=0))
+    words = make(synth.word_frames(2, 200))
+    mono = emphases_amd.from_alignment_and_audio(words, stereo[:1], 16000)
+    assert torch.equal(
+        emphases_amd.from_alignment_and_audio(words, stereo, 16000), mono)
+    half = torch.from_numpy(synth.audio(2, 200))[:, ::2].contiguous()
+    resampled = emphases_amd.from_alignment_and_audio(words, half, 8000)
+    assert resampled.shape == mono.shape and torch.isfinite(resampled).all()
+    on_device = emphases_amd.from_alignment_and_audio(
+        words, stereo[:1].cuda(), 16000, gpu=0)
+    assert on_device.is_cuda and torch.equal(on_device.cpu(), mono)
+    mixed = emphases_amd.from_alignments_and_audios(
+        [words, empty, one], [stereo[:1], torch.zeros(1, 1600), audio_one])
+    assert [tuple(m.shape) for m in mixed] == [mono.shape, (1, 0), (1, 1)]
+    assert np.abs(mixed[0].numpy() - mono.numpy()).max() < 1e-6
+    assert np.abs(mixed[2].numpy() - single.numpy()).max() < 1e-6
+
+
 def test_many_words_per_segment(default_engine):
     """Segments far longer than the 64-word window of the fused word stage
     (halo recompute across word tiles), incl. 1-frame words."""
