@@ -1,6 +1,6 @@
 """Benchmark of the prominence-inference hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
@@ -43,8 +43,8 @@ FLOPS_PER_FRAME, FLOPS_PER_WORD = 0.2968e6, 0.2309e6
 def parse_args():
     parser = argparse.ArgumentParser()
     parser.add_argument('--gpus', type=int, default=1)
-    parser.add_argument('--steps', type=int, default=50)
-    parser.add_argument('--warmup', type=int, default=10)
+    parser.add_argument('--steps', type=int, default=200)
+    parser.add_argument('--warmup', type=int, default=20)
     parser.add_argument('--config', default='conv',
                         choices=['conv', 'transformer'])
     parser.add_argument('--tile', type=int, default=None)
