@@ -276,8 +276,10 @@ def main():
                     (elapsed / args.steps),
                 'traffic': traffic,
                 'algorithmic_flops_per_launch': flops / launches,
-                # Winograd F(2,3) executes 2/3 of the direct form's MFMA work
+                # Winograd F(2,3) executes 2/3, F(4,3) 1/2 of the direct form's
+                # MFMA work
                 'executed_mfma_flops_per_launch': flops / launches * (
+                    .5 if 'winograd4' in dominant else
                     2. / 3. if 'winograd' in dominant else 1.)},
             # the whole path against both ceilings (per GPU).
             # The conv path is MFMA-bound: its compulsory HBM traffic is only

@@ -1,0 +1,332 @@
+// Winograd F(4,3) form of Conv1d(kernel_size 3, 'same'): four adjacent outputs
+// share six inputs d0..d5 = x[4q-1 .. 4q+4], so a layer is SIX [c_out x c_in]
+// GEMMs over QUADS of positions instead of three over positions: half of the
+// direct form's MFMA work (F(2,3), conv.hip, does two thirds).
+//
+//   v = B^T d   (13 VALU ops per fragment and iteration, see transform())
+//   m_j = U_j v_j,  U = G w formed in float64 on the host
+//   y0 = m0 + m1 + m2 + m3 + m4      y1 = (m1 - m2) + 2 (m3 - m4)
+//   y2 = (m1 + m2) + 4 (m3 + m4)     y3 = (m1 - m2) + 8 (m3 - m4) + m5
+//
+// In fp32 the encoder output of the trained model differs from the direct form
+// by 2.5e-7 (scale 0.64) and the input layer by 9.5e-6 (scale 27): the same
+// level as F(2,3) (numpy emulation, then the GPU parity tests).
+//
+// A workgroup is eight waves around one 6 x (c_in/4) x (c_out/16) x 256-byte
+// pack in LDS (153.6 KB for 80 x 80: identity / ReLU epilogues only, there is no
+// room for an LDS patch).  Four tiles of 64 positions per workgroup; waves w and
+// w + 4 - the two waves of a SIMD - share a tile and split its m-tiles 3 + 2, so
+// every SIMD carries c_out/16 tiles.  A lane holds one quad: its six inputs are
+// one 16-byte and one 8-byte load, its four outputs one 16-byte store (256-byte
+// runs per row).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+#ifndef EMPH_STAMP
+#define EMPH_STAMP(slot)
+#endif
+
+namespace emph {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+struct Run6 {
+    f32x4u a;
+    f32x2u b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const f32x4u*>(p);
+        b = *reinterpret_cast<const f32x2u*>(p + 4);
+    }
+    __device__ __forceinline__ float get(int i) const { return i < 4 ? a[i] : b[i - 4]; }
+};
+
+// M_TILES = ceil(c_out / 16) (compile time: the LDS offsets of the 6 M_TILES
+// fragments of an iteration are immediates)
+template <int M_TILES>
+__global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
+    const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+    const float* __restrict__ pack, const float* __restrict__ bias, int c_in, int c_out,
+    int act, const int32_t* __restrict__ tiles, int n_tiles, int bias_offset) {
+    EMPH_STAMP(0);
+    extern __shared__ __align__(16) float weights[];   // [groups][6][m_tiles][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kk = lane >> 4;
+    const int col = lane & 15;
+    const int iterations = (c_in + 3) >> 2;
+    constexpr int m_tiles = M_TILES;
+    constexpr int split = (m_tiles + 1) >> 1;
+    constexpr int MT = split;
+    const int part = wave >> 2;
+    const int m_begin = part ? split : 0;
+    const int m_count = part ? m_tiles - split : split;     // wave-uniform, <= MT
+    float* bias_lds = weights + bias_offset;
+
+    Tile span;
+    int t0 = 0;
+    bool active = false;
+    bool inside[6];
+    bool edge = false;              // wave-uniform: the tile touches its segment's ends
+    const float* lane_rows = x;     // row kk of the lane's quad
+    auto open_tile = [&](int group) {
+        const int tile = group * 4 + (wave & 3);
+        active = tile < n_tiles && m_count > 0;
+        span = load_tile(tiles, tile < n_tiles ? tile : 0);
+        t0 = span.first;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int t = t0 + 4 * col - 1 + i;
+            inside[i] = t >= 0 && t < span.count;
+        }
+        edge = t0 == 0 || t0 + 65 > span.count;
+        lane_rows = x + span.offset + t0 + 4 * col - 1 + static_cast<int64_t>(kk) * ldx;
+    };
+    // c_in is a multiple of 4 (checked by the launcher), so rows 4 it + kk always
+    // exist: the address is a wave-uniform offset on a per-tile lane pointer.
+    auto load_b = [&](Run6& b, int iteration) {
+        const int it = min(iteration, iterations - 1);
+        b.load(lane_rows + static_cast<int64_t>(4 * it) * ldx);
+    };
+
+    const int groups_of_tiles = (n_tiles + 3) / 4;
+    Run6 b0, b1;
+    open_tile(blockIdx.x);
+    {
+        const int quads = iterations * 6 * m_tiles * 16;
+        // (480 quads per iteration: an odd iteration count ends in half a wave)
+        for (int base = wave * 64; base < quads; base += 512)
+            if (base + lane < quads)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(pack + 4 * (base + lane)),
+                    (__attribute__((address_space(3))) void*)(weights + 4 * base), 16, 0, 0);
+        if (active) load_b(b0, 0);
+        for (int index = threadIdx.x; index < m_tiles * 16; index += 512)
+            bias_lds[index] = (bias != nullptr && index < c_out) ? bias[index] : 0.f;
+        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): LDS-DMA landed
+        __syncthreads();
+    }
+    EMPH_STAMP(1);
+
+    for (int group = blockIdx.x; group < groups_of_tiles; group += gridDim.x) {
+        if (group != static_cast<int>(blockIdx.x)) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);    // drain the previous tile's stores
+            open_tile(group);
+            if (active) load_b(b0, 0);
+        }
+        if (!active) continue;
+        // one instantiation per number of m-tiles a wave can own (a wave-uniform
+        // `if (m < m_count)` around the MFMAs makes hipcc shuffle accumulators)
+        auto run = [&](auto count_tag) {
+            constexpr int COUNT = decltype(count_tag)::value;
+        f32x4 acc[6][COUNT];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int m = 0; m < COUNT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        float a0[6][COUNT], av[6][COUNT], v[6];
+        auto load_a = [&](int iteration) {
+            const float* fragment =
+                weights + ((iteration * 6 * m_tiles + m_begin) << 6) + lane;
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int m = 0; m < COUNT; ++m) a0[j][m] = fragment[(j * m_tiles + m) << 6];
+        };
+        auto step = [&](Run6& b, int iteration) {
+            float d[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i] = b.get(i);
+            if (edge) {                                    // wave-uniform
+#pragma unroll
+                for (int i = 0; i < 6; ++i) d[i] = inside[i] ? d[i] : 0.f;
+            }
+            // v = B^T d
+            const float p = fmaf(-4.f, d[2], d[4]);
+            const float q = fmaf(-4.f, d[1], d[3]);
+            const float c = d[4] - d[2];
+            const float e = 2.f * (d[3] - d[1]);
+            v[0] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
+            v[1] = p + q;
+            v[2] = p - q;
+            v[3] = c + e;
+            v[4] = c - e;
+            v[5] = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int m = 0; m < COUNT; ++m) av[j][m] = a0[j][m];
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(b, iteration + 2);
+            load_a(min(iteration + 1, iterations - 1));
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int m = 0; m < COUNT; ++m)
+                    acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                        av[j][m], v[j], acc[j][m], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x006, 8, 0);   // VALU/SALU
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);   // VMEM read
+#pragma unroll
+            for (int k = 0; k < 6 * COUNT; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        load_a(0);
+        load_b(b1, 1);
+        EMPH_STAMP(2);
+        int iteration = 0;
+#pragma unroll 1
+        for (; iteration + 1 < iterations; iteration += 2) {
+            step(b0, iteration);
+            step(b1, iteration + 1);
+        }
+        if (iteration < iterations) step(b0, iteration);
+        EMPH_STAMP(3);
+
+        // ---- output transform, bias, ReLU, one 16-byte store per row and quad
+        const bool relu = act == EMPH_ACT_RELU;
+        const int t = t0 + 4 * col;
+        const bool vector_ok = (ldy & 3) == 0 && (span.offset & 3) == 0 &&
+                               (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+#pragma unroll
+        for (int m = 0; m < COUNT; ++m) {
+            const int channel0 = 16 * (m_begin + m) + 4 * kk;
+            const f32x4 add = *reinterpret_cast<const f32x4*>(bias_lds + channel0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float m1 = acc[1][m][r], m2 = acc[2][m][r];
+                const float m3 = acc[3][m][r], m4 = acc[4][m][r];
+                const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                float4 out;
+                out.x = acc[0][m][r] + s12 + s34 + add[r];
+                out.y = fmaf(2.f, d34, d12) + add[r];
+                out.z = fmaf(4.f, s34, s12) + add[r];
+                out.w = fmaf(8.f, d34, d12) + acc[5][m][r] + add[r];
+                if (relu) {
+                    out.x = out.x < 0.f ? 0.f : out.x;
+                    out.y = out.y < 0.f ? 0.f : out.y;
+                    out.z = out.z < 0.f ? 0.f : out.z;
+                    out.w = out.w < 0.f ? 0.f : out.w;
+                }
+                if (channel0 + r >= c_out || t >= span.count) continue;
+                float* target = y + static_cast<int64_t>(channel0 + r) * ldy + span.offset + t;
+                if (vector_ok && t + 3 < span.count) {
+                    *reinterpret_cast<float4*>(target) = out;
+                } else {
+                    target[0] = out.x;
+                    if (t + 1 < span.count) target[1] = out.y;
+                    if (t + 2 < span.count) target[2] = out.z;
+                    if (t + 3 < span.count) target[3] = out.w;
+                }
+            }
+        }
+        };
+        if (m_count == MT) run(std::integral_constant<int, MT>{});
+        else run(std::integral_constant<int, (MT > 1 ? MT - 1 : 1)>{});
+        EMPH_STAMP(4);
+    }
+}
+
+}  // namespace emph
+
+using namespace emph;
+
+extern "C" {
+
+int64_t emph_conv_winograd4_pack_size(int32_t c_out, int32_t c_in) {
+    return static_cast<int64_t>((c_in + 3) / 4) * 6 * ((c_out + 15) / 16) * 64;
+}
+
+int64_t emph_conv_winograd4_lds_bytes(int32_t c_out, int32_t c_in) {
+    return (emph_conv_winograd4_pack_size(c_out, c_in) + ((c_out + 15) / 16) * 16) *
+           static_cast<int64_t>(sizeof(float));
+}
+
+// pack[group][j][m][lane] = U_j[16 m + (lane & 15)][4 group + (lane >> 4)],
+// U_j = sum_k G[j][k] w[:, :, k]
+int emph_conv_winograd4_pack(const float* host_weight, int32_t c_out, int32_t c_in,
+                             float* host_pack) {
+    EMPH_REQUIRE(host_weight && host_pack, EMPH_EINVAL,
+                 "emph_conv_winograd4_pack: null pointer");
+    EMPH_REQUIRE(c_out > 0 && c_in > 0, EMPH_EINVAL, "emph_conv_winograd4_pack: bad shape");
+    static const double G[6][3] = {{1. / 4, 0., 0.},           {-1. / 6, -1. / 6, -1. / 6},
+                                   {-1. / 6, 1. / 6, -1. / 6}, {1. / 24, 1. / 12, 1. / 6},
+                                   {1. / 24, -1. / 12, 1. / 6}, {0., 0., 1.}};
+    const int groups = (c_in + 3) / 4, m_tiles = (c_out + 15) / 16;
+    for (int group = 0; group < groups; ++group)
+        for (int j = 0; j < 6; ++j)
+            for (int m = 0; m < m_tiles; ++m)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int co = 16 * m + (lane & 15);
+                    const int ci = 4 * group + (lane >> 4);
+                    double value = 0.;
+                    if (co < c_out && ci < c_in) {
+                        const float* w = host_weight + (static_cast<int64_t>(co) * c_in + ci) * 3;
+                        value = G[j][0] * w[0] + G[j][1] * w[1] + G[j][2] * w[2];
+                    }
+                    host_pack[(((static_cast<int64_t>(group) * 6 + j) * m_tiles + m) << 6) +
+                              lane] = static_cast<float>(value);
+                }
+    return EMPH_OK;
+}
+
+int emph_conv1d_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
+                          const float* pack, const float* bias, int32_t c_in, int32_t c_out,
+                          int32_t activation, const int32_t* tiles, int32_t n_tiles,
+                          void* stream) {
+    if (n_tiles == 0) return EMPH_OK;
+    EMPH_REQUIRE(x && y && pack && tiles, EMPH_EINVAL, "emph_conv1d_winograd4: null pointer");
+    EMPH_REQUIRE(activation == EMPH_ACT_NONE || activation == EMPH_ACT_RELU, EMPH_ERANGE,
+                 "emph_conv1d_winograd4: activation %d (identity or ReLU only)", activation);
+    EMPH_REQUIRE(c_in >= 4 && c_in % 4 == 0 && c_out >= 1 && c_out <= 96, EMPH_ERANGE,
+                 "emph_conv1d_winograd4: channels %d -> %d (c_in a multiple of 4, c_out <= 96)",
+                 c_in, c_out);
+    const size_t lds = static_cast<size_t>(emph_conv_winograd4_lds_bytes(c_out, c_in));
+    EMPH_REQUIRE(lds <= 160 * 1024, EMPH_ERANGE,
+                 "emph_conv1d_winograd4: %zu bytes of LDS needed", lds);
+    const int m_tiles = (c_out + 15) / 16;
+    const int bias_offset = static_cast<int>(emph_conv_winograd4_pack_size(c_out, c_in));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int groups = (n_tiles + 3) / 4;
+    dim3 grid(groups < 256 ? groups : 256);
+#define EMPH_W4(M_TILES)                                                                       \
+    do {                                                                                  \
+        auto kernel = conv1d_winograd4_kernel<M_TILES>;                                        \
+        static size_t reserved = 64 * 1024;                                               \
+        if (lds > reserved) {                                                             \
+            hipError_t status = hipFuncSetAttribute(                                      \
+                reinterpret_cast<const void*>(kernel),                                    \
+                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));       \
+            if (status != hipSuccess) {                                                   \
+                set_error("emph_conv1d_winograd4: cannot reserve %zu bytes of LDS", lds); \
+                return static_cast<int>(status);                                          \
+            }                                                                             \
+            reserved = lds;                                                               \
+        }                                                                                 \
+        hipLaunchKernelGGL(kernel, grid, dim3(512), lds, s, x, ldx, y, ldy, pack, bias,   \
+                           c_in, c_out, activation, tiles, n_tiles, bias_offset);         \
+    } while (0)
+    switch (m_tiles) {
+        case 1: EMPH_W4(1); break;
+        case 2: EMPH_W4(2); break;
+        case 3: EMPH_W4(3); break;
+        case 4: EMPH_W4(4); break;
+        case 5: EMPH_W4(5); break;
+        case 6: EMPH_W4(6); break;
+        default:
+            set_error("emph_conv1d_winograd4: %d output channels (at most 96)", c_out);
+            return EMPH_ERANGE;
+    }
+#undef EMPH_W4
+    return check_launch("emph_conv1d_winograd4");
+}
+
+}  // extern "C"

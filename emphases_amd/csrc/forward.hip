@@ -37,10 +37,18 @@ int emph_prominence_forward(const emph_conv_model* model, const float* audio,
                  "rows only)", m.features);
     EMPH_REQUIRE(m.encoder_layers >= 0 && m.encoder_layers <= 16, EMPH_ERANGE,
                  "emph_prominence_forward: %d encoder layers", m.encoder_layers);
-    EMPH_REQUIRE(emph_conv_winograd_lds_bytes(m.channels, m.channels) <= 160 * 1024 &&
-                     emph_conv_winograd_lds_bytes(m.channels, m.features) <= 160 * 1024,
-                 EMPH_ERANGE, "emph_prominence_forward: %d channels do not fit the Winograd "
-                 "kernel's LDS", m.channels);
+    const bool quad = m.conv_variant == 1;        // Winograd F(4,3)
+    EMPH_REQUIRE(m.conv_variant == 0 || quad, EMPH_EINVAL,
+                 "emph_prominence_forward: conv_variant %d", m.conv_variant);
+    EMPH_REQUIRE(!quad || tile_n == 64, EMPH_ERANGE,
+                 "emph_prominence_forward: F(4,3) takes 64-position tiles, not %d", tile_n);
+    const int64_t lds_square = quad ? emph_conv_winograd4_lds_bytes(m.channels, m.channels)
+                                    : emph_conv_winograd_lds_bytes(m.channels, m.channels);
+    const int64_t lds_input = quad ? emph_conv_winograd4_lds_bytes(m.channels, m.features)
+                                   : emph_conv_winograd_lds_bytes(m.channels, m.features);
+    EMPH_REQUIRE(lds_square <= 160 * 1024 && lds_input <= 160 * 1024, EMPH_ERANGE,
+                 "emph_prominence_forward: %d channels do not fit the Winograd kernel's LDS",
+                 m.channels);
     const int c = m.channels;
     float* features = workspace;
     float* current = features + static_cast<int64_t>(m.features) * ld_frames;
@@ -51,16 +59,21 @@ int emph_prominence_forward(const emph_conv_model* model, const float* audio,
                              m.mel_start, m.mel_count, m.mel_offset, m.mel_values, m.mel_nnz,
                              features, ld_frames, 0, -1, nullptr, nullptr, m.normalize, stream);
     if (status) return status;
-    status = emph_conv1d_winograd(features, ld_frames, current, ld_frames, m.input_pack,
-                                  m.input_bias, m.features, c, EMPH_ACT_NONE, frame_tiles,
-                                  n_frame_tiles, tile_n, stream);
+    auto conv = [&](const float* in, float* out, const float* pack, const float* bias, int c_in,
+                    int activation) {
+        return quad ? emph_conv1d_winograd4(in, ld_frames, out, ld_frames, pack, bias, c_in, c,
+                                            activation, frame_tiles, n_frame_tiles, stream)
+                    : emph_conv1d_winograd(in, ld_frames, out, ld_frames, pack, bias, c_in, c,
+                                           activation, frame_tiles, n_frame_tiles, tile_n,
+                                           stream);
+    };
+    status = conv(features, current, m.input_pack, m.input_bias, m.features, EMPH_ACT_NONE);
     if (status) return status;
-    const int64_t pack_floats = emph_conv_winograd_pack_size(c, c);
+    const int64_t pack_floats =
+        quad ? emph_conv_winograd4_pack_size(c, c) : emph_conv_winograd_pack_size(c, c);
     for (int layer = 0; layer < m.encoder_layers; ++layer) {
-        status = emph_conv1d_winograd(current, ld_frames, other, ld_frames,
-                                      m.encoder_packs + layer * pack_floats,
-                                      m.encoder_biases + static_cast<int64_t>(layer) * c, c, c,
-                                      m.activation, frame_tiles, n_frame_tiles, tile_n, stream);
+        status = conv(current, other, m.encoder_packs + layer * pack_floats,
+                      m.encoder_biases + static_cast<int64_t>(layer) * c, c, m.activation);
         if (status) return status;
         float* swap = current;
         current = other;

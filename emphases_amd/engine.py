@@ -65,6 +65,14 @@ class _Conv:
                 WINOGRAD_LDS_BUDGET:
             self.winograd = torch.from_numpy(
                 runtime.conv_winograd_pack(weight)).to(device)
+        # Winograd F(4,3): half the MFMA work, identity / ReLU, 64-position tiles
+        self.winograd4 = None
+        if winograd and self.kernel_size == 3 and self.c_out <= 96 and \
+                self.c_in % 4 == 0 and \
+                runtime.conv_winograd4_lds_bytes(self.c_out, self.c_in) <= \
+                WINOGRAD_LDS_BUDGET:
+            self.winograd4 = torch.from_numpy(
+                runtime.conv_winograd4_pack(weight)).to(device)
         self.bias = None if bias is None else torch.from_numpy(
             np.ascontiguousarray(bias, dtype=np.float32)).to(device)
 
@@ -125,6 +133,13 @@ class Engine:
         if config.architecture == 'transformer':
             self.position = to(weights_module.positional_encoding(
                 cfg.MAX_POSITIONS, config.channels))
+        # F(4,3) when every frame-rate k=3 layer has a pack and the activation
+        # is one its register epilogue handles
+        frame_layers = [self.input_layer] + (
+            self.frame_encoder if config.architecture == 'convolution' else [])
+        self.quad = winograd and config.activation in (None, 'relu') and \
+            config.architecture == 'convolution' and \
+            all(layer.winograd4 is not None for layer in frame_layers)
         self.model = self._conv_model()
 
     def _conv_model(self):
@@ -141,7 +156,8 @@ class Engine:
                 any(layer.winograd is None for layer in layers):
             return None
         encoder = self.frame_encoder
-        self._encoder_packs = torch.cat([l.winograd for l in encoder]) \
+        pick = (lambda l: l.winograd4) if self.quad else (lambda l: l.winograd)
+        self._encoder_packs = torch.cat([pick(l) for l in encoder]) \
             if encoder else torch.zeros(1, device=self.device)
         self._encoder_biases = torch.cat([l.bias for l in encoder]) \
             if encoder else torch.zeros(1, device=self.device)
@@ -154,11 +170,12 @@ class Engine:
             reduction=runtime.REDUCTIONS[config.downsample_method],
             post=runtime.POSTPROCESS[config.loss],
             normalize=int(config.normalize), mel_nnz=self.mel_nnz,
+            conv_variant=int(self.quad),
             table=pointer(self.table), mel_start=pointer(self.mel_start),
             mel_count=pointer(self.mel_count),
             mel_offset=pointer(self.mel_offset),
             mel_values=pointer(self.mel_values),
-            input_pack=pointer(self.input_layer.winograd),
+            input_pack=pointer(pick(self.input_layer)),
             input_bias=pointer(self.input_layer.bias),
             encoder_packs=pointer(self._encoder_packs),
             encoder_biases=pointer(self._encoder_biases),
@@ -236,18 +253,22 @@ class Engine:
         (trips over the 256 CUs) x (time of one trip): pick the tile that
         minimises it.  Microseconds per trip measured on the 80x80 k=3 layer
         (tools/micro/conv_bench.hip): Winograd 32: 24.0, Winograd 64: 26.7,
-        direct 64: 33.5, direct 32: 31.3, direct 16: 16.1."""
+        direct 64: 33.5, direct 32: 31.3, direct 16: 16.1; Winograd F(4,3)
+        (64-position tiles, identity / ReLU layers): 20.7."""
         if self.conv_tile is not None:
             return self.conv_tile
         frames = [segment.frames for segment in plan.segments]
         if self.winograd:
-            cost = {64: 26.7, 32: 24.0, 16: 16.1}
+            cost = {64: 20.7 if self.quad else 26.7, 32: 23.2, 16: 16.1}
         else:
             cost = {64: 33.5, 32: 31.3, 16: 16.1}
         best = None
-        for tile in (32, 64, 16):
+        for tile in (64, 32, 16) if self.quad else (32, 64, 16):
             tiles = sum(-(-count // tile) for count in frames)
-            groups = -(-tiles // (4 if tile == 64 else 8))
+            waves = 4 if tile == 64 else 8
+            if tile == 64 and self.quad:
+                waves = 4          # four 64-position tiles per 8-wave workgroup
+            groups = -(-tiles // waves)
             trips = -(-groups // 256)
             if best is None or trips * cost[tile] < best[0]:
                 best = (trips * cost[tile], tile)
@@ -347,6 +368,17 @@ class Engine:
                 f'_{layer.c_in}x{layer.c_out}_k{layer.kernel_size}')
         flops = 2. * layer.c_in * layer.c_out * layer.kernel_size * positions
         bias = None if layer.bias is None else layer.bias.data_ptr()
+        if layer.winograd4 is not None and axis == runtime.AXIS_FRAMES and \
+                block == 64 and self.quad and not transpose_out and \
+                activation in (None, 'relu'):
+            with self._timed(name.replace('conv1d', 'conv1d_winograd4'), flops):
+                runtime.check(self.lib.emph_conv1d_winograd4(
+                    x.data_ptr(), ldx, y.data_ptr(), ldy,
+                    layer.winograd4.data_ptr(), bias, layer.c_in, layer.c_out,
+                    runtime.ACTIVATIONS[activation], tiles.data_ptr(),
+                    size // runtime.TILE_FIELDS, runtime.stream()),
+                    'emph_conv1d_winograd4')
+            return
         if layer.winograd is not None and axis == runtime.AXIS_FRAMES and \
                 block in (32, 64) and not transpose_out:
             # same algorithmic flops; the kernel executes two thirds of them
@@ -518,7 +550,8 @@ class Engine:
         ld_f, ld_w = plan.ld_frames, plan.ld_words
         frames, words = runtime.AXIS_FRAMES, runtime.AXIS_WORDS
         if self.model is not None and stages is None and features is None \
-                and self.timers is None and block in (32, 64) and \
+                and self.timers is None and \
+                block in ((64,) if self.quad else (32, 64)) and \
                 len(plan.segments):
             # the whole path behind one C call
             check_bounds(plan, config.downsample_method)

@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -50,6 +50,12 @@ SIGNATURES = {
     'emph_conv_winograd_pack': (_c.c_int, [_ptr, _i32, _i32, _ptr]),
     'emph_conv1d_winograd': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _ptr, _i32, _i32,
+        _ptr]),
+    'emph_conv_winograd4_pack_size': (_i64, [_i32, _i32]),
+    'emph_conv_winograd4_lds_bytes': (_i64, [_i32, _i32]),
+    'emph_conv_winograd4_pack': (_c.c_int, [_ptr, _i32, _i32, _ptr]),
+    'emph_conv1d_winograd4': (_c.c_int, [
+        _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _ptr, _i32,
         _ptr]),
     'emph_segment_reduce': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _i64, _i32, _ptr]),
@@ -184,7 +190,7 @@ class ConvModel(_c.Structure):
     _fields_ = [(name, _i32) for name in (
         'channels', 'features', 'encoder_layers', 'decoder_layers',
         'decoder_kernel_size', 'activation', 'reduction', 'post',
-        'normalize', 'mel_nnz')] + [(name, _ptr) for name in (
+        'normalize', 'mel_nnz', 'conv_variant')] + [(name, _ptr) for name in (
             'table', 'mel_start', 'mel_count', 'mel_offset', 'mel_values',
             'input_pack', 'input_bias', 'encoder_packs', 'encoder_biases',
             'decoder_packs', 'decoder_biases', 'out_weight', 'out_bias')]
@@ -203,6 +209,24 @@ def word_decoder_pack(weight):
         weight.ctypes.data, channels, kernel_size, pack.ctypes.data),
         'emph_word_decoder_pack')
     return pack
+
+
+def conv_winograd4_pack(weight):
+    """Winograd F(4,3) pack of a [c_out, c_in, 3] weight (host, numpy)."""
+    lib = library()
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    c_out, c_in, kernel_size = weight.shape
+    assert kernel_size == 3
+    pack = np.zeros(
+        lib.emph_conv_winograd4_pack_size(c_out, c_in), dtype=np.float32)
+    check(lib.emph_conv_winograd4_pack(
+        weight.ctypes.data, c_out, c_in, pack.ctypes.data),
+        'emph_conv_winograd4_pack')
+    return pack
+
+
+def conv_winograd4_lds_bytes(c_out, c_in):
+    return int(library().emph_conv_winograd4_lds_bytes(c_out, c_in))
 
 
 def conv_winograd_lds_bytes(c_out, c_in):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 10
+#define EMPH_ABI_VERSION 11
 
 /* Segment-table fields */
 enum {
@@ -193,6 +193,20 @@ int emph_conv1d_winograd(const float* x, int64_t ldx, float* y, int64_t ldy,
                          int32_t c_out, int32_t activation,
                          const int32_t* tiles, int32_t n_tiles, int32_t tile_n,
                          void* stream);
+
+/* Winograd F(4,3) form: six GEMMs over quads of positions, half of the direct
+ * form's matrix-core work; the same contract as emph_conv1d(kernel_size = 3)
+ * for identity / ReLU, with 64-position tiles (the tile table's block), c_in a
+ * multiple of 4, c_out <= 96 and the whole pack in LDS
+ * (emph_conv_winograd4_lds_bytes <= 160 KiB: up to 80 x 80). */
+int64_t emph_conv_winograd4_pack_size(int32_t c_out, int32_t c_in);
+int64_t emph_conv_winograd4_lds_bytes(int32_t c_out, int32_t c_in);
+int emph_conv_winograd4_pack(const float* host_weight, int32_t c_out,
+                             int32_t c_in, float* host_pack);
+int emph_conv1d_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
+                          const float* pack, const float* bias, int32_t c_in,
+                          int32_t c_out, int32_t activation,
+                          const int32_t* tiles, int32_t n_tiles, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Frame -> word resampling                                                  */
@@ -376,14 +390,15 @@ typedef struct emph_conv_model {
     int32_t post;                 /* EMPH_POST_*                               */
     int32_t normalize;            /* emphases NORMALIZE                        */
     int32_t mel_nnz;
+    int32_t conv_variant;         /* 0: Winograd F(2,3) packs, 1: F(4,3) packs */
     const float* table;           /* emph_frontend_table_fill                  */
     const int32_t* mel_start;
     const int32_t* mel_count;
     const int32_t* mel_offset;
     const float* mel_values;
-    const float* input_pack;      /* emph_conv_winograd_pack [C][features][3]  */
+    const float* input_pack;      /* emph_conv_winograd[4]_pack [C][features][3] */
     const float* input_bias;      /* [C]                                       */
-    const float* encoder_packs;   /* encoder_layers Winograd packs [C][C][3]   */
+    const float* encoder_packs;   /* encoder_layers packs [C][C][3], same variant */
     const float* encoder_biases;  /* [encoder_layers][C]                       */
     const float* decoder_packs;   /* emph_word_decoder_pack per layer          */
     const float* decoder_biases;  /* [decoder_layers][C]                       */
@@ -402,7 +417,7 @@ int64_t emph_prominence_workspace_floats(int32_t features, int32_t channels,
  * core.py:89-138) of the convolutional configurations with encoder
  * kernel_size 3 and mel features.  The tables are those of the individual
  * entry points: `frontend_tiles` with 32-frame blocks, `frame_tiles` with
- * block `tile_n` (32 or 64), `word_tiles` with block
+ * block `tile_n` (32 or 64; 64 for conv_variant 1), `word_tiles` with block
  * emph_word_decoder_block(...).  Enqueues on `stream`; allocates nothing. */
 int emph_prominence_forward(const emph_conv_model* model, const float* audio,
                             const int64_t* seg, const int32_t* frontend_tiles,

@@ -156,6 +156,53 @@ def test_conv1d_winograd(c_in, c_out, activation, tile):
     assert float(y[:, :batch.LEAD].min()) == 7.0
 
 
+@pytest.mark.parametrize('c_in,c_out,activation', [
+    (80, 80, 'relu'), (80, 80, None), (64, 64, 'relu'), (64, 96, None),
+    (84, 80, 'relu'), (4, 7, None), (80, 1, None), (48, 33, 'relu')])
+def test_conv1d_winograd4(c_in, c_out, activation):
+    """F(4,3) form == Conv1d(k=3, 'same') on ragged segments, odd lengths,
+    channel counts that do not fill the last group / tile / half."""
+    lib = runtime.library()
+    plan = ragged_plan([200, 1, 2, 3, 4, 5, 17, 64, 65, 130, 63, 66, 127])
+    axis, tile = runtime.AXIS_FRAMES, 64
+    meta = Meta(plan, [(axis, tile)])
+    x = random_packed(c_in, plan, axis, 11)
+    x[:, :batch.LEAD] = float('nan')
+    x[:, -batch.TAIL:] = float('nan')
+    weight = synth.weights(5, (c_out, c_in, 3), 0.2)
+    bias = synth.weights(6, (c_out,), 0.5)
+    y = torch.full((c_out, plan.ld_frames), 7.0, device=DEVICE)
+    assert runtime.conv_winograd4_lds_bytes(c_out, c_in) <= 160 * 1024
+    pack = torch.from_numpy(runtime.conv_winograd4_pack(weight)).to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    x_dev, bias_dev = x.to(DEVICE), torch.from_numpy(bias).to(DEVICE)
+    runtime.check(lib.emph_conv1d_winograd4(
+        x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
+        pack.data_ptr(), bias_dev.data_ptr(), c_in, c_out,
+        runtime.ACTIVATIONS[activation], tiles.data_ptr(), size // 4, None),
+        'emph_conv1d_winograd4')
+    y = y.cpu()
+    for off, count in spans(plan, axis):
+        want = ACTIVATIONS[activation](torch.nn.functional.conv1d(
+            x[None, :, off:off + count], torch.from_numpy(weight),
+            torch.from_numpy(bias), padding=1))[0]
+        got = y[:, off:off + count]
+        assert torch.isfinite(got).all()
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) < 5e-5 * scale
+    assert float(y[:, :batch.LEAD].min()) == 7.0
+    # transcendental activations and packs beyond the LDS are refused
+    assert lib.emph_conv1d_winograd4(
+        x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
+        pack.data_ptr(), None, c_in, c_out, 2, tiles.data_ptr(), size // 4,
+        None) == -2
+    assert runtime.conv_winograd4_lds_bytes(80, 88) > 160 * 1024
+    assert lib.emph_conv1d_winograd4(
+        x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
+        pack.data_ptr(), None, 83, 80, 0, tiles.data_ptr(), size // 4,
+        None) == -2                         # c_in must be a multiple of 4
+
+
 def test_conv1d_winograd_rejects_bad_arguments():
     lib = runtime.library()
     buffer = torch.zeros(4096, device=DEVICE)

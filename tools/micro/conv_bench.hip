@@ -22,13 +22,18 @@ __device__ unsigned long long* g_stamps = nullptr;
     } while (0)
 #endif
 #include "../../emphases_amd/csrc/conv.hip"
+#include "../../emphases_amd/csrc/conv_w4.hip"
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
-static bool g_wino = false;
+static bool g_wino = false, g_w4 = false;
 static float* g_wino_pack = nullptr;
+static float* g_w4_pack = nullptr;
 static int conv(const float* x, int64_t ld, float* y, const float* pack, const float* bias, int c,
                 int ks, const int32_t* tiles, int n_tiles, int tile_n) {
+    if (g_w4)
+        return emph_conv1d_winograd4(x, ld, y, ld, g_w4_pack, bias, c, c, 1, tiles, n_tiles,
+                                     nullptr);
     if (g_wino)
         return emph_conv1d_winograd(x, ld, y, ld, g_wino_pack, bias, c, c, 1, tiles, n_tiles,
                                     tile_n, nullptr);
@@ -37,6 +42,7 @@ static int conv(const float* x, int64_t ld, float* y, const float* pack, const f
 
 int main(int argc, char** argv) {
     g_wino = getenv("WINO") != nullptr;
+    g_w4 = getenv("W4") != nullptr;
     const int segments = 64, frames = 1000, c = 80;
     const int ks = getenv("KS") ? atoi(getenv("KS")) : 3;
     const int64_t ld = 16 + static_cast<int64_t>(segments) * 1008 + 64;
@@ -48,6 +54,10 @@ int main(int argc, char** argv) {
     emph_conv_pack(hw.data(), c, c, ks, hpack.data());
     std::vector<float> hwino(emph_conv_winograd_pack_size(c, c));
     emph_conv_winograd_pack(hw.data(), c, c, hwino.data());
+    std::vector<float> hw4(emph_conv_winograd4_pack_size(c, c));
+    emph_conv_winograd4_pack(hw.data(), c, c, hw4.data());
+    CHECK(hipMalloc(&g_w4_pack, hw4.size() * 4));
+    CHECK(hipMemcpy(g_w4_pack, hw4.data(), hw4.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&g_wino_pack, hwino.size() * 4));
     CHECK(hipMemcpy(g_wino_pack, hwino.data(), hwino.size() * 4, hipMemcpyHostToDevice));
     std::vector<float> hbias(c, 0.1f);
@@ -61,6 +71,7 @@ int main(int argc, char** argv) {
     CHECK(hipEventCreate(&start)); CHECK(hipEventCreate(&stop));
     for (int tile_n : {64, 32, 16}) {
         if (g_wino && tile_n == 16) continue;
+        if (g_w4 && tile_n != 64) continue;
         std::vector<int32_t> tiles;
         for (int s = 0; s < segments; ++s)
             for (int t = 0; t < frames; t += tile_n) {

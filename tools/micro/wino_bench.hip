@@ -9,6 +9,8 @@
 #include <vector>
 
 #include "../../emphases_amd/csrc/conv.hip"
+#undef EMPH_STAMP
+#include "../../emphases_amd/csrc/conv_w4.hip"
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -27,6 +29,11 @@ int main(int argc, char** argv) {
     emph_conv_pack(hw.data(), c, c, ks, hpack.data());
     std::vector<float> hwino(emph_conv_winograd_pack_size(c, c));
     emph_conv_winograd_pack(hw.data(), c, c, hwino.data());
+    std::vector<float> hwino4(emph_conv_winograd4_pack_size(c, c));
+    emph_conv_winograd4_pack(hw.data(), c, c, hwino4.data());
+    float* wino4;
+    CHECK(hipMalloc(&wino4, hwino4.size() * 4));
+    CHECK(hipMemcpy(wino4, hwino4.data(), hwino4.size() * 4, hipMemcpyHostToDevice));
     std::vector<float> hbias(c, 0.1f);
     float *x, *y, *z, *pack, *wino, *bias;
     CHECK(hipMalloc(&x, hx.size() * 4)); CHECK(hipMalloc(&y, hx.size() * 4));
@@ -51,11 +58,14 @@ int main(int argc, char** argv) {
         CHECK(hipMalloc(&dtiles, tiles.size() * 4));
         CHECK(hipMemcpy(dtiles, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
         CHECK(hipMemset(y, 0, hx.size() * 4)); CHECK(hipMemset(z, 0, hx.size() * 4));
-        for (int which = 0; which < 2; ++which) {
+        for (int which = 0; which < 3; ++which) {
+            if (which == 2 && tile_n != 64) continue;
             auto run = [&]() {
                 int status = which == 0
                     ? emph_conv1d(x, ld, y, ld, pack, bias, c, c, ks, 1, dtiles, n_tiles, tile_n, 0, nullptr)
-                    : emph_conv1d_winograd(x, ld, z, ld, wino, bias, c, c, 1, dtiles, n_tiles, tile_n, nullptr);
+                    : which == 1
+                    ? emph_conv1d_winograd(x, ld, z, ld, wino, bias, c, c, 1, dtiles, n_tiles, tile_n, nullptr)
+                    : emph_conv1d_winograd4(x, ld, z, ld, wino4, bias, c, c, 1, dtiles, n_tiles, nullptr);
                 if (status) { printf("status %d: %s\n", status, emph_last_error()); exit(1); }
             };
             for (int rep = 0; rep < 5; ++rep) run();
@@ -69,7 +79,7 @@ int main(int argc, char** argv) {
             CHECK(hipEventElapsedTime(&ms, start, stop));
             const double us = ms * 1e3 / reps;
             printf("%s tile %2d: %7.2f us/launch  %6.1f direct-equivalent TFLOP/s\n",
-                   which ? "winograd" : "direct  ", tile_n, us,
+                   which == 2 ? "F(4,3)  " : which ? "winograd" : "direct  ", tile_n, us,
                    2.0 * c * c * ks * segments * frames / us * 1e-6);
         }
         std::vector<float> hy(hx.size()), hz(hx.size());

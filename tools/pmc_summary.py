@@ -11,6 +11,9 @@ import sys
 FRAMES, WORDS, CHANNELS = 64000, 1882, 80
 KERNELS = {
     # kernel function substring -> (bench.py name, algorithmic bytes per launch)
+    'conv1d_winograd4_kernel': (
+        'conv1d_winograd4_frames_80x80_k3',
+        2 * CHANNELS * FRAMES * 4 + 153600),
     'conv1d_winograd_kernel': (
         'conv1d_winograd_frames_80x80_k3',
         2 * CHANNELS * FRAMES * 4 + 102400),
