@@ -255,3 +255,42 @@ class Pieces:
                 self.plan.frames[piece])
             self.bounds[:, column] = segments[piece].bounds[:, 0]
             self.word_piece[column] = piece
+
+
+def chunk_audio(audio, segment):
+    """The chunk's samples as the reference slices them out of the
+    432-zero-padded signal (`core.py:357-358,395-401`): float32 tensor
+    [1, segment.length].  Host-side; only the pitch tracker needs it (the HIP
+    front-end does this indexing on the fly)."""
+    import torch
+    audio = audio.reshape(-1)
+    first = segment.start_sample - cfg.PADDING
+    last = first + segment.length
+    lo, hi = max(first, 0), min(last, int(audio.shape[0]))
+    piece = torch.zeros(segment.length, dtype=torch.float32)
+    if hi > lo:
+        piece[lo - first:hi - first] = audio[lo:hi].to(torch.float32).cpu()
+    return piece[None]
+
+
+def pack_tracks(plan, tracks):
+    """Pitch-tracker outputs of every segment on the packed frame axis.
+
+    tracks: per segment, `(pitch [1, Fc], periodicity [1, Fc])` as
+    `penn.from_audio` returns them (`data/preprocess/core.py:84-92`).
+    Returns float32 numpy [2, ld_frames]; padding columns hold 1 (log2 -> 0)."""
+    packed = np.ones((2, plan.ld_frames), dtype=np.float32)
+    for segment, off, count, pair in zip(
+            plan.segments, plan.frame_off, plan.frames, tracks):
+        for row, track in enumerate(pair):
+            track = np.asarray(
+                track.detach().cpu() if hasattr(track, 'detach') else track,
+                dtype=np.float32).reshape(-1)
+            if track.size != count:
+                # the reference's torch.cat would raise and the chunk would be
+                # dropped without a trace (core.py:123, core.py:414-415)
+                raise ValueError(
+                    f'the pitch tracker returned {track.size} frames for a '
+                    f'chunk of {count}')
+            packed[row, off:off + count] = track
+    return packed

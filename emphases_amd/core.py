@@ -66,11 +66,48 @@ def get_engine(checkpoint=None, gpu=None, config=None):
 ###############################################################################
 
 
+def penn_tracker(gpu=None):
+    """The reference's pitch tracker call (`data/preprocess/core.py:84-92`) as
+    a `pitch_tracker` callable; `penn` is third-party and optional."""
+    try:
+        import penn
+    except ImportError as error:
+        raise NotImplementedError(
+            'PITCH_FEATURE / PERIODICITY_FEATURE need the third-party `penn` '
+            'pitch tracker, which is not installed: pass pitch_tracker=, a '
+            'callable (audio [1, S] at 16 kHz) -> (pitch [1, F] in Hz, '
+            'periodicity [1, F])') from error
+
+    def track(audio):
+        return penn.from_audio(
+            audio, cfg.SAMPLE_RATE, hopsize=cfg.HOPSIZE_SECONDS,
+            fmin=cfg.FMIN, fmax=cfg.FMAX, pad=True, interp_unvoiced_at=50,
+            gpu=gpu)
+    return track
+
+
+def _tracks(engine, plan, audios, pitch_tracker, gpu):
+    """Device tensor [2, ld_frames] of tracker outputs, or None."""
+    config = engine.config
+    if not (config.pitch_feature or config.periodicity_feature):
+        return None
+    tracker = pitch_tracker or penn_tracker(gpu)
+    pairs = [
+        tracker(batch.chunk_audio(audios[segment.utterance], segment))
+        for segment in plan.segments]
+    packed = torch.from_numpy(batch.pack_tracks(plan, pairs))
+    return packed.pin_memory().to(engine.device, non_blocking=True)
+
+
 def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
                                checkpoint=None, batch_size=None, gpu=None,
-                               config=None):
+                               config=None, pitch_tracker=None):
     """Scores for many utterances in one ragged batch.
 
+    pitch_tracker: for configurations with PITCH_FEATURE / PERIODICITY_FEATURE,
+        the stand-in for `penn.from_audio` (`data/preprocess/core.py:84-92`):
+        `(chunk audio [1, Sc]) -> (pitch [1, Fc] Hz, periodicity [1, Fc])`;
+        default: `penn` itself, if installed.
     Returns a list of float32 tensors [1, W_i] (CPU if `gpu is None`)."""
     engine = get_engine(checkpoint, gpu, config)
     device = engine.device
@@ -85,11 +122,13 @@ def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
     results = [torch.zeros((1, 0)) for _ in audios]
     if segments:
         plan = batch.Plan(segments, offsets, lengths)
-        with torch.cuda.device(device):
+        # forward() returns workspace buffers of a cached engine: hold its
+        # lock until the result is detached from them
+        with torch.cuda.device(device), engine.lock:
+            tracks = _tracks(engine, plan, audios, pitch_tracker, gpu)
             packed = engine.pack_audio(audios)
-            scores, _ = engine.forward(packed, plan)
-        # forward() returns workspace buffers: detach the result from them
-        scores = scores.clone() if gpu is not None else scores.cpu()
+            scores, _ = engine.forward(packed, plan, tracks=tracks)
+            scores = scores.clone() if gpu is not None else scores.cpu()
         pieces = [[] for _ in audios]
         for segment, off, count in zip(
                 plan.segments, plan.word_off, plan.words):
@@ -187,7 +226,7 @@ def from_files_to_files(text_files, audio_files, output_prefixes=None,
 
 
 def preprocess(alignment, audio, sample_rate=cfg.SAMPLE_RATE, batch_size=None,
-               gpu=None):
+               gpu=None, pitch_tracker=None):
     """Convert audio to model input (`core.py:345-418`): yields
     `(features [1, NUM_FEATURES, Fc] on the device, word_bounds int64
     [1, 2, Wc] on the CPU)` per chunk."""
@@ -197,10 +236,11 @@ def preprocess(alignment, audio, sample_rate=cfg.SAMPLE_RATE, batch_size=None,
     if not segments:
         return
     plan = batch.Plan(segments, [0], [int(audio.shape[0])])
-    with torch.cuda.device(engine.device):
+    with torch.cuda.device(engine.device), engine.lock:
         meta = engine.upload(plan)
         features = engine.features(
-            audio.to(engine.device).contiguous(), plan, meta)
+            audio.to(engine.device).contiguous(), plan, meta,
+            tracks=_tracks(engine, plan, [audio], pitch_tracker, gpu)).clone()
     for segment, off, count in zip(segments, plan.frame_off, plan.frames):
         yield (features[None, :, off:off + count],
                torch.from_numpy(segment.bounds)[None])
@@ -298,7 +338,7 @@ class Model:
         plan = _packed_plan(
             [int(n) for n in frame_lengths], word_bounds,
             [int(n) for n in word_lengths])
-        with torch.cuda.device(device):
+        with torch.cuda.device(device), engine.lock:
             packed = _pack(
                 features.to(device, torch.float32), plan, plan.frame_off,
                 plan.frames, plan.ld_frames, device)

@@ -358,17 +358,10 @@ int emph_transformer_block(const float* attended, float* x, int64_t ld, int32_t 
 #define EMPH_BLOCK(MB, NB)                                                              \
     do {                                                                                \
         auto kernel = transformer_block_kernel<MB, NB>;                                 \
-        static size_t reserved = 64 * 1024;                                             \
-        if (lds > reserved) {                                                           \
-            hipError_t status = hipFuncSetAttribute(                                    \
-                reinterpret_cast<const void*>(kernel),                                  \
-                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));     \
-            if (status != hipSuccess) {                                                 \
-                set_error("emph_transformer_block: cannot reserve %zu bytes of LDS", lds); \
-                return static_cast<int>(status);                                        \
-            }                                                                           \
-            reserved = lds;                                                             \
-        }                                                                               \
+        static LdsReservation reserved;                                                        \
+        if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,     \
+                                     "emph_transformer_block"))                                \
+            return status;                                                                     \
         hipLaunchKernelGGL(kernel, grid, dim3(512), lds, s, attended, x, ld, packs,     \
                            vectors, eps, activation, tiles, n_tiles);                   \
     } while (0)
@@ -404,17 +397,10 @@ int emph_qkv_projection(const float* x, int64_t ld, float* qk, float* v, int32_t
 #define EMPH_QKV(MB, NB)                                                                \
     do {                                                                                \
         auto kernel = qkv_kernel<MB, NB>;                                               \
-        static size_t reserved = 64 * 1024;                                             \
-        if (lds > reserved) {                                                           \
-            hipError_t status = hipFuncSetAttribute(                                    \
-                reinterpret_cast<const void*>(kernel),                                  \
-                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));     \
-            if (status != hipSuccess) {                                                 \
-                set_error("emph_qkv_projection: cannot reserve %zu bytes of LDS", lds); \
-                return static_cast<int>(status);                                        \
-            }                                                                           \
-            reserved = lds;                                                             \
-        }                                                                               \
+        static LdsReservation reserved;                                                        \
+        if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,     \
+                                     "emph_transformer_block"))                                \
+            return status;                                                                     \
         hipLaunchKernelGGL(kernel, grid, dim3(512), lds, s, x, ld, qk, v, packs, bias,  \
                            tiles, n_tiles);                                             \
     } while (0)

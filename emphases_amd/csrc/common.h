@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/emphases_hip.h"
 
 namespace emph {
@@ -23,6 +25,41 @@ inline int check_launch(const char* what) {
     if (status != hipSuccess) {
         set_error("%s: %s", what, hipGetErrorString(status));
         return static_cast<int>(status);
+    }
+    return EMPH_OK;
+}
+
+// Dynamic-LDS limit of a kernel above the 64 KiB default.  The attribute
+// belongs to each DEVICE's function object, so the "already raised" cache is
+// per (call site = kernel instantiation, device); atomics because two host
+// threads may launch at once.  hipFuncSetAttribute is not a stream operation:
+// it runs on a kernel's first launch per device only, which keeps steady-state
+// launches hipGraph-capturable.
+constexpr int kMaxDevices = 32;
+struct LdsReservation {
+    std::atomic<size_t> bytes[kMaxDevices];
+};
+
+inline int reserve_lds(LdsReservation& cache, const void* kernel, size_t lds,
+                       const char* what) {
+    if (lds <= 64 * 1024) return EMPH_OK;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) device = -1;
+    const bool cached = device >= 0 && device < kMaxDevices;
+    if (cached && lds <= cache.bytes[device].load(std::memory_order_acquire))
+        return EMPH_OK;
+    hipError_t status = hipFuncSetAttribute(
+        kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (status != hipSuccess) {
+        set_error("%s: cannot reserve %zu bytes of LDS: %s", what, lds,
+                  hipGetErrorString(status));
+        return static_cast<int>(status);
+    }
+    if (cached) {
+        size_t seen = cache.bytes[device].load(std::memory_order_relaxed);
+        while (seen < lds && !cache.bytes[device].compare_exchange_weak(
+                                 seen, lds, std::memory_order_release)) {
+        }
     }
     return EMPH_OK;
 }

@@ -803,20 +803,10 @@ int launch_conv_waves(int n_tiles, int m_blocks, size_t weight_bytes, hipStream_
                        (WAVES * 16 * patch_stride(NB) + MB * 16) * sizeof(float);
     const int patch_offset = static_cast<int>(weight_bytes / sizeof(float));
     auto kernel = conv1d_kernel<KS, MB, NB, WAVES>;
-    // raise the kernel's dynamic-LDS limit once per size (not a stream
-    // operation: kept out of the steady state so that launches stay capturable)
-    static size_t reserved = 64 * 1024;
-    if (lds > reserved) {
-        hipError_t status = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(kernel),
-            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        if (status != hipSuccess) {
-            set_error("emph_conv1d: cannot reserve %zu bytes of LDS: %s", lds,
-                      hipGetErrorString(status));
-            return static_cast<int>(status);
-        }
-        reserved = lds;
-    }
+    static LdsReservation reserved;
+    if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,
+                                 "emph_conv1d"))
+        return status;
     // persistent workgroups: LDS admits one (two for small packs) per CU
     const int groups_of_tiles = (n_tiles + WAVES - 1) / WAVES;
     const int resident = 256 * (lds > 80 * 1024 ? 1 : 2);
@@ -875,18 +865,10 @@ static int launch_winograd(const float* x, int64_t ldx, float* y, int64_t ldy,
     EMPH_REQUIRE(lds <= 160 * 1024, EMPH_ERANGE,
                  "emph_conv1d_winograd: %zu bytes of LDS needed (c_in too large)", lds);
     auto kernel = conv1d_winograd_kernel<MB, NB, WAVES>;
-    static size_t reserved = 64 * 1024;
-    if (lds > reserved) {
-        hipError_t status = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(kernel),
-            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        if (status != hipSuccess) {
-            set_error("emph_conv1d_winograd: cannot reserve %zu bytes of LDS: %s", lds,
-                      hipGetErrorString(status));
-            return static_cast<int>(status);
-        }
-        reserved = lds;
-    }
+    static LdsReservation reserved;
+    if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,
+                                 "emph_conv1d"))
+        return status;
     const int groups_of_tiles = (n_tiles + WAVES - 1) / WAVES;
     dim3 grid(groups_of_tiles < 256 ? groups_of_tiles : 256, m_blocks);
     hipLaunchKernelGGL(kernel, grid, dim3(64 * WAVES), lds, s, x, ldx, y, ldy, pack, bias, c_in,

@@ -300,17 +300,10 @@ int emph_conv1d_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
 #define EMPH_W4(M_TILES)                                                                       \
     do {                                                                                  \
         auto kernel = conv1d_winograd4_kernel<M_TILES>;                                        \
-        static size_t reserved = 64 * 1024;                                               \
-        if (lds > reserved) {                                                             \
-            hipError_t status = hipFuncSetAttribute(                                      \
-                reinterpret_cast<const void*>(kernel),                                    \
-                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));       \
-            if (status != hipSuccess) {                                                   \
-                set_error("emph_conv1d_winograd4: cannot reserve %zu bytes of LDS", lds); \
-                return static_cast<int>(status);                                          \
-            }                                                                             \
-            reserved = lds;                                                               \
-        }                                                                                 \
+        static LdsReservation reserved;                                                        \
+        if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,     \
+                                     "emph_conv1d_winograd4"))                                 \
+            return status;                                                                     \
         hipLaunchKernelGGL(kernel, grid, dim3(512), lds, s, x, ldx, y, ldy, pack, bias,   \
                            c_in, c_out, activation, tiles, n_tiles, bias_offset);         \
     } while (0)

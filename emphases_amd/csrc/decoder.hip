@@ -441,17 +441,10 @@ int emph_word_decoder(const float* x, int64_t ldx, const int32_t* tiles,
     do {                                                                            \
         auto kernel = m_tiles <= 6 ? word_decoder_kernel<KS, 3>                     \
                                    : word_decoder_kernel<KS, 4>;                    \
-        static size_t reserved[2] = {64 * 1024, 64 * 1024};                         \
-        if (lds > reserved[m_tiles <= 6]) {                                         \
-            hipError_t status = hipFuncSetAttribute(                                \
-                reinterpret_cast<const void*>(kernel),                              \
-                hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
-            if (status != hipSuccess) {                                             \
-                set_error("emph_word_decoder: cannot reserve %zu bytes of LDS", lds); \
-                return static_cast<int>(status);                                    \
-            }                                                                       \
-            reserved[m_tiles <= 6] = lds;                                           \
-        }                                                                           \
+        static LdsReservation reserved[2];                                                     \
+        if (int status = reserve_lds(reserved[m_tiles <= 6], reinterpret_cast<const void*>(kernel), lds,\
+                                     "emph_word_decoder"))                                     \
+            return status;                                                                     \
         hipLaunchKernelGGL(kernel, dim3(n_tiles), dim3(threads), lds, s, x, ldx,     \
                            tiles, block, halo, channels, packs, biases, layers,      \
                            activation, chunk_trips, out_weight, out_bias,            \

@@ -121,7 +121,7 @@ template <int D>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_kernel(
     const float* __restrict__ qk, const float* __restrict__ v,
     float* __restrict__ out, int64_t ld, int channels,
-    const int32_t* __restrict__ tiles) {
+    const int32_t* __restrict__ tiles, const int32_t* __restrict__ key_counts) {
     constexpr int QT = 4;                 // 16-query tiles per wave
     constexpr int KSTEPS = D / 4;         // k-steps of the QK^T product
     constexpr int MT = (D + 15) / 16;     // 16-row tiles of O^T
@@ -131,7 +131,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const int head = blockIdx.y;
     const Tile span = load_tile(tiles, blockIdx.x);
     const int q0 = span.first;
-    const int length = span.count;
+    const int queries = span.count;
+    // keys: all positions of the segment, or its leading `key_counts[segment]`
+    // when the rest is padding hidden by src_key_padding_mask (transformer.py:
+    // 26-29); padded positions are still computed as queries
+    const int length = key_counts != nullptr ? min(key_counts[span.segment], span.count)
+                                             : span.count;
     // softmax in base 2: log2(e) rides on the query scale, exp is v_exp_f32
     const float scale = 1.44269504088896340736f / sqrtf(static_cast<float>(D));
 
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int query = q0 + 16 * t + col;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s)
-            bq[t][s] = query < length
+            bq[t][s] = query < queries
                            ? q_rows[static_cast<int64_t>(4 * s + kk) * ld + query] * scale
                            : 0.f;
     }
@@ -258,8 +263,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int query = q0 + 16 * t + col;
-        if (query >= length) continue;
-        const float inverse = 1.f / row_sum[t];
+        if (query >= queries) continue;
+        // no key at all: softmax over an empty set is NaN, as in torch
+        const float inverse = length > 0 ? 1.f / row_sum[t] : NAN;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -312,7 +318,7 @@ int emph_add_layernorm(const float* x, const float* r, float* y, int64_t ld,
 
 int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
                    int32_t channels, int32_t heads, const int32_t* tiles,
-                   int32_t n_tiles, void* stream) {
+                   int32_t n_tiles, const int32_t* key_counts, void* stream) {
     if (n_tiles == 0) return EMPH_OK;
     EMPH_REQUIRE(qk && v && out && tiles, EMPH_EINVAL,
                  "emph_attention: null pointer");
@@ -325,15 +331,15 @@ int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
     switch (d) {
         case 32:
             hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64), 0, s, qk, v, out, ld,
-                               channels, tiles);
+                               channels, tiles, key_counts);
             break;
         case 40:
             hipLaunchKernelGGL(attention_kernel<40>, grid, dim3(64), 0, s, qk, v, out, ld,
-                               channels, tiles);
+                               channels, tiles, key_counts);
             break;
         case 64:
             hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64), 0, s, qk, v, out, ld,
-                               channels, tiles);
+                               channels, tiles, key_counts);
             break;
         default:
             set_error("emph_attention: head dimension %d not in {32, 40, 64}", d);

@@ -16,6 +16,7 @@ cache is an explicit object.
 """
 import contextlib
 import ctypes
+import threading
 
 import numpy as np
 import torch
@@ -91,6 +92,10 @@ class Engine:
         # launch stream: (name, algorithmic flops, start, end)
         self.timers = None
         self._workspace = {}
+        # forward() returns workspace buffers: callers that may run on several
+        # host threads hold this lock from pack_audio() until they have cloned
+        # the scores (core.from_alignments_and_audios does)
+        self.lock = threading.RLock()
         state = weights_module.load(state, config)
         self.state = state
         dev = self.device
@@ -282,9 +287,10 @@ class Engine:
             (runtime.AXIS_FRAMES, FRONTEND_BLOCK),
             (runtime.AXIS_FRAMES, tile),
             (runtime.AXIS_WORDS, self.word_block)]
-        if self.config.architecture == 'transformer' and not nested:
-            requests += [(runtime.AXIS_FRAMES, ATTENTION_BLOCK),
-                         (runtime.AXIS_WORDS, ATTENTION_BLOCK)]
+        if self.config.architecture == 'transformer':
+            requests += [(runtime.AXIS_FRAMES, ATTENTION_BLOCK)]
+            if not nested:
+                requests += [(runtime.AXIS_WORDS, ATTENTION_BLOCK)]
         requests = list(dict.fromkeys(requests))
         host, offsets = plan.pack_metadata(requests)
         pinned = torch.from_numpy(host)
@@ -303,14 +309,19 @@ class Engine:
                 pieces.plan, self.frame_tile(pieces.plan), nested=True)
             extra = torch.from_numpy(np.concatenate([
                 pieces.gather.view(np.int32).ravel(),
-                pieces.bounds.ravel(), pieces.word_piece]))
+                pieces.bounds.ravel(), pieces.word_piece,
+                pieces.gather[:, 1].astype(np.int32)]))
             if self.device.type == 'cuda':
                 extra = extra.pin_memory()
             extra = extra.to(self.device, non_blocking=True)
             cut = pieces.gather.size * 2
             piece_meta['gather'] = extra[:cut]
             piece_meta['piece_bounds'] = extra[cut:cut + pieces.bounds.size]
-            piece_meta['word_piece'] = extra[cut + pieces.bounds.size:]
+            cut += pieces.bounds.size
+            piece_meta['word_piece'] = extra[cut:cut + pieces.word_piece.size]
+            # frames of each piece that are the word itself (the rest of the
+            # piece is zero padding): the Transformer's key-padding mask
+            piece_meta['key_counts'] = extra[cut + pieces.word_piece.size:]
             piece_meta['plan'] = pieces.plan
             piece_meta['_extra'] = extra
             views['pieces'] = piece_meta
@@ -398,24 +409,38 @@ class Engine:
                 size // runtime.TILE_FIELDS, block, int(transpose_out),
                 runtime.stream()), 'emph_conv1d')
 
-    def features(self, audio, plan, meta, extra_rows=None):
+    def features(self, audio, plan, meta, tracks=None):
         """Feature matrix [num_features, ld_frames] of every segment
-        (`data/preprocess/core.py:71-125`).  Pitch/periodicity rows come from
-        a third-party neural tracker (`penn`) and are accepted only as
-        precomputed packed rows in `extra_rows`."""
+        (`data/preprocess/core.py:71-125`).  The pitch tracker (`penn`, a
+        third-party neural network) runs outside the library: `tracks` =
+        float32 device tensor [2, ld_frames] with its per-frame pitch (Hz) and
+        periodicity on the packed frame axis (`batch.pack_tracks`); the
+        log2 / normalisation / row placement of core.py:94-106,123 happens
+        on the device."""
         config = self.config
         rows = config.num_features
         out = self._buffer('features', rows, plan.ld_frames)
         mel_row = 0 if config.mel_feature else -1
         loud_row = rows - 1 if config.loudness_feature else -1
-        extra = int(config.pitch_feature) + int(config.periodicity_feature)
-        if extra:
-            if extra_rows is None or extra_rows.shape[0] != extra:
+        if config.pitch_feature or config.periodicity_feature:
+            if tracks is None or tuple(tracks.shape) != (2, plan.ld_frames):
                 raise NotImplementedError(
                     'pitch/periodicity features come from the third-party '
-                    '`penn` tracker; pass them precomputed as extra_rows')
+                    '`penn` tracker; pass its outputs as tracks '
+                    '[2, ld_frames] (see core.from_alignments_and_audios '
+                    'pitch_tracker=)')
             first = cfg.NUM_MELS if config.mel_feature else 0
-            out[first:first + extra] = extra_rows
+            pitch_row = first if config.pitch_feature else -1
+            periodicity_row = first + int(config.pitch_feature) \
+                if config.periodicity_feature else -1
+            with self._timed('pitch_rows'):
+                runtime.check(self.lib.emph_pitch_rows(
+                    tracks[0].data_ptr(), tracks[1].data_ptr(),
+                    out.data_ptr(), plan.ld_frames, pitch_row,
+                    periodicity_row, int(config.normalize),
+                    float(np.log2(np.float32(cfg.FMIN))),
+                    float(np.log2(np.float32(cfg.FMAX))), runtime.stream()),
+                    'emph_pitch_rows')
         tiles, size = meta[('tiles', runtime.AXIS_FRAMES, FRONTEND_BLOCK)]
         count = size // runtime.TILE_FIELDS
         table = meta['table'][0]
@@ -441,8 +466,11 @@ class Engine:
                     runtime.stream()), 'emph_logmel')
         return out
 
-    def _transformer(self, layers, x, ld, plan, meta, axis, block, tag):
-        """`Transformer.forward` (transformer.py:25-30) in place on x."""
+    def _transformer(self, layers, x, ld, plan, meta, axis, block, tag,
+                     key_counts=None):
+        """`Transformer.forward` (transformer.py:25-30) in place on x.
+        `key_counts`: int32 device tensor, real (unpadded) positions per
+        segment, for the key-padding mask over zero-padded word pieces."""
         config = self.config
         channels = config.channels
         att_tiles, att_size = meta[('tiles', axis, ATTENTION_BLOCK)]
@@ -494,6 +522,7 @@ class Engine:
                 runtime.check(self.lib.emph_attention(
                     qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld,
                     channels, config.heads, att_tiles.data_ptr(), att_count,
+                    None if key_counts is None else key_counts.data_ptr(),
                     runtime.stream()), 'emph_attention')
             if layer['block'] is not None and block <= 32:
                 packs, vectors = layer['block']
@@ -518,7 +547,7 @@ class Engine:
         return x
 
     def _stack_forward(self, layers, x, other, ld, plan, meta, axis, block,
-                       tag):
+                       tag, key_counts=None):
         """Frame encoder / word decoder; returns the tensor holding the
         result (x or other)."""
         config = self.config
@@ -528,14 +557,15 @@ class Engine:
                            config.activation)
                 x, other = other, x
             return x
-        return self._transformer(layers, x, ld, plan, meta, axis, block, tag)
+        return self._transformer(
+            layers, x, ld, plan, meta, axis, block, tag, key_counts)
 
     ###########################################################################
     # Forward
     ###########################################################################
 
     def forward(self, audio, plan, meta=None, stages=None, features=None,
-                extra_rows=None):
+                tracks=None):
         """Scores of every word of every segment.
 
         audio: float32 device tensor, all utterances back to back.
@@ -576,7 +606,7 @@ class Engine:
                 runtime.stream()), 'emph_prominence_forward')
             return scores, logits
         if features is None:
-            features = self.features(audio, plan, meta, extra_rows=extra_rows)
+            features = self.features(audio, plan, meta, tracks=tracks)
         table = meta['table'][0]
         logits = self._buffer('logits', ld_w)
         scores = self._buffer('scores', ld_w)
@@ -585,10 +615,6 @@ class Engine:
             # model/core.py:41-87: gather every word into its own zero-padded
             # piece, encode the pieces as independent sequences, pool each
             # over its padded length into the word's column
-            if config.architecture != 'convolution':
-                raise NotImplementedError(
-                    "DOWNSAMPLE_LOCATION='input' is built for the "
-                    'convolutional encoder only')
             if stages is not None:
                 stages['features'] = features.clone()
             piece_meta = meta['pieces']
@@ -608,7 +634,9 @@ class Engine:
                        frames, piece_meta['tile'], None)
             encoded = self._stack_forward(
                 self.frame_encoder, a, b, ld_p, piece_plan, piece_meta,
-                frames, piece_meta['tile'], 'frames')
+                frames, piece_meta['tile'], 'pieces',
+                key_counts=piece_meta['key_counts']
+                if config.architecture == 'transformer' else None)
             with self._timed('segment_reduce'):
                 runtime.check(self.lib.emph_segment_reduce(
                     encoded.data_ptr(), ld_p,
@@ -695,7 +723,16 @@ class Engine:
         # query events while this thread captures
         with torch.cuda.graph(graph, capture_error_mode='thread_local'):
             scores, logits = self.forward(audio, plan, meta)
-        return graph.replay, scores, logits
+        # the graph holds raw pointers into the workspace (allocated by the
+        # warm-up, outside the graph's pool): keep those tensors alive for as
+        # long as the replay closure lives, even if a later forward() with
+        # another layout drops them from the workspace
+        held = (list(self._workspace.values()), meta, audio)
+
+        def replay():
+            graph.replay()
+            return held[0] is not None
+        return replay, scores, logits
 
 
 def check_bounds(plan, method):

@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -40,6 +40,8 @@ SIGNATURES = {
         _i32, _i32, _ptr, _ptr, _i32, _ptr]),
     'emph_frontend_peak': (_c.c_int, [
         _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr]),
+    'emph_pitch_rows': (_c.c_int, [
+        _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _f32, _f32, _ptr]),
     'emph_conv_pack_size': (_i64, [_i32, _i32, _i32]),
     'emph_conv_pack': (_c.c_int, [_ptr, _i32, _i32, _i32, _ptr]),
     'emph_conv1d': (_c.c_int, [
@@ -84,7 +86,7 @@ SIGNATURES = {
     'emph_add_position': (_c.c_int, [
         _ptr, _i64, _ptr, _i32, _i32, _ptr, _i32, _i32, _ptr]),
     'emph_attention': (_c.c_int, [
-        _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i32, _ptr]),
+        _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i32, _ptr, _ptr]),
     'emph_add_layernorm': (_c.c_int, [
         _ptr, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _f32, _i64, _i64, _ptr]),
 }

@@ -65,6 +65,25 @@ def pcm_to_float(pcm):
     return (pcm.astype(np.float32) / np.float32(32768.0))[None]
 
 
+def pitch_tracks(audio, *args, **kwargs):
+    """Deterministic stand-in for `penn.from_audio` (a third-party neural
+    pitch tracker the reference calls at `data/preprocess/core.py:84-92`):
+    per-frame pitch in [80, 380) Hz and periodicity in [0, 1) derived from the
+    frame energy of `audio` [1, S].  Same signature tail as penn so that it can
+    be patched over it when the goldens are captured; returns torch tensors
+    [1, S // 160] like penn with `pad=True`."""
+    import torch
+    x = np.asarray(
+        audio.detach().cpu() if hasattr(audio, 'detach') else audio,
+        dtype=np.float32).reshape(-1)
+    frames = x.size // cfg.HOPSIZE
+    x = x[:frames * cfg.HOPSIZE].reshape(frames, cfg.HOPSIZE).astype(np.float64)
+    rms = np.sqrt((x * x).mean(axis=1))
+    pitch = (80.0 + 300.0 * rms / (rms + 0.05)).astype(np.float32)
+    periodicity = (rms / (rms + 0.02)).astype(np.float32)
+    return torch.from_numpy(pitch)[None], torch.from_numpy(periodicity)[None]
+
+
 def word_frames(index, frames, low=8, high=60):
     """Word boundaries in integer frames: int64 [2, W], gap-free, first start
     0, last end `frames`."""

@@ -96,6 +96,7 @@ def load(checkpoint=None, config=cfg.DEFAULT):
         import torch
         raw = torch.load(checkpoint, map_location='cpu', weights_only=False)
         raw = raw['model'] if 'model' in raw else raw
+    raw = _renumber(raw, config)
     state = collections.OrderedDict()
     for name, shape in parameter_shapes(config).items():
         if name not in raw:
@@ -109,6 +110,33 @@ def load(checkpoint=None, config=cfg.DEFAULT):
                 f'expected {tuple(shape)}')
         state[name] = np.ascontiguousarray(value, dtype=np.float32)
     return state
+
+
+def _renumber(raw, config):
+    """Map the Sequential indices of a conv stack onto layer numbers.  The
+    reference's `Convolution` is `Sequential(conv, activation[, Dropout])` per
+    layer (`convolution.py:25-33`): checkpoints of the dropout configs
+    (`config/hparam-search/dropout-{05,10}.py`) keep layer i at index 3 i, not
+    2 i.  Dropout is the identity at inference, so only the names differ."""
+    if config.architecture != 'convolution':
+        return raw
+    import re
+    renamed = dict(raw)
+    for prefix in ('frame_encoder', 'word_decoder'):
+        pattern = re.compile(rf'^{prefix}\.(\d+)\.weight$')
+        indices = sorted(
+            int(m.group(1)) for m in map(pattern.match, raw) if m)
+        if indices == [2 * i for i in range(len(indices))]:
+            continue
+        for layer, index in enumerate(indices):
+            for kind in ('weight', 'bias'):
+                old = f'{prefix}.{index}.{kind}'
+                renamed.pop(old, None)
+            for kind in ('weight', 'bias'):
+                old = f'{prefix}.{index}.{kind}'
+                if old in raw:
+                    renamed[f'{prefix}.{2 * layer}.{kind}'] = raw[old]
+    return renamed
 
 
 def positional_encoding(length, channels):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 11
+#define EMPH_ABI_VERSION 12
 
 /* Segment-table fields */
 enum {
@@ -147,6 +147,27 @@ int emph_logmel(const float* audio, const int64_t* seg, const int32_t* tiles,
 int emph_frontend_peak(const float* audio, const int64_t* seg,
                        const int32_t* tiles, int32_t n_tiles,
                        const float* table, float* seg_peak, void* stream);
+
+/* Pitch / periodicity rows of the feature matrix.
+ *
+ * Replaces what emphases/data/preprocess/core.py:94-106,123 does with the
+ * outputs of the pitch tracker (`penn.from_audio`, core.py:84-92 — a third-party
+ * neural network that stays outside this library): torch.log2(pitch), or
+ * (log2(pitch) - LOGFMIN) / (LOGFMAX - LOGFMIN) under NORMALIZE
+ * (config/static.py:33-36), the periodicity row as it is, and the torch.cat
+ * that puts them under the mel rows.
+ *
+ *   pitch, periodicity  float32 [ld]  tracker outputs on the packed frame axis
+ *                                     (Hz; columns outside segments are ignored
+ *                                     downstream and may hold anything)
+ *   out                 float32 [rows, ld]  feature matrix
+ *   pitch_row, periodicity_row        destination rows, or -1 to skip
+ *   logfmin, logfmax    float32 log2(FMIN), log2(FMAX)
+ * ld must be a multiple of 4 and the rows 16-byte aligned. */
+int emph_pitch_rows(const float* pitch, const float* periodicity, float* out,
+                    int64_t ld, int32_t pitch_row, int32_t periodicity_row,
+                    int32_t normalize, float logfmin, float logfmax,
+                    void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Conv1d 'same' (+ bias + activation) over ragged segments, fp32 MFMA       */
@@ -326,11 +347,18 @@ int emph_add_position(float* x, int64_t ldx, const float* table,
  *   v    float32 [ld, channels]     position-major V
  *   out  float32 [channels, ld]
  *   tiles int32 [n_tiles][4]        tile table, block = 64 queries
+ *   key_counts int32 [n_seg] or NULL  src_key_padding_mask (transformer.py:
+ *                                   26-29) as the number of leading positions
+ *                                   of each segment that are real keys; the
+ *                                   rest (zero padding of the word pieces of
+ *                                   DOWNSAMPLE_LOCATION 'input', model/core.py:
+ *                                   41-87) is hidden as keys but still computed
+ *                                   as queries.  NULL: every position is a key.
  * Head dimension (channels / heads) must be 32, 40 or 64.
  */
 int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
                    int32_t channels, int32_t heads, const int32_t* tiles,
-                   int32_t n_tiles, void* stream);
+                   int32_t n_tiles, const int32_t* key_counts, void* stream);
 
 /* y = LayerNorm(x + r) over channels for columns [first_column,
  * first_column + columns) (post-LN residual of nn.TransformerEncoderLayer,

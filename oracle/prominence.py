@@ -170,17 +170,29 @@ def loudness(audio, normalize=False):
     return result
 
 
-def features(audio, cfg, extra_rows=None):
+def features(audio, cfg, pitch_tracker=None):
     """data/preprocess/core.py:71-125 -> [1, NUM_FEATURES, F].  Pitch and
-    periodicity come from `penn` (a neural tracker, not restatable): accepted
-    only as precomputed `extra_rows`."""
+    periodicity come from `penn` (a neural tracker, not restatable):
+    `pitch_tracker(audio [1, S]) -> (pitch [1, F] Hz, periodicity [1, F])`
+    stands in for `penn.from_audio` (core.py:84-92); what the reference does
+    with its outputs (core.py:94-106) is restated here."""
     rows = []
     if cfg.get('mel_feature', True):
         rows.append(logmel(audio, cfg.get('normalize', False)))
     if cfg.get('pitch_feature') or cfg.get('periodicity_feature'):
-        if extra_rows is None:
+        if pitch_tracker is None:
             raise NotImplementedError('penn pitch is third-party')
-        rows.extend(extra_rows)
+        pitch, periodicity = pitch_tracker(audio)
+        if cfg.get('pitch_feature'):
+            if cfg.get('normalize', False):
+                logfmin = torch.log2(torch.tensor(40.))     # static.py:33-36
+                logfmax = torch.log2(torch.tensor(550.))
+                rows.append(
+                    (torch.log2(pitch) - logfmin) / (logfmax - logfmin))
+            else:
+                rows.append(torch.log2(pitch))
+        if cfg.get('periodicity_feature'):
+            rows.append(periodicity)
     if cfg.get('loudness_feature'):
         rows.append(loudness(audio, cfg.get('normalize', False)))
     return (rows[0] if len(rows) == 1 else torch.cat(rows))[None]
@@ -264,10 +276,13 @@ def layer_norm(x, weight, bias, eps=1e-5):
         x, (x.shape[-1],), weight, bias, eps)
 
 
-def transformer_stack(x, state, prefix, layers, heads=2):
-    """transformer.py:25-30 for one unpadded sequence: x [C, T] -> [C, T].
+def transformer_stack(x, state, prefix, layers, heads=2, valid=None):
+    """transformer.py:25-30 for one sequence: x [C, T] -> [C, T].
     `nn.TransformerEncoderLayer` defaults: post-LN, ReLU, eps 1e-5; dropout is
-    the identity in eval mode."""
+    the identity in eval mode.  `valid`: number of leading positions that are
+    real; the rest are padding that `src_key_padding_mask` hides as KEYS
+    (transformer.py:26-29) while they are still computed as queries — only the
+    zero-padded word pieces of DOWNSAMPLE_LOCATION='input' have any."""
     channels, length = x.shape
     head_dim = channels // heads
     h = x.T + positional_encoding(length, channels)            # [T, C]
@@ -280,6 +295,8 @@ def transformer_stack(x, state, prefix, layers, heads=2):
         k = k.reshape(length, heads, head_dim).transpose(0, 1)
         v = v.reshape(length, heads, head_dim).transpose(0, 1)
         scores = (q / math.sqrt(head_dim)) @ k.transpose(1, 2)
+        if valid is not None and valid < length:
+            scores[:, :, valid:] = float('-inf')
         attention = torch.softmax(scores, dim=-1) @ v          # [H, T, D]
         attention = attention.transpose(0, 1).reshape(length, channels)
         attention = attention @ state[p + 'self_attn.out_proj.weight'].T + \
@@ -294,12 +311,13 @@ def transformer_stack(x, state, prefix, layers, heads=2):
     return h.T
 
 
-def stack(x, state, prefix, cfg):
+def stack(x, state, prefix, cfg, valid=None):
     if cfg.get('architecture', 'convolution') == 'convolution':
         return conv_stack(
             x, state, prefix, cfg.get('layers', 6),
             cfg.get('activation', 'relu'))
-    return transformer_stack(x, state, prefix, cfg.get('layers', 6))
+    return transformer_stack(
+        x, state, prefix, cfg.get('layers', 6), valid=valid)
 
 
 ###############################################################################
@@ -330,7 +348,7 @@ def forward(feats, bounds, state, cfg=None, stages=None):
             embedding = stack(
                 conv(piece, state['input_layer.weight'],
                      state['input_layer.bias']),
-                state, 'frame_encoder', cfg)
+                state, 'frame_encoder', cfg, valid=int(lengths[j]))
             if method == 'average':
                 words.append(embedding.mean(dim=1))
             elif method == 'max':
@@ -378,7 +396,8 @@ def postprocess(logits, loss='bce'):
 ###############################################################################
 
 
-def from_alignment_and_audio(words, audio, state, cfg=None, batch_size=None):
+def from_alignment_and_audio(words, audio, state, cfg=None, batch_size=None,
+                             pitch_tracker=None):
     """words: [(start_s, end_s)], audio float32 [1, S] at 16 kHz.
     Returns scores float32 [1, sum Wc]."""
     cfg = cfg or {}
@@ -390,7 +409,7 @@ def from_alignment_and_audio(words, audio, state, cfg=None, batch_size=None):
             if chunk['dropped']:
                 continue
             piece = padded[:, chunk['start_sample']:chunk['end_sample']]
-            feats = features(piece, cfg)[0]
+            feats = features(piece, cfg, pitch_tracker)[0]
             logits = forward(feats, chunk['bounds'], state, cfg)
             scores.append(postprocess(logits, cfg.get('loss', 'bce'))[None])
     return torch.cat(scores, 1)

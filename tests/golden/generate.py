@@ -286,10 +286,25 @@ def variant_list():
     variants += [dict(loss='mse'), dict(normalize=True),
                  dict(loudness_feature=True),
                  dict(loudness_feature=True, normalize=True)]
+    # pitch / periodicity rows: `penn.from_audio` is patched with
+    # synth.pitch_tracks (the tracker itself is third-party and absent)
+    variants += [dict(pitch_feature=True, periodicity_feature=True),
+                 dict(pitch_feature=True, periodicity_feature=True,
+                      normalize=True),
+                 dict(pitch_feature=True, periodicity_feature=True,
+                      loudness_feature=True),
+                 dict(periodicity_feature=True)]
     variants += [dict(architecture='transformer'),
                  dict(architecture='transformer',
                       downsample_location='inference',
-                      downsample_method='average')]
+                      downsample_method='average'),
+                 # key-padding mask over zero-padded word pieces
+                 # (transformer.py:26-29 with model/core.py:41-87)
+                 dict(architecture='transformer',
+                      downsample_location='input'),
+                 dict(architecture='transformer',
+                      downsample_location='input',
+                      downsample_method='center')]
     return variants
 
 
@@ -310,10 +325,14 @@ def configure_reference(config):
     emphases.LOSS = config.loss
     emphases.NORMALIZE = config.normalize
     emphases.LOUDNESS_FEATURE = config.loudness_feature
+    emphases.PITCH_FEATURE = config.pitch_feature
+    emphases.PERIODICITY_FEATURE = config.periodicity_feature
     emphases.NUM_FEATURES = config.num_features
 
 
 def capture_variants(out):
+    import penn
+    penn.from_audio = synth.pitch_tracks
     frames = 300
     audio = synth.audio(4, frames)
     bounds = synth.word_frames(4, frames, 3, 40)
@@ -338,13 +357,11 @@ def capture_variants(out):
         assert len(stages) == 1
         out[f'{name}/logits'] = stages[0]['logits']
         out[f'{name}/scores'] = stages[0]['scores']
-        if config.loudness_feature:
+        if config.loudness_feature or config.pitch_feature or \
+                config.periodicity_feature:
             out[f'{name}/features'] = stages[0]['features']
         cfg_dict = {k: getattr(config, k) for k in overrides}
-        if config.architecture == 'transformer' and \
-                config.downsample_location == 'input':
-            delta = float('nan')
-        else:
+        if True:
             mine = oracle.forward(
                 torch.from_numpy(stages[0]['features']), stages[0]['bounds'],
                 {k: torch.from_numpy(v) for k, v in state.items()},

@@ -35,7 +35,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, queue):
+def _worker(rank, world, port, queue, frames=(300, 120, 450, 80, 200)):
     sys.path.insert(0, ROOT)
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -46,7 +46,7 @@ def _worker(rank, world, port, queue):
         from emphases_amd import synth, weights
         from oracle import prominence as oracle
         state = {k: torch.from_numpy(v) for k, v in weights.load().items()}
-        frames = [300, 120, 450, 80, 200]
+        frames = list(frames)
         audios = [torch.from_numpy(synth.audio(i, n))
                   for i, n in enumerate(frames)]
         bounds = [synth.word_frames(i, n, 3, 40) for i, n in enumerate(frames)]
@@ -61,11 +61,12 @@ def _worker(rank, world, port, queue):
 
         scores = edist.from_alignments_and_audios(
             aligns, audios, compute=compute)
+        shard_calls = list(calls)
         reference = compute(aligns, audios)
         worst = max(
             float((a - b).abs().max()) for a, b in zip(scores, reference))
         shapes = [tuple(s.shape) for s in scores]
-        queue.put((rank, calls[0], worst, shapes,
+        queue.put((rank, shard_calls[0] if shard_calls else 0, worst, shapes,
                    [b.shape[1] for b in bounds]))
     finally:
         torch.distributed.destroy_process_group()
@@ -89,4 +90,26 @@ def test_two_rank_gather_equals_single_process():
     assert sum(shard_sizes) == 5 and shard_sizes[0] >= 2
     for rank, _, worst, shapes, words in results:
         assert worst == 0.0            # no arithmetic crosses a rank boundary
+        assert shapes == [(1, w) for w in words]
+
+
+@pytest.mark.timeout(300)
+def test_more_ranks_than_utterances():
+    """LPT leaves ranks empty when world_size > utterances: the collective's
+    device comes from the backend, not from the (absent) data."""
+    world = 3
+    context = mp.get_context('spawn')
+    queue = context.Queue()
+    port = _free_port()
+    workers = [context.Process(
+        target=_worker, args=(r, world, port, queue, (150, 90)))
+        for r in range(world)]
+    for worker in workers:
+        worker.start()
+    results = [queue.get(timeout=240) for _ in workers]
+    for worker in workers:
+        worker.join(timeout=60)
+        assert worker.exitcode == 0
+    for rank, _, worst, shapes, words in results:
+        assert worst == 0.0
         assert shapes == [(1, w) for w in words]

@@ -1,0 +1,89 @@
+"""The HIP engine under N > 1 ranks (BASELINE configs[3]): fresh
+child processes, one per rank, running `dist.from_alignments_and_audios` with
+its DEFAULT compute.  The GPU box has one MI355X, so the two gloo ranks share
+`cuda:0` (LOCAL_RANK modulo the device count); a world_size-1 `nccl` run takes
+RCCL initialisation and the device-tensor all_gather through once.  The
+scores must be bitwise those of a single-process run: no arithmetic crosses a
+rank boundary."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+import emphases_amd
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+WORKER = os.path.join(ROOT, 'tests', 'dist_worker.py')
+COUNT, LOW, HIGH = 200, 200, 3000        # 2-30 s utterances
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _launch(backend, world, tmp_path, count=COUNT):
+    port = _free_port()
+    children = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        out = tmp_path / f'{backend}_{rank}.pt'
+        children.append((out, subprocess.Popen(
+            [sys.executable, WORKER, backend, str(count), str(LOW),
+             str(HIGH), str(out)], env=env, cwd=ROOT)))
+    results = []
+    for out, child in children:
+        assert child.wait(timeout=600) == 0
+        results.append(torch.load(out))
+    return results
+
+
+@pytest.fixture(scope='module')
+def single_process():
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import dist_worker
+    aligns, audios = dist_worker.corpus(COUNT, LOW, HIGH)
+    scores = emphases_amd.from_alignments_and_audios(aligns, audios, gpu=0)
+    return [s.cpu() for s in scores], aligns
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_share_one_gpu(tmp_path, single_process):
+    want, aligns = single_process
+    results = _launch('gloo', 2, tmp_path)
+    assert sum(r['shard'] for r in results) == COUNT
+    assert min(r['shard'] for r in results) >= COUNT // 2 - 20
+    for result in results:
+        assert result['device'] == 'cpu'          # gloo gathers on the host
+        assert len(result['scores']) == COUNT
+        for got, expect, words in zip(result['scores'], want, aligns):
+            assert got.shape == (1, len(words))
+            assert torch.equal(got, expect)       # bitwise
+
+
+@pytest.mark.timeout(900)
+def test_one_rank_rccl(tmp_path, single_process):
+    want, _ = single_process
+    (result,) = _launch('nccl', 1, tmp_path)
+    assert result['device'].startswith('cuda')    # RCCL gathers device tensors
+    for got, expect in zip(result['scores'], want):
+        assert torch.equal(got, expect)
+
+
+@pytest.mark.timeout(900)
+def test_more_ranks_than_utterances(tmp_path):
+    """Three ranks, two utterances: a rank with an empty shard still joins the
+    collectives on the right device."""
+    results = _launch('gloo', 3, tmp_path, count=2)
+    assert sorted(r['shard'] for r in results) == [0, 1, 1]
+    for result in results[1:]:
+        for a, b in zip(result['scores'], results[0]['scores']):
+            assert torch.equal(a, b)

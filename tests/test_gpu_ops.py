@@ -412,17 +412,35 @@ def test_attention(channels, heads):
     qk_dev, v_dev = qk.to(DEVICE), v.to(DEVICE)
     runtime.check(lib.emph_attention(
         qk_dev.data_ptr(), v_dev.data_ptr(), out.data_ptr(), ld,
-        channels, heads, tiles.data_ptr(), size // 4, None), 'emph_attention')
+        channels, heads, tiles.data_ptr(), size // 4, None, None),
+        'emph_attention')
     out = out.cpu()
     d = channels // heads
-    for off, count in spans(plan, axis):
+
+    def reference(off, count, keys):
         q = qk[:channels, off:off + count].T.reshape(count, heads, d)
-        k = qk[channels:, off:off + count].T.reshape(count, heads, d)
-        vv = v[off:off + count].reshape(count, heads, d)
+        k = qk[channels:, off:off + keys].T.reshape(keys, heads, d)
+        vv = v[off:off + keys].reshape(keys, heads, d)
         scores = torch.einsum('qhd,khd->hqk', q, k) / np.sqrt(d)
-        want = torch.einsum(
+        return torch.einsum(
             'hqk,khd->qhd', torch.softmax(scores, -1), vv).reshape(
                 count, channels).T
+
+    for off, count in spans(plan, axis):
+        want = reference(off, count, count)
+        assert float((out[:, off:off + count] - want).abs().max()) < 2e-5
+    # key-padding mask (transformer.py:26-29): only the leading key_counts[s]
+    # positions of a segment are keys; every position is still a query
+    key_counts = np.array([50, 16, 1, 333, 17], dtype=np.int32)
+    counts_dev = torch.from_numpy(key_counts).to(DEVICE)
+    out = torch.zeros((channels, ld), device=DEVICE)
+    runtime.check(lib.emph_attention(
+        qk_dev.data_ptr(), v_dev.data_ptr(), out.data_ptr(), ld,
+        channels, heads, tiles.data_ptr(), size // 4, counts_dev.data_ptr(),
+        None), 'emph_attention')
+    out = out.cpu()
+    for (off, count), keys in zip(spans(plan, axis), key_counts):
+        want = reference(off, count, int(keys))
         assert float((out[:, off:off + count] - want).abs().max()) < 2e-5
 
 
@@ -540,3 +558,148 @@ def test_qkv_projection(channels, tile):
                       want[2 * channels:]).abs().max()) < 2e-5
     assert float(qk[:, :batch.LEAD].min()) == 7.0
     assert float(v[:batch.LEAD].min()) == 7.0
+
+
+###############################################################################
+# feature rows
+###############################################################################
+
+
+@pytest.mark.parametrize('normalize', [False, True])
+def test_pitch_rows(normalize):
+    """emph_pitch_rows against the torch ops of data/preprocess/core.py:94-106."""
+    lib = runtime.library()
+    ld = 1000 + 144
+    pitch = torch.from_numpy(40.0 + 510.0 * np.abs(
+        synth.weights(71, (ld,), 1.0)))
+    periodicity = torch.from_numpy(np.abs(synth.weights(72, (ld,), 1.0)))
+    out = torch.full((83, ld), 5.0, device=DEVICE)
+    pitch_dev, periodicity_dev = pitch.to(DEVICE), periodicity.to(DEVICE)
+    logfmin = torch.log2(torch.tensor(40.))
+    logfmax = torch.log2(torch.tensor(550.))
+    runtime.check(lib.emph_pitch_rows(
+        pitch_dev.data_ptr(), periodicity_dev.data_ptr(), out.data_ptr(), ld,
+        80, 81, int(normalize), float(logfmin), float(logfmax), None),
+        'emph_pitch_rows')
+    out = out.cpu()
+    want = torch.log2(pitch)
+    if normalize:
+        want = (want - logfmin) / (logfmax - logfmin)
+    assert float((out[80] - want).abs().max()) < 1e-6
+    assert torch.equal(out[81], periodicity)
+    assert float(out[:80].min()) == 5.0 and float(out[82].min()) == 5.0
+    # periodicity only, in row 80 (PITCH_FEATURE off)
+    out = torch.full((81, ld), 5.0, device=DEVICE)
+    runtime.check(lib.emph_pitch_rows(
+        None, periodicity_dev.data_ptr(), out.data_ptr(), ld, -1, 80, 0,
+        float(logfmin), float(logfmax), None), 'emph_pitch_rows')
+    assert torch.equal(out[80].cpu(), periodicity)
+    assert lib.emph_pitch_rows(
+        None, None, out.data_ptr(), ld, 80, -1, 0, 0., 1., None) == -1
+
+
+def test_logmel_against_torch_stft():
+    """emph_logmel alone against the ATen ops of mels.py:16-109 (reflect pad,
+    torch.stft, magnitude, mel matmul, log) on ragged chunks: a chunk that
+    starts inside the zero padding, one that ends in it, a minimal 433-sample
+    chunk, and interior chunks of one utterance."""
+    from emphases_amd import engine as engine_module, melbasis
+    engine = engine_module.Engine(device=0)
+    lib = runtime.library()
+    samples = 160 * 230
+    audio = torch.from_numpy(synth.audio(61, 230))[0]
+    padded = torch.nn.functional.pad(audio, (432, 432))
+    # (start in the padded signal, length)
+    chunks = [(0, 160 * 50), (160 * 50, 160 * 77), (160 * 127, 433),
+              (160 * 130, samples + 864 - 160 * 130), (160 * 3, 160 * 200 + 7)]
+    segments = [batch.Segment(
+        0, 0, 1, start, length, 1 + (length + 864 - 1024) // 160,
+        np.array([[0], [1]], dtype=np.int64)) for start, length in chunks]
+    plan = batch.Plan(segments, [0], [samples])
+    meta = engine.upload(plan)
+    features = engine.features(audio.to(DEVICE), plan, meta).cpu()
+    basis = torch.from_numpy(melbasis.default().dense)
+    window = torch.hann_window(1024)
+    for (start, length), off, count in zip(
+            chunks, plan.frame_off, plan.frames):
+        piece = torch.nn.functional.pad(
+            padded[None, None, start:start + length], (432, 432),
+            mode='reflect')[0, 0]
+        spectrum = torch.stft(
+            piece, 1024, hop_length=160, window=window, center=False,
+            return_complex=True)
+        magnitude = torch.sqrt(
+            torch.view_as_real(spectrum).pow(2).sum(-1) + 1e-6)
+        want = torch.log(torch.clamp(basis @ magnitude, min=1e-5))
+        assert want.shape == (80, count)
+        got = features[:, off:off + count]
+        assert float((got - want).abs().max()) < 5e-4
+        loud = want > -6.0          # away from the 1e-6 magnitude floor
+        assert float((got - want)[loud].abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize('kernel_size,layers,activation,post', [
+    (3, 6, 'relu', 'bce'), (5, 6, 'gelu', 'mse'), (1, 6, 'silu', 'bce'),
+    (3, 0, 'relu', 'bce'), (5, 3, 'leaky_relu', None)])
+def test_word_decoder(kernel_size, layers, activation, post):
+    """emph_word_decoder alone against torch conv1d stacks: segments shorter
+    than, equal to and several times longer than the workgroup's word window
+    (halo recompute between windows), NaN in the padding columns."""
+    lib = runtime.library()
+    channels = 80
+    block = int(lib.emph_word_decoder_block(layers, kernel_size, kernel_size))
+    counts = [block, 1, 2, block + 1, 3 * block + 5, 7, 2 * block]
+    bounds = [np.stack([np.arange(n), np.arange(n) + 1]).astype(np.int64)
+              for n in counts]
+    plan = ragged_plan(counts, bounds)
+    axis = runtime.AXIS_WORDS
+    meta = Meta(plan, [(axis, block)])
+    x = random_packed(channels, plan, axis, 81) * 2.0
+    valid = np.zeros(plan.ld_words, dtype=bool)
+    for off, count in spans(plan, axis):
+        valid[off:off + count] = True
+    x[:, ~valid] = float('nan')
+    weights_ = [synth.weights(90 + i, (channels, channels, kernel_size),
+                              (2.0 / (channels * kernel_size)) ** 0.5 * 1.7)
+                for i in range(layers)]
+    biases = [synth.weights(100 + i, (channels,), 0.1) for i in range(layers)]
+    out_w = synth.weights(110, (1, channels, kernel_size), 0.2)
+    out_b = synth.weights(111, (1,), 0.2)
+    packs = torch.from_numpy(np.concatenate(
+        [runtime.word_decoder_pack(w) for w in weights_])).to(DEVICE) \
+        if layers else None
+    bias_dev = torch.from_numpy(np.concatenate(biases)).to(DEVICE) \
+        if layers else None
+    logits = torch.full((plan.ld_words,), 9.0, device=DEVICE)
+    scores = torch.full((plan.ld_words,), 9.0, device=DEVICE)
+    tiles, size = meta.view(('tiles', axis, block))
+    x_dev = x.to(DEVICE)
+    out_w_dev = torch.from_numpy(out_w).to(DEVICE)
+    out_b_dev = torch.from_numpy(out_b).to(DEVICE)
+    runtime.check(lib.emph_word_decoder(
+        x_dev.data_ptr(), plan.ld_words, tiles.data_ptr(), size // 4,
+        channels, None if packs is None else packs.data_ptr(),
+        None if bias_dev is None else bias_dev.data_ptr(), layers,
+        kernel_size, runtime.ACTIVATIONS[activation], out_w_dev.data_ptr(),
+        out_b_dev.data_ptr(), kernel_size, runtime.POSTPROCESS[post],
+        logits.data_ptr(), scores.data_ptr(), None), 'emph_word_decoder')
+    logits, scores = logits.cpu(), scores.cpu()
+    pad = (kernel_size - 1) // 2
+    for off, count in spans(plan, axis):
+        h = x[None, :, off:off + count]
+        for w, b in zip(weights_, biases):
+            h = ACTIVATIONS[activation](torch.nn.functional.conv1d(
+                h, torch.from_numpy(w), torch.from_numpy(b), padding=pad))
+        want = torch.nn.functional.conv1d(
+            h, torch.from_numpy(out_w), torch.from_numpy(out_b),
+            padding=pad)[0, 0]
+        got = logits[off:off + count]
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) < 2e-5 * scale
+        if post == 'bce':
+            assert float((scores[off:off + count] -
+                          torch.sigmoid(want)).abs().max()) < 1e-5
+        elif post == 'mse':
+            assert float((scores[off:off + count] -
+                          want.clamp(0., 1.)).abs().max()) < 2e-5 * scale
+    assert float(logits[~torch.from_numpy(valid)].min()) == 9.0

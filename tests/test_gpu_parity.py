@@ -33,9 +33,16 @@ def run_case(engine, audio, bounds, batch_size, stages=None, tile=None):
     segments = batch.chunk_utterance(words, audio.shape[1], batch_size)
     plan = batch.Plan(segments, [0], [audio.shape[1]])
     meta = engine.upload(plan, tile)
+    tracks = None
+    if engine.config.pitch_feature or engine.config.periodicity_feature:
+        # the stand-in for penn.from_audio the goldens were captured with
+        tracks = torch.from_numpy(batch.pack_tracks(plan, [
+            synth.pitch_tracks(batch.chunk_audio(
+                torch.from_numpy(audio[0]), segment))
+            for segment in plan.segments])).to(engine.device)
     scores, logits = engine.forward(
         torch.from_numpy(audio[0]).to(engine.device), plan, meta,
-        stages=stages)
+        stages=stages, tracks=tracks)
     return plan, scores, logits
 
 
@@ -150,7 +157,60 @@ def test_variant_matrix(variants):
         assert np.abs(scores.cpu().numpy()[columns] -
                       variants[f'{name}/scores']).max() < SCORE_TOLERANCE, name
         checked += 1
-    assert checked == 33
+    assert checked == 39
+
+
+def test_pitch_and_periodicity_rows(variants):
+    """Feature rows 80.. built from the pitch tracker's outputs
+    (`data/preprocess/core.py:83-113`; the tracker is `synth.pitch_tracks`, as
+    when the goldens were captured): log2 / normalised pitch, periodicity,
+    loudness last (`static.py:42-46` NUM_FEATURES 81-83)."""
+    audio = synth.pcm_to_float(variants['audio_pcm'])
+    bounds = variants['bounds_frames'].astype(np.int64)
+    seen = 0
+    for name in variants['names']:
+        config, _ = variant_config(name)
+        if not (config.pitch_feature or config.periodicity_feature):
+            continue
+        engine = engine_module.Engine(
+            config, weights.random_state(config, seed=7), 0)
+        assert engine.model is None        # the step-by-step path
+        stages = {}
+        plan, _, _ = run_case(engine, audio, bounds, None, stages)
+        got = stages['features'].cpu().numpy()[:, frame_columns(plan)]
+        want = variants[f'{name}/features']
+        assert got.shape == want.shape == (config.num_features, 300)
+        extra = int(config.pitch_feature) + int(config.periodicity_feature)
+        np.testing.assert_allclose(
+            got[80:80 + extra], want[80:80 + extra], atol=2e-6, err_msg=name)
+        np.testing.assert_allclose(got[:80], want[:80], atol=5e-4)
+        seen += 1
+    assert seen == 4
+    # through the public API, chunked: the tracker sees each chunk's audio
+    config = cfg.Config(pitch_feature=True, periodicity_feature=True)
+    state = weights.random_state(config, seed=7)
+    frames = 1300
+    audio = torch.from_numpy(synth.audio(41, frames))
+    words = synth.word_frames(41, frames)
+    engine = engine_module.Engine(config, state, 0)
+    segments = batch.chunk_utterance(
+        emphases_amd.Alignment.from_frames(words), frames * 160, 400)
+    assert len(segments) > 2
+    plan = batch.Plan(segments, [0], [frames * 160])
+    tracks = torch.from_numpy(batch.pack_tracks(plan, [
+        synth.pitch_tracks(batch.chunk_audio(audio, segment))
+        for segment in segments])).to(engine.device)
+    scores, _ = engine.forward(
+        audio[0].to(engine.device), plan, tracks=tracks)
+    want = oracle.from_alignment_and_audio(
+        seconds(words), audio,
+        {k: torch.from_numpy(v) for k, v in state.items()},
+        {'pitch_feature': True, 'periodicity_feature': True}, 400,
+        synth.pitch_tracks)
+    got = scores.cpu().numpy()[plan.word_columns()]
+    assert np.abs(got - want[0].numpy()).max() < SCORE_TOLERANCE
+    with pytest.raises(NotImplementedError, match='penn'):
+        engine.forward(audio[0].to(engine.device), plan)
 
 
 def test_loudness_row(variants):
@@ -254,6 +314,48 @@ def test_transformer_against_oracle():
             assert np.abs(got - want[0].numpy()).max() < SCORE_TOLERANCE
     finally:
         emphases_amd.configure(cfg.DEFAULT)
+
+
+def test_full_size_transformer_batch():
+    """BASELINE configs[2] at full size: 64 x 10 s through the Transformer
+    config (seeded weights — the reference ships no transformer checkpoint).
+    Determinism, range, and four sampled utterances against the oracle."""
+    config = cfg.Config(architecture='transformer')
+    state = weights.random_state(config, seed=0)
+    count, frames = 64, 1000
+    audios = [torch.from_numpy(synth.audio(i, frames)) for i in range(count)]
+    aligns = [emphases_amd.Alignment.from_frames(synth.word_frames(i, frames))
+              for i in range(count)]
+    first = emphases_amd.from_alignments_and_audios(
+        aligns, audios, checkpoint=state_file(state), config=config)
+    second = emphases_amd.from_alignments_and_audios(
+        aligns, audios, checkpoint=state_file(state), config=config)
+    torch_state = {k: torch.from_numpy(v) for k, v in state.items()}
+    for index, (a, b) in enumerate(zip(first, second)):
+        assert torch.equal(a, b)
+        assert a.shape == (1, len(aligns[index]))
+        assert torch.isfinite(a).all() and (a > 0).all() and (a < 1).all()
+        if index % 16 == 5:
+            times = [(w.start(), w.end()) for w in aligns[index]]
+            want = oracle.from_alignment_and_audio(
+                times, audios[index], torch_state,
+                {'architecture': 'transformer'})
+            assert np.abs(a.numpy() - want.numpy()).max() < SCORE_TOLERANCE
+
+
+_STATE_FILES = {}
+
+
+def state_file(state):
+    """A checkpoint file for a seeded state (the public API takes paths)."""
+    import tempfile
+    key = id(state)
+    if key not in _STATE_FILES:
+        handle = tempfile.NamedTemporaryFile(suffix='.npz', delete=False)
+        np.savez(handle, **state)
+        handle.close()
+        _STATE_FILES[key] = handle.name
+    return _STATE_FILES[key]
 
 
 def test_transformer_position_limit():

@@ -114,20 +114,19 @@ def test_variant_matrix_matches_reference(variants):
     checked = 0
     for name in variants['names']:
         config, overrides = variant_config(name)
-        if config.architecture == 'transformer' and \
-                config.downsample_location == 'input':
-            continue
         state = {k: torch.from_numpy(v) for k, v in
                  weights.random_state(config, seed=7).items()}
-        feats = oracle.features(padded[:, :audio.shape[1]], overrides)[0]
+        feats = oracle.features(
+            padded[:, :audio.shape[1]], overrides, synth.pitch_tracks)[0]
         logits = oracle.forward(feats, bounds, state, overrides).numpy()
         want = variants[f'{name}/logits']
         scale = max(1.0, float(np.abs(want).max()))
         assert np.abs(logits - want).max() < 2e-5 * scale, name
-        if config.loudness_feature:
+        if config.loudness_feature or config.pitch_feature or \
+                config.periodicity_feature:
             np.testing.assert_allclose(
                 feats.numpy(), variants[f'{name}/features'][0]
                 if variants[f'{name}/features'].ndim == 3
                 else variants[f'{name}/features'], atol=2e-4)
         checked += 1
-    assert checked == len(variants["names"]) == 33
+    assert checked == len(variants["names"]) == 39
