@@ -362,7 +362,7 @@ int emph_transformer_block(const float* attended, float* x, int64_t ld, int32_t 
         if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,     \
                                      "emph_transformer_block"))                                \
             return status;                                                                     \
-        hipLaunchKernelGGL(kernel, grid, dim3(512), lds, s, attended, x, ld, packs,     \
+        EMPH_LAUNCH(kernel, grid, dim3(512), lds, s, attended, x, ld, packs,     \
                            vectors, eps, activation, tiles, n_tiles);                   \
     } while (0)
     if (channels == 80) {
@@ -401,7 +401,7 @@ int emph_qkv_projection(const float* x, int64_t ld, float* qk, float* v, int32_t
         if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,     \
                                      "emph_transformer_block"))                                \
             return status;                                                                     \
-        hipLaunchKernelGGL(kernel, grid, dim3(512), lds, s, x, ld, qk, v, packs, bias,  \
+        EMPH_LAUNCH(kernel, grid, dim3(512), lds, s, x, ld, qk, v, packs, bias,  \
                            tiles, n_tiles);                                             \
     } while (0)
     if (channels == 80) {

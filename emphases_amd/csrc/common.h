@@ -20,6 +20,15 @@ constexpr int kPad = 432;          // (1024 - 160) / 2, core.py:357, mels.py:31
 
 void set_error(const char* format, ...);
 
+// Launch + check_launch report errors of THIS launch only: hipGetLastError is a
+// per-thread sticky slot that other users of the runtime in the same process
+// (torch probing a host pointer, say) may leave set.
+#define EMPH_LAUNCH(...)                 \
+    do {                                 \
+        (void)hipGetLastError();         \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)
+
 inline int check_launch(const char* what) {
     hipError_t status = hipGetLastError();
     if (status != hipSuccess) {

@@ -811,7 +811,7 @@ int launch_conv_waves(int n_tiles, int m_blocks, size_t weight_bytes, hipStream_
     const int groups_of_tiles = (n_tiles + WAVES - 1) / WAVES;
     const int resident = 256 * (lds > 80 * 1024 ? 1 : 2);
     dim3 grid(groups_of_tiles < resident ? groups_of_tiles : resident, m_blocks);
-    hipLaunchKernelGGL(kernel, grid, dim3(64 * WAVES), lds, s, x, ldx, y, ldy, pack,
+    EMPH_LAUNCH(kernel, grid, dim3(64 * WAVES), lds, s, x, ldx, y, ldy, pack,
                        bias, c_in, c_out, act, tiles, n_tiles, chunk_iterations,
                        patch_offset, transpose_out);
     return check_launch("emph_conv1d");
@@ -871,7 +871,7 @@ static int launch_winograd(const float* x, int64_t ldx, float* y, int64_t ldy,
         return status;
     const int groups_of_tiles = (n_tiles + WAVES - 1) / WAVES;
     dim3 grid(groups_of_tiles < 256 ? groups_of_tiles : 256, m_blocks);
-    hipLaunchKernelGGL(kernel, grid, dim3(64 * WAVES), lds, s, x, ldx, y, ldy, pack, bias, c_in,
+    EMPH_LAUNCH(kernel, grid, dim3(64 * WAVES), lds, s, x, ldx, y, ldy, pack, bias, c_in,
                        c_out, act, tiles, n_tiles,
                        static_cast<int>(weight_bytes / sizeof(float)));
     return check_launch("emph_conv1d_winograd");

@@ -304,7 +304,7 @@ int emph_conv1d_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
         if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,     \
                                      "emph_conv1d_winograd4"))                                 \
             return status;                                                                     \
-        hipLaunchKernelGGL(kernel, grid, dim3(512), lds, s, x, ldx, y, ldy, pack, bias,   \
+        EMPH_LAUNCH(kernel, grid, dim3(512), lds, s, x, ldx, y, ldy, pack, bias,   \
                            c_in, c_out, activation, tiles, n_tiles, bias_offset);         \
     } while (0)
     switch (m_tiles) {

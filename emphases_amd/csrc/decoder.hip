@@ -445,7 +445,7 @@ int emph_word_decoder(const float* x, int64_t ldx, const int32_t* tiles,
         if (int status = reserve_lds(reserved[m_tiles <= 6], reinterpret_cast<const void*>(kernel), lds,\
                                      "emph_word_decoder"))                                     \
             return status;                                                                     \
-        hipLaunchKernelGGL(kernel, dim3(n_tiles), dim3(threads), lds, s, x, ldx,     \
+        EMPH_LAUNCH(kernel, dim3(n_tiles), dim3(threads), lds, s, x, ldx,     \
                            tiles, block, halo, channels, packs, biases, layers,      \
                            activation, chunk_trips, out_weight, out_bias,            \
                            out_kernel_size, post, logits, scores);                   \

@@ -72,7 +72,7 @@ int emph_pitch_rows(const float* pitch, const float* periodicity, float* out, in
     EMPH_REQUIRE(!normalize || logfmax > logfmin, EMPH_EINVAL,
                  "emph_pitch_rows: LOGFMAX must exceed LOGFMIN");
     const unsigned blocks = static_cast<unsigned>((ld / 4 + 255) / 256);
-    hipLaunchKernelGGL(
+    EMPH_LAUNCH(
         pitch_rows_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), pitch,
         periodicity, pitch_row < 0 ? nullptr : out + static_cast<int64_t>(pitch_row) * ld,
         periodicity_row < 0 ? nullptr : out + static_cast<int64_t>(periodicity_row) * ld, ld,

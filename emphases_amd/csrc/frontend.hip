@@ -41,6 +41,19 @@ void set_error(const char* format, ...) {
     va_end(args);
 }
 
+// Exchange between lanes of one wave through LDS.  A wave's DS instructions are
+// executed by the LDS unit in program order, so a read issued after a write
+// sees it: only the COMPILER has to be kept from reordering them; the wait for
+// the data is the s_waitcnt hipcc places before the first use of what was read.
+__device__ __forceinline__ void frontend_fence() {
+#ifdef EMPH_FE_FENCE_WAIT
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+    __builtin_amdgcn_wave_barrier();
+}
+
 constexpr float kLn2 = 0.69314718055994530942f;
 constexpr int kBlockFrames = 32;                               // frames per workgroup
 constexpr int kStage = kHop * (kBlockFrames - 1) + kFft;       // 5984 samples
@@ -342,31 +355,31 @@ __global__ __launch_bounds__(256) void frontend_kernel(
             if (r) v[r] = cmul(v[r], tw1[r]);
             ex[r * kExRow + p] = v[r];
         }
-        wave_lds_fence();
+        frontend_fence();
 
         if (local == wave) EMPH_STAMP(3);
         // pass 2: lane (r, p0) takes A[p0 + 8 p1][r], radix-8 over p1
 #pragma unroll
         for (int p1 = 0; p1 < 8; ++p1) v[p1] = ex[r1 * kExRow + p0 + 8 * p1];
-        wave_lds_fence();
+        frontend_fence();
         dft8(v);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             if (t) v[t] = cmul(v[t], tw2[t]);
             ex[r1 * kExRowB + t * kExStepB + p0] = v[t];     // C[r][t][p0]
         }
-        wave_lds_fence();
+        frontend_fence();
 
         if (local == wave) EMPH_STAMP(4);
         // pass 3: lane (r, t) takes C[r][p0][t], radix-8 over p0
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = ex[r1 * kExRowB + p0 * kExStepB + q];
-        wave_lds_fence();
+        frontend_fence();
         dft8(v);
         // Z[r + 8 t + 64 u] = v[u]; natural-order spectrum into LDS
 #pragma unroll
         for (int u = 0; u < 8; ++u) ex[spectrum_slot(r1 + 8 * p0 + 64 * u)] = v[u];
-        wave_lds_fence();
+        frontend_fence();
 
         if (local == wave) EMPH_STAMP(5);
         // real-FFT split for bins k = lane + 64 j (and k = 512 on lane 0)
@@ -388,7 +401,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(
             const float re = z0.x - z0.y;
             power[8] = re * re;
         }
-        wave_lds_fence();
+        frontend_fence();
 
         if (local == wave) EMPH_STAMP(6);
         if (kPeak) {
@@ -428,7 +441,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(
             for (int j = 0; j < 8; ++j)
                 mag[lane + 64 * j] = __builtin_amdgcn_sqrtf(power[j] + 1e-6f);
             if (lane == 0) mag[512] = __builtin_amdgcn_sqrtf(power[8] + 1e-6f);
-            wave_lds_fence();
+            frontend_fence();
             float acc = 0.f;
 #pragma unroll
             for (int piece = 0; piece < kRunA / 4; ++piece) {
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(
                 if (normalize) value = fmaf(value, 0.1f, 1.f);
                 tile[(64 + (lane >> 2)) * kOutStride + local] = value;
             }
-            wave_lds_fence();
+            frontend_fence();
         }
         if (local == wave) EMPH_STAMP(7);
     }
@@ -563,17 +576,17 @@ int emph_logmel(const float* audio, const int64_t* seg, const int32_t* tiles,
     const size_t lds = frontend_lds_bytes(loud);
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* peak = const_cast<float*>(seg_peak);
-#define EMPH_LAUNCH(MODE)                                                      \
-    hipLaunchKernelGGL(frontend_kernel<MODE>, dim3(frontend_grid(n_tiles)),    \
+#define EMPH_FRONTEND(MODE)                                                    \
+    EMPH_LAUNCH(frontend_kernel<MODE>, dim3(frontend_grid(n_tiles)),    \
                        dim3(256), lds, s, audio, seg, tiles, table, mel_start, \
                        mel_count, mel_offset, mel_values, mel_nnz, out, ld,    \
                        mel_row, loud_row, peak, a_weights, normalize, n_tiles)
     if (mel && loud) {
-        EMPH_LAUNCH(2);
+        EMPH_FRONTEND(2);
     } else if (mel) {
-        EMPH_LAUNCH(0);
+        EMPH_FRONTEND(0);
     } else {
-        EMPH_LAUNCH(3);
+        EMPH_FRONTEND(3);
     }
     return check_launch("emph_logmel");
 }
@@ -589,11 +602,11 @@ int emph_frontend_peak(const float* audio, const int64_t* seg,
     const int32_t* none_i = nullptr;
     const float* none_f = nullptr;
     float* none_o = nullptr;
-    hipLaunchKernelGGL(frontend_kernel<1>, dim3(frontend_grid(n_tiles)), dim3(256), lds,
+    EMPH_LAUNCH(frontend_kernel<1>, dim3(frontend_grid(n_tiles)), dim3(256), lds,
                        s, audio, seg, tiles, table, none_i, none_i, none_i, none_f, 0,
                        none_o, int64_t{0}, -1, -1, seg_peak, none_f, 0, n_tiles);
     return check_launch("emph_frontend_peak");
 }
-#undef EMPH_LAUNCH
+#undef EMPH_FRONTEND
 
 }  // extern "C"

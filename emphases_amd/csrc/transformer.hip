@@ -290,7 +290,7 @@ int emph_add_position(float* x, int64_t ldx, const float* table, int32_t channel
     EMPH_REQUIRE(x && table && tiles, EMPH_EINVAL,
                  "emph_add_position: null pointer");
     EMPH_REQUIRE(tile_n > 0 && channels > 0, EMPH_EINVAL, "emph_add_position: bad shape");
-    hipLaunchKernelGGL(add_position_kernel, dim3(n_tiles), dim3(256), 0,
+    EMPH_LAUNCH(add_position_kernel, dim3(n_tiles), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, ldx, table, channels,
                        max_positions, tiles, tile_n);
     return check_launch("emph_add_position");
@@ -308,10 +308,10 @@ int emph_add_layernorm(const float* x, const float* r, float* y, int64_t ld,
     const unsigned blocks = static_cast<unsigned>((columns + 63) / 64);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (channels <= 80)
-        hipLaunchKernelGGL(add_layernorm_kernel<80>, dim3(blocks), dim3(256), 0, s, x,
+        EMPH_LAUNCH(add_layernorm_kernel<80>, dim3(blocks), dim3(256), 0, s, x,
                            r, y, ld, channels, gamma, beta, eps, first_column, columns);
     else
-        hipLaunchKernelGGL(add_layernorm_kernel<128>, dim3(blocks), dim3(256), 0, s, x,
+        EMPH_LAUNCH(add_layernorm_kernel<128>, dim3(blocks), dim3(256), 0, s, x,
                            r, y, ld, channels, gamma, beta, eps, first_column, columns);
     return check_launch("emph_add_layernorm");
 }
@@ -330,15 +330,15 @@ int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
     dim3 grid(n_tiles, heads);
     switch (d) {
         case 32:
-            hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(64), 0, s, qk, v, out, ld,
+            EMPH_LAUNCH(attention_kernel<32>, grid, dim3(64), 0, s, qk, v, out, ld,
                                channels, tiles, key_counts);
             break;
         case 40:
-            hipLaunchKernelGGL(attention_kernel<40>, grid, dim3(64), 0, s, qk, v, out, ld,
+            EMPH_LAUNCH(attention_kernel<40>, grid, dim3(64), 0, s, qk, v, out, ld,
                                channels, tiles, key_counts);
             break;
         case 64:
-            hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(64), 0, s, qk, v, out, ld,
+            EMPH_LAUNCH(attention_kernel<64>, grid, dim3(64), 0, s, qk, v, out, ld,
                                channels, tiles, key_counts);
             break;
         default:

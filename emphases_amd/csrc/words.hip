@@ -182,7 +182,7 @@ int emph_segment_reduce(const float* x, int64_t ldx, const int32_t* bounds,
     const unsigned blocks = static_cast<unsigned>((total_words + 3) / 4);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned slices = static_cast<unsigned>(((channels + 3) / 4 + 4) / 5);
-    hipLaunchKernelGGL(segment_reduce_kernel<5>, dim3(blocks, slices), dim3(256), 0, s, x, ldx,
+    EMPH_LAUNCH(segment_reduce_kernel<5>, dim3(blocks, slices), dim3(256), 0, s, x, ldx,
                        bounds, out, ldw, channels, seg, word_segment, total_words, mode);
     return check_launch("emph_segment_reduce");
 }
@@ -194,7 +194,7 @@ int emph_gather_columns(const float* x, int64_t ldx, float* y, int64_t ldy,
     EMPH_REQUIRE(x && y && pieces, EMPH_EINVAL, "emph_gather_columns: null pointer");
     EMPH_REQUIRE(channels > 0 && n_pieces > 0, EMPH_EINVAL,
                  "emph_gather_columns: bad shape");
-    hipLaunchKernelGGL(gather_columns_kernel, dim3(n_pieces), dim3(256), 0,
+    EMPH_LAUNCH(gather_columns_kernel, dim3(n_pieces), dim3(256), 0,
                        static_cast<hipStream_t>(stream), x, ldx, y, ldy, channels, pieces);
     return check_launch("emph_gather_columns");
 }
@@ -212,7 +212,7 @@ int emph_output_layer(const float* x, int64_t ldx, const float* weight,
     EMPH_REQUIRE(channels > 0 && channels * kernel_size <= 8192, EMPH_ERANGE,
                  "emph_output_layer: channels %d", channels);
     const unsigned blocks = static_cast<unsigned>((total + 3) / 4);
-    hipLaunchKernelGGL(output_layer_kernel, dim3(blocks), dim3(256),
+    EMPH_LAUNCH(output_layer_kernel, dim3(blocks), dim3(256),
                        channels * kernel_size * sizeof(float),
                        static_cast<hipStream_t>(stream), x, ldx, weight, bias,
                        channels, kernel_size, seg, position_segment, total, axis,
