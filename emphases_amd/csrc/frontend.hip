@@ -71,6 +71,7 @@ constexpr int kExFloats = 2 * 8 * kExRowB;                     // 1408 floats pe
 // stride-8 writes of the last pass (lanes t and t + 4 used to collide) and the
 // contiguous reads of the real-FFT split are both conflict free
 __device__ __forceinline__ int spectrum_slot(int k) { return k + 4 * (k >> 5); }
+constexpr int kHighBase = 256 + 4 * (256 >> 5);   // slot of bin 256: only 256..511 are stored
 constexpr int kOutStride = kBlockFrames + 1;
 constexpr int kMagFloats = 560;      // 513 magnitudes per wave + zero tail for the runs
 // Filterbank runs are read from LDS as 16-byte pieces from a start rounded down
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     const int r1 = lane >> 3;        // pass-2/3 residue r
     const int p0 = lane & 7;         // pass-2 position / pass-3 output t
     float window[16];
-    cf tw1[8], tw2[8], tw3[8];
+    cf tw1[8], tw2[8], tw3[4];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         window[2 * q] = table[kTabWindow + 2 * (p + 64 * q)];
@@ -221,10 +222,20 @@ __global__ __launch_bounds__(256) void frontend_kernel(
                   table[kTabTw1 + 2 * (q * 64 + p) + 1]};
         tw2[q] = {table[kTabTw2 + 2 * (q * 8 + p0)],
                   table[kTabTw2 + 2 * (q * 8 + p0) + 1]};
-        // -i W1024^k: the real-FFT split multiplies it with zk - conj(zm)
-        tw3[q] = {table[kTabTw3 + 2 * (lane + 64 * q) + 1],
-                  -table[kTabTw3 + 2 * (lane + 64 * q)]};
     }
+    // -i W1024^k for the lane's four low bins k = r + 8 t + 64 u: the real-FFT
+    // split multiplies it with Z[k] - conj(Z[512 - k])
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = r1 + 8 * p0 + 64 * u;
+        tw3[u] = {table[kTabTw3 + 2 * k + 1], -table[kTabTw3 + 2 * k]};
+    }
+    // spectrum bin of power[j]: the low bins, their partners 512 - k, and bin 256
+    // (lane 0 only)
+    auto bin_of = [&](int j) {
+        const int k = r1 + 8 * p0 + 64 * (j & 3);
+        return j == 8 ? 256 : (j < 4 ? k : 512 - k);
+    };
 
     // Sparse mel projection: every filterbank row is a contiguous run of bins.
     // Rows 0..63 (runs of at most kRunA bins) get one lane each; rows 64..79
@@ -376,31 +387,34 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         for (int q = 0; q < 8; ++q) v[q] = ex[r1 * kExRowB + p0 * kExStepB + q];
         frontend_fence();
         dft8(v);
-        // Z[r + 8 t + 64 u] = v[u]; natural-order spectrum into LDS
+        // Z[r + 8 t + 64 u] = v[u].  Real-FFT split, two bins per pair: with
+        // E = Z[k] + conj(Z[512-k]) and O' = (-i W^k)(Z[k] - conj(Z[512-k])),
+        //     X[k] = E + O'        conj(X[512-k]) = E - O'
+        // (the 1/2 rides on the window table).  A lane owns the pairs of its
+        // four low bins k = r + 8 t + 64 u, u < 4, so only the HIGH half of the
+        // spectrum (u >= 4) crosses lanes: four 8-byte LDS writes and four reads
+        // per lane instead of eight and sixteen for a natural-order round trip.
 #pragma unroll
-        for (int u = 0; u < 8; ++u) ex[spectrum_slot(r1 + 8 * p0 + 64 * u)] = v[u];
+        for (int u = 4; u < 8; ++u) ex[spectrum_slot(r1 + 8 * p0 + 64 * u) - kHighBase] = v[u];
         frontend_fence();
 
         if (local == wave) EMPH_STAMP(5);
-        // real-FFT split for bins k = lane + 64 j (and k = 512 on lane 0)
         float power[9];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = lane + 64 * j;
-            const cf zk = ex[spectrum_slot(k)];
-            const cf zm = ex[spectrum_slot((512 - k) & 511)];
-            // X[k] = (E + W^k O) / 2 with E = zk + conj(zm), O = -i (zk -
-            // conj(zm)): the -i rides on the twiddle table, the halves on the
-            // power
-            const cf value = add_conj(zk, zm) + cmul(tw3[j], sub_conj(zk, zm));
-            power[j] = 0.25f * (value.x * value.x + value.y * value.y);
+        for (int u = 0; u < 4; ++u) {
+            const int k = r1 + 8 * p0 + 64 * u;
+            // k = 0 pairs with itself: bins 0 and 512 come out of the same formulas
+            cf zm = ex[spectrum_slot((512 - k) & 511 ? (512 - k) & 511 : 256) - kHighBase];
+            if (u == 0) zm = lane == 0 ? v[0] : zm;
+            const cf e = add_conj(v[u], zm);
+            const cf o = cmul(tw3[u], sub_conj(v[u], zm));
+            const cf low = e + o, high = e - o;
+            power[u] = low.x * low.x + low.y * low.y;            // |X[k]|^2
+            power[4 + u] = high.x * high.x + high.y * high.y;    // |X[512 - k]|^2
         }
-        {
-            const cf z0 = ex[0];
-            // k = 512: E = (2 z0.x, 0), O = (2 z0.y, 0), W = -1
-            const float re = z0.x - z0.y;
-            power[8] = re * re;
-        }
+        // k = 256 pairs with itself: X[256] = conj(Z[256]) (lane 0 holds it, u = 4);
+        // the window's 1/2 has to be undone there
+        power[8] = 4.f * (v[4].x * v[4].x + v[4].y * v[4].y);
         frontend_fence();
 
         if (local == wave) EMPH_STAMP(6);
@@ -418,7 +432,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
                 if (j == 8 && lane != 0) break;
-                const int k = j == 8 ? 512 : lane + 64 * j;
+                const int k = bin_of(j);
                 float db = 10.f * log10f(fmaxf(1e-10f, power[j]));
                 db = fmaxf(db, floor_db) + weights[k];
                 total += static_cast<double>(fmaxf(db, -100.f));
@@ -439,8 +453,8 @@ __global__ __launch_bounds__(256) void frontend_kernel(
             // v_sqrt_f32 (1 ulp; the argument is >= 1e-6, never denormal): the
             // correctly rounded sqrtf is ten more instructions per bin
             for (int j = 0; j < 8; ++j)
-                mag[lane + 64 * j] = __builtin_amdgcn_sqrtf(power[j] + 1e-6f);
-            if (lane == 0) mag[512] = __builtin_amdgcn_sqrtf(power[8] + 1e-6f);
+                mag[bin_of(j)] = __builtin_amdgcn_sqrtf(power[j] + 1e-6f);
+            if (lane == 0) mag[256] = __builtin_amdgcn_sqrtf(power[8] + 1e-6f);
             frontend_fence();
             float acc = 0.f;
 #pragma unroll
@@ -530,9 +544,12 @@ int64_t emph_frontend_table_size(void) { return kTabSize; }
 int emph_frontend_table_fill(float* host_table) {
     EMPH_REQUIRE(host_table != nullptr, EMPH_EINVAL, "table is null");
     const double two_pi = 6.283185307179586476925286766559;
-    for (int n = 0; n < kFft; ++n)   // periodic Hann, torch.hann_window default
+    // periodic Hann (torch.hann_window default), rounded to float32 like torch's,
+    // then halved: the exact power of two carries the 1/2 of the real-FFT split
+    // X[k] = (E + W^k O) / 2 through the whole transform
+    for (int n = 0; n < kFft; ++n)
         host_table[kTabWindow + n] =
-            static_cast<float>(0.5 - 0.5 * cos(two_pi * n / kFft));
+            0.5f * static_cast<float>(0.5 - 0.5 * cos(two_pi * n / kFft));
     for (int r = 0; r < 8; ++r)
         for (int p = 0; p < 64; ++p) {
             const double angle = -two_pi * (p * r) / 512.;

@@ -341,8 +341,9 @@ def test_library_exports_every_declared_symbol():
 def test_host_side_abi_helpers():
     table = runtime.frontend_table()
     n = np.arange(1024)
+    # periodic Hann, halved (the 1/2 of the real-FFT split rides on it)
     np.testing.assert_allclose(
-        table[:1024], 0.5 - 0.5 * np.cos(2 * np.pi * n / 1024), atol=1e-7)
+        2. * table[:1024], 0.5 - 0.5 * np.cos(2 * np.pi * n / 1024), atol=1e-7)
     weight = np.arange(80 * 80 * 3, dtype=np.float32).reshape(80, 80, 3)
     pack = runtime.conv_pack(weight)
     # pack[step][m][lane] = W[16 m + (lane & 15)][4 group + (lane >> 4)][tap]

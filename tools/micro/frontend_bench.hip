@@ -6,11 +6,18 @@
 #include <vector>
 #include <math.h>
 __device__ unsigned long long* g_stamps = nullptr;
+#ifdef STAMP_FIRST   // the first block of every workgroup instead of its last
+#define EMPH_STAMP_KEEP(p) (*(p) == 0)
+#else
+#define EMPH_STAMP_KEEP(p) true
+#endif
 #define EMPH_STAMP(slot)                                                          \
     do {                                                                          \
-        if (g_stamps != nullptr && (threadIdx.x & 63) == 0)                       \
-            g_stamps[(static_cast<size_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + \
-                     (slot)] = __builtin_amdgcn_s_memrealtime();                  \
+        if (g_stamps != nullptr && (threadIdx.x & 63) == 0) {                     \
+            unsigned long long* p_ = g_stamps + (static_cast<size_t>(blockIdx.x) * 4 + \
+                     (threadIdx.x >> 6)) * 16 + (slot);                           \
+            if (EMPH_STAMP_KEEP(p_)) *p_ = __builtin_amdgcn_s_memrealtime();      \
+        }                                                                         \
     } while (0)
 #include "../../emphases_amd/csrc/frontend.hip"
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
