@@ -20,8 +20,9 @@ int64_t emph_prominence_workspace_floats(int32_t features, int32_t channels,
            static_cast<int64_t>(channels) * ld_words;
 }
 
-int emph_prominence_forward(const emph_conv_model* model, const float* audio,
-                            const int64_t* seg, const int32_t* frontend_tiles,
+int emph_prominence_forward(const emph_conv_model* model, const void* audio,
+                            int32_t audio_format, const int64_t* seg,
+                            const int32_t* frontend_tiles,
                             int32_t n_frontend_tiles, const int32_t* frame_tiles,
                             int32_t n_frame_tiles, int32_t tile_n,
                             const int32_t* word_tiles, int32_t n_word_tiles,
@@ -55,7 +56,7 @@ int emph_prominence_forward(const emph_conv_model* model, const float* audio,
     float* other = current + static_cast<int64_t>(c) * ld_frames;
     float* words = other + static_cast<int64_t>(c) * ld_frames;
 
-    int status = emph_logmel(audio, seg, frontend_tiles, n_frontend_tiles, m.table,
+    int status = emph_logmel(audio, audio_format, seg, frontend_tiles, n_frontend_tiles, m.table,
                              m.mel_start, m.mel_count, m.mel_offset, m.mel_values, m.mel_nnz,
                              features, ld_frames, 0, -1, nullptr, nullptr, m.normalize, stream);
     if (status) return status;

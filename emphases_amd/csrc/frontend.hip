@@ -9,16 +9,19 @@
 //   mel basis matmul, log(clamp(., 1e-5))             mels.py:94-109
 //   librosa loudness (always on CPU in the reference) data/preprocess/loudness.py:59-107
 //
-// Design (gfx950): one 256-thread workgroup owns a block of 32 frames of one
-// chunk.  The 5984 contiguous samples those frames cover are staged ONCE into
-// LDS with the zero-pad / slice / reflect index arithmetic applied per sample,
-// so HBM sees each audio sample about once (adjacent blocks share 864).  Each
-// wave then transforms one frame at a time: a 1024-point real FFT as a
-// 512-point complex FFT held 8 points per lane — three radix-8 passes in
-// registers with two wave-private LDS transposes — followed by the real-FFT
-// split, magnitudes, the 1001-non-zero sparse mel projection and the log.
-// The [80 x 32] result tile is staged in LDS and written as 128-byte row
-// segments.  Nothing of the 513 x F complex spectrogram ever reaches HBM.
+// Design (gfx950): a wave owns tiles of 16 consecutive frames and transforms
+// them two at a time.  A frame's 1024 samples come straight from the packed
+// audio as eight coalesced 8-byte loads per lane (float32; 4-byte loads for
+// 16-bit PCM) - consecutive frames overlap by 864 samples, so all but the first
+// touch of a sample is an L1/L2 hit and HBM sees each sample about once; the
+// zero-pad / slice / reflect index arithmetic runs only for the frames at a
+// chunk's ends.  The 1024-point real FFT is a 512-point complex FFT held 8
+// points per lane - three radix-8 passes in registers with two wave-private LDS
+// transposes - followed by the real-FFT split on bin pairs (only the high half
+// of the spectrum crosses lanes), magnitudes, the 1001-non-zero sparse mel
+// projection and the log.  The wave's [80 x 16] result tile is staged in LDS and
+// written as 64-byte row segments.  There is no workgroup barrier anywhere, and
+// nothing of the 513 x F complex spectrogram ever reaches HBM.
 #include <math.h>
 #include <stdarg.h>
 
@@ -54,9 +57,25 @@ __device__ __forceinline__ void frontend_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// End of one frame's section of a stage: hipcc's scheduler may not move the
+// other frame's arithmetic across it (left alone it hoists both frames'
+// arithmetic in front of both exchanges, and each exchange's latency is then
+// exposed instead of running under the other frame's work).
+__device__ __forceinline__ void frontend_section() { __builtin_amdgcn_sched_barrier(0); }
+
 constexpr float kLn2 = 0.69314718055994530942f;
-constexpr int kBlockFrames = 32;                               // frames per workgroup
-constexpr int kStage = kHop * (kBlockFrames - 1) + kFft;       // 5984 samples
+#ifndef EMPH_FE_TILE
+#define EMPH_FE_TILE 8
+#endif
+constexpr int kWaveFrames = EMPH_FE_TILE;   // consecutive frames per wave = tile-table block
+#ifndef EMPH_FE_PAIR
+#define EMPH_FE_PAIR 1
+#endif
+#ifndef EMPH_FE_WAVES
+#define EMPH_FE_WAVES 3
+#endif
+constexpr int kPair = EMPH_FE_PAIR;  // frames a wave transforms at a time
+constexpr int kTileStride = kWaveFrames + 1;
 constexpr int kExRow = 72;                                     // complex per exchange row
 // Second exchange, C[r][t][p0] at r * kExRowB + t * kExStepB + p0: written by
 // lane (r, p0) for each t and read by lane (r, t) for each p0, 8 bytes each.
@@ -72,8 +91,10 @@ constexpr int kExFloats = 2 * 8 * kExRowB;                     // 1408 floats pe
 // contiguous reads of the real-FFT split are both conflict free
 __device__ __forceinline__ int spectrum_slot(int k) { return k + 4 * (k >> 5); }
 constexpr int kHighBase = 256 + 4 * (256 >> 5);   // slot of bin 256: only 256..511 are stored
-constexpr int kOutStride = kBlockFrames + 1;
-constexpr int kMagFloats = 560;      // 513 magnitudes per wave + zero tail for the runs
+constexpr int kMagFloats = 560;      // 513 magnitudes + zero tail for the runs, laid over
+                                     // the frame's exchange buffer
+// floats of LDS per wave: exchange buffers, output tile, loudness tile
+constexpr int kWaveFloats = kPair * kExFloats + kMels * kTileStride + kWaveFrames;
 // Filterbank runs are read from LDS as 16-byte pieces from a start rounded down
 // to a multiple of four bins: rows 0..63 (at most 20 bins + 3 of alignment) as
 // six pieces by one lane each, rows 64..79 (at most 40 + 3) as three pieces by
@@ -164,6 +185,14 @@ __device__ __forceinline__ void dft8(cf v[8]) {
     v[7] = sub_mi(e1, t);
 }
 
+// Sum over the four lanes of a quad on the DPP path (quad_perm [1,0,3,2] and
+// [2,3,0,1]): __shfl_xor goes through ds_bpermute, an LDS round trip each.
+__device__ __forceinline__ float quad_sum(float x) {
+    x += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(x), 0xB1, 0xF, 0xF, true));
+    x += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(x), 0x4E, 0xF, 0xF, true));
+    return x;
+}
+
 __device__ __forceinline__ float wave_max(float value) {
 #pragma unroll
     for (int offset = 32; offset > 0; offset >>= 1)
@@ -171,11 +200,92 @@ __device__ __forceinline__ float wave_max(float value) {
     return value;
 }
 
+// One frame's 1024 samples as the 512 complex points z[n] = y[2n] + i y[2n+1]
+// the lane transforms: s[q] = z[p + 64 q].  Interior frames (all but the first
+// and last few of a chunk) are eight coalesced 8-byte loads straight from the
+// packed audio (4-byte loads for 16-bit PCM); frames that touch a chunk's or
+// the utterance's ends apply the zero-pad / slice / reflect index arithmetic of
+// emphases/core.py:357-401 and mels.py:31-36 per sample.  Consecutive frames of
+// a wave overlap by 864 of 1024 samples, so most of these loads hit in L1/L2.
+typedef float cf_u __attribute__((ext_vector_type(2), aligned(4)));
+
+// Where a chunk's samples live, in 32-bit chunk positions (a chunk is far
+// shorter than 2^31 samples): position r of the chunk is audio sample
+// `origin[r]` when r_lo <= r < r_hi and zero otherwise (the 432 zeros that
+// emphases/core.py:357-358 pads the utterance with, or beyond the audio).
+struct Chunk {
+    const void* origin;   // address of chunk position 0 (may lie before the buffer)
+    int length;           // samples in the chunk
+    int r_lo, r_hi;       // chunk positions backed by audio
+};
+
+template <bool PCM>
+__device__ __forceinline__ Chunk open_chunk(const void* audio, int64_t audio_off,
+                                            int64_t audio_len, int64_t start, int64_t length) {
+    Chunk chunk;
+    const int64_t shift = audio_off + start - kPad;     // audio index of position 0
+    chunk.origin = PCM ? static_cast<const void*>(static_cast<const int16_t*>(audio) + shift)
+                       : static_cast<const void*>(static_cast<const float*>(audio) + shift);
+    chunk.length = static_cast<int>(length);
+    const int64_t lo = kPad - start, hi = audio_len + kPad - start;
+    chunk.r_lo = static_cast<int>(lo < 0 ? 0 : (lo > length ? length : lo));
+    chunk.r_hi = static_cast<int>(hi < 0 ? 0 : (hi > length ? length : hi));
+    return chunk;
+}
+
+template <bool PCM>
+__device__ __forceinline__ void load_frame(const Chunk& chunk, int frame, int p, cf (&s)[8]) {
+    const int first = frame * kHop - kPad;              // chunk position of sample 0
+    if (first >= chunk.r_lo && first + kFft <= chunk.r_hi) {      // wave-uniform
+        if (PCM) {
+            const int16_t* source = static_cast<const int16_t*>(chunk.origin) + first;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                typedef uint32_t u32_u __attribute__((aligned(2)));
+                const uint32_t two = *reinterpret_cast<const u32_u*>(source + 2 * (p + 64 * q));
+                s[q] = {static_cast<float>(static_cast<int16_t>(two & 0xffffu)),
+                        static_cast<float>(static_cast<int16_t>(two >> 16))};
+            }
+        } else {
+            const float* source = static_cast<const float*>(chunk.origin) + first;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                s[q] = *reinterpret_cast<const cf_u*>(source + 2 * (p + 64 * q));
+        }
+        return;
+    }
+    // a frame at a chunk's (or the utterance's) end: reflect / zero per sample
+    const int safe = chunk.r_hi > chunk.r_lo ? chunk.r_lo : 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float pair[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int r = first + 2 * (p + 64 * q) + h;          // position in the chunk
+            if (r < 0) r = -r;                             // reflect (no edge repeat)
+            if (r >= chunk.length) r = 2 * (chunk.length - 1) - r;
+            const bool live = r >= chunk.r_lo && r < chunk.r_hi;
+            const int at = live ? r : safe;
+            float value = 0.f;
+            if (chunk.r_hi > chunk.r_lo)
+                value = PCM ? static_cast<float>(static_cast<const int16_t*>(chunk.origin)[at])
+                            : static_cast<const float*>(chunk.origin)[at];
+            pair[h] = live ? value : 0.f;
+        }
+        s[q] = {pair[0], pair[1]};
+    }
+}
+
 // MODE 0: mel rows.  MODE 1: per-chunk peak power only.  MODE 2: mel rows and
-// loudness row.  MODE 3: loudness row only.
-template <int MODE>
-__global__ __launch_bounds__(256) void frontend_kernel(
-    const float* __restrict__ audio, const int64_t* __restrict__ seg,
+// loudness row.  MODE 3: loudness row only.  PCM: audio is int16 (x / 32768).
+//
+// A workgroup is four INDEPENDENT waves (no workgroup barrier anywhere): each
+// owns tiles of kWaveFrames consecutive frames and transforms them kPair at a
+// time, so that one frame's arithmetic covers the other's LDS round trips.
+template <int MODE, bool PCM>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend_kernel(
+    const void* __restrict__ audio, const int64_t* __restrict__ seg,
     const int32_t* __restrict__ tiles, const float* __restrict__ table,
     const int32_t* __restrict__ mel_start, const int32_t* __restrict__ mel_count,
     const int32_t* __restrict__ mel_offset, const float* __restrict__ mel_values,
@@ -188,25 +298,19 @@ __global__ __launch_bounds__(256) void frontend_kernel(
 
     extern __shared__ __align__(16) float lds[];
     EMPH_STAMP(0);
-    float* stage = lds;                                  // [kStage]
-    float* exchange = stage + kStage;                    // [4][kExFloats]
-    float* tile = exchange + 4 * kExFloats;              // [80][kOutStride]
-    float* loud_tile = tile + kMels * kOutStride;        // [kBlockFrames]
-    float* mel_sums = loud_tile + kBlockFrames;          // [4][kMagFloats] magnitudes
-    float* weights = mel_sums + 4 * kMagFloats;          // [513+]
-
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* mine = lds + wave * kWaveFloats;
+    float* exchange = mine;                                  // [kPair][kExFloats]
+    float* tile = exchange + kPair * kExFloats;              // [80][kTileStride]
+    float* loud_tile = tile + kMels * kTileStride;           // [kWaveFrames]
+    float* weights = lds + 4 * kWaveFloats;                  // [513+] (loudness only)
 
-    if (kLoud)
-        for (int index = tid; index < kBins; index += 256)
-            weights[index] = a_weights[index];
-    if (kMel)   // zero tail of each wave's magnitude row: the fixed-length mel
-                // runs read up to kMagPad bins past the last one (weight 0)
-        for (int index = tid; index < 4 * (kMagFloats - kBins); index += 256)
-            mel_sums[(index / (kMagFloats - kBins)) * kMagFloats + kBins +
-                     index % (kMagFloats - kBins)] = 0.f;
+    if (kLoud) {
+        for (int index = tid; index < kBins; index += 256) weights[index] = a_weights[index];
+        __syncthreads();
+    }
 
     // ---- per-lane constants
     const int p = lane;              // pass-1 position
@@ -216,8 +320,10 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     cf tw1[8], tw2[8], tw3[4];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        window[2 * q] = table[kTabWindow + 2 * (p + 64 * q)];
-        window[2 * q + 1] = table[kTabWindow + 2 * (p + 64 * q) + 1];
+        // 16-bit PCM: the 1/32768 rides on the window (an exact power of two)
+        const float unit = PCM ? 1.f / 32768.f : 1.f;
+        window[2 * q] = unit * table[kTabWindow + 2 * (p + 64 * q)];
+        window[2 * q + 1] = unit * table[kTabWindow + 2 * (p + 64 * q) + 1];
         tw1[q] = {table[kTabTw1 + 2 * (q * 64 + p)],
                   table[kTabTw1 + 2 * (q * 64 + p) + 1]};
         tw2[q] = {table[kTabTw2 + 2 * (q * 8 + p0)],
@@ -240,8 +346,8 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     // Sparse mel projection: every filterbank row is a contiguous run of bins.
     // Rows 0..63 (runs of at most kRunA bins) get one lane each; rows 64..79
     // (runs of at most 4*kRunB) get four lanes each.  The run weights live in
-    // registers for the whole block, zero-padded to a fixed length so that the
-    // per-frame loops are fully unrolled with every LDS read independent.
+    // registers for the kernel's whole life, zero-padded to a fixed length so
+    // that the per-frame loops are fully unrolled with every LDS read independent.
     float weight_a[kRunA], weight_b[kRunB];
     int start_a = 0, start_b = 0;
     if (kMel) {
@@ -270,14 +376,17 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         }
     }
 
-    // ---- persistent loop over this workgroup's blocks of 32 frames: the
-    // per-lane tables above are loaded once (96 global loads per lane)
-    cf* ex = reinterpret_cast<cf*>(exchange + wave * kExFloats);
+    // ---- persistent loop over this WAVE's tiles of kWaveFrames frames
     float peak = 0.f;
     int peak_segment = -1;
-    for (int block = blockIdx.x; block < n_tiles; block += gridDim.x) {
-    const int segment = tiles[EMPH_TILE_FIELDS * block];
-    const int frame0 = tiles[EMPH_TILE_FIELDS * block + 1];
+    const int wave_id = blockIdx.x * 4 + wave;
+    const int wave_stride = gridDim.x * 4;
+    // (handing tiles out through an atomic counter was measured: 8 000 requests to
+    // one address serialise in L2 and the launch takes 2.7x as long)
+    for (int block = wave_id; block < n_tiles; block += wave_stride) {
+    const Tile span = load_tile(tiles, block);
+    const int segment = __builtin_amdgcn_readfirstlane(span.segment);
+    const int frame0 = __builtin_amdgcn_readfirstlane(span.first);
     const int64_t* row = seg + static_cast<int64_t>(segment) * EMPH_SEG_FIELDS;
     const int64_t audio_off = row[EMPH_SEG_AUDIO_OFF];
     const int64_t audio_len = row[EMPH_SEG_AUDIO_LEN];
@@ -285,6 +394,8 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     const int64_t length = row[EMPH_SEG_LENGTH];
     const int64_t frame_off = row[EMPH_SEG_FRAME_OFF];
     const int frames = static_cast<int>(row[EMPH_SEG_FRAMES]);
+    const int valid = min(kWaveFrames, frames - frame0);
+    const Chunk chunk = open_chunk<PCM>(audio, audio_off, audio_len, start, length);
     if (kPeak && segment != peak_segment) {
         // a new chunk: publish the running peak of the previous one
         if (peak_segment >= 0) {
@@ -296,49 +407,6 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         peak = 0.f;
         peak_segment = segment;
     }
-
-    // ---- stage the block's samples: zero pad + slice + reflect in one pass.
-    // Every load is unconditional (clamped address, masked value) and the loop
-    // is fully unrolled, so a thread's 24 requests are in flight together; a
-    // predicated, rolled loop pays one 1-2 us memory round trip per sample.
-    const int64_t first = static_cast<int64_t>(frame0) * kHop - kPad;
-    __syncthreads();          // the previous block is done with `stage` and `tile`
-    {
-        constexpr int kPerThread = (kStage + 255) / 256;
-        float value[kPerThread];
-        const float* source = audio + audio_off;
-        const int64_t base = start + first - kPad;      // audio index of stage[0]
-        if (first >= 0 && first + kStage <= length && base >= 0 &&
-            base + kStage <= audio_len) {
-            // interior block (all but the first and last of an utterance): a
-            // straight copy, no per-sample index arithmetic
-            const float* from = source + base + tid;
-#pragma unroll
-            for (int j = 0; j < kPerThread; ++j)
-                value[j] = from[tid + 256 * j < kStage ? 256 * j : 0];
-#pragma unroll
-            for (int j = 0; j < kPerThread; ++j)
-                if (tid + 256 * j < kStage) stage[tid + 256 * j] = value[j];
-        } else {
-            bool live[kPerThread];
-#pragma unroll
-            for (int j = 0; j < kPerThread; ++j) {
-                int64_t r = first + tid + 256 * j;     // position in the chunk
-                if (r < 0) r = -r;                     // reflect (no edge repeat)
-                if (r >= length) r = 2 * (length - 1) - r;
-                const int64_t a = start + r - kPad;    // undo the 432 zero pad
-                live[j] = r >= 0 && r < length && a >= 0 && a < audio_len;
-                const int64_t clamped = a < 0 ? 0 : (a >= audio_len ? audio_len - 1 : a);
-                value[j] = source[audio_len > 0 ? clamped : 0];
-            }
-#pragma unroll
-            for (int j = 0; j < kPerThread; ++j) {
-                const int index = tid + 256 * j;
-                if (index < kStage) stage[index] = live[j] ? value[j] : 0.f;
-            }
-        }
-    }
-    __syncthreads();
     EMPH_STAMP(1);
 
     float floor_db = 0.f;
@@ -348,45 +416,71 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         floor_db = top - 80.f;
     }
 
-    for (int local = wave; local < kBlockFrames; local += 4) {
-        if (frame0 + local >= frames) break;   // wave-uniform
-        const float* samples = stage + local * kHop;
-
-        // pass 1: radix-8 over q of z[p + 64 q], z[n] = y[2n] + i y[2n+1]
-        cf v[8];
+    // samples of the first pair; every later pair is requested one iteration
+    // ahead (a global load takes 1-2 us under load: far longer than a pair's
+    // arithmetic could hide behind the transform's own LDS round trips)
+    cf raw[kPair][8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            v[q] = *reinterpret_cast<const cf*>(samples + 2 * (p + 64 * q)) *
-                   cf{window[2 * q], window[2 * q + 1]};
-        }
-        if (local == wave) EMPH_STAMP(2);
-        dft8(v);
+    for (int f = 0; f < kPair; ++f)
+        // an odd tail repeats the last frame (its result is written twice)
+        load_frame<PCM>(chunk, frame0 + min(f, valid - 1), p, raw[f]);
+    for (int local = 0; local < valid; local += kPair) {
+        cf v[kPair][8];
+        cf* ex[kPair];
+        if (local == 8) EMPH_STAMP(2);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if (r) v[r] = cmul(v[r], tw1[r]);
-            ex[r * kExRow + p] = v[r];
+        for (int f = 0; f < kPair; ++f) {
+            ex[f] = reinterpret_cast<cf*>(exchange + f * kExFloats);
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[f][q] = raw[f][q] * cf{window[2 * q], window[2 * q + 1]};
         }
-        frontend_fence();
-
-        if (local == wave) EMPH_STAMP(3);
+        if (local == 8) EMPH_STAMP(3);
+        if (local + kPair < valid) {          // wave-uniform
+#pragma unroll
+            for (int f = 0; f < kPair; ++f)
+                load_frame<PCM>(chunk, frame0 + min(local + kPair + f, valid - 1), p, raw[f]);
+        }
+        if (local == 8) EMPH_STAMP(4);
+        // Every exchange below is written frame by frame as
+        //     compute(f); write(f); fence; read(f)
+        // so that a frame's LDS round trip runs under the OTHER frame's
+        // arithmetic (a wave's LDS operations execute in program order: the
+        // fence only keeps the compiler from reordering them).
+        //
+        // pass 1: radix-8 over q of z[p + 64 q], z[n] = y[2n] + i y[2n+1];
         // pass 2: lane (r, p0) takes A[p0 + 8 p1][r], radix-8 over p1
 #pragma unroll
-        for (int p1 = 0; p1 < 8; ++p1) v[p1] = ex[r1 * kExRow + p0 + 8 * p1];
-        frontend_fence();
-        dft8(v);
+        for (int f = 0; f < kPair; ++f) {
+            dft8(v[f]);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            if (t) v[t] = cmul(v[t], tw2[t]);
-            ex[r1 * kExRowB + t * kExStepB + p0] = v[t];     // C[r][t][p0]
+            for (int r = 0; r < 8; ++r) {
+                if (r) v[f][r] = cmul(v[f][r], tw1[r]);
+                ex[f][r * kExRow + p] = v[f][r];
+            }
+            frontend_fence();
+#pragma unroll
+            for (int p1 = 0; p1 < 8; ++p1) v[f][p1] = ex[f][r1 * kExRow + p0 + 8 * p1];
+            frontend_fence();
+            frontend_section();
+            if (local == 8) EMPH_STAMP(5 + f);
         }
-        frontend_fence();
-
-        if (local == wave) EMPH_STAMP(4);
         // pass 3: lane (r, t) takes C[r][p0][t], radix-8 over p0
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = ex[r1 * kExRowB + p0 * kExStepB + q];
-        frontend_fence();
-        dft8(v);
+        for (int f = 0; f < kPair; ++f) {
+            dft8(v[f]);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t) v[f][t] = cmul(v[f][t], tw2[t]);
+                ex[f][r1 * kExRowB + t * kExStepB + p0] = v[f][t];     // C[r][t][p0]
+            }
+            frontend_fence();
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[f][q] = ex[f][r1 * kExRowB + p0 * kExStepB + q];
+            frontend_fence();
+            frontend_section();
+            if (local == 8) EMPH_STAMP(7 + f);
+        }
         // Z[r + 8 t + 64 u] = v[u].  Real-FFT split, two bins per pair: with
         // E = Z[k] + conj(Z[512-k]) and O' = (-i W^k)(Z[k] - conj(Z[512-k])),
         //     X[k] = E + O'        conj(X[512-k]) = E - O'
@@ -394,122 +488,154 @@ __global__ __launch_bounds__(256) void frontend_kernel(
         // four low bins k = r + 8 t + 64 u, u < 4, so only the HIGH half of the
         // spectrum (u >= 4) crosses lanes: four 8-byte LDS writes and four reads
         // per lane instead of eight and sixteen for a natural-order round trip.
+        cf zm[kPair][4];
 #pragma unroll
-        for (int u = 4; u < 8; ++u) ex[spectrum_slot(r1 + 8 * p0 + 64 * u) - kHighBase] = v[u];
-        frontend_fence();
-
-        if (local == wave) EMPH_STAMP(5);
-        float power[9];
+        for (int f = 0; f < kPair; ++f) {
+            dft8(v[f]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = r1 + 8 * p0 + 64 * u;
-            // k = 0 pairs with itself: bins 0 and 512 come out of the same formulas
-            cf zm = ex[spectrum_slot((512 - k) & 511 ? (512 - k) & 511 : 256) - kHighBase];
-            if (u == 0) zm = lane == 0 ? v[0] : zm;
-            const cf e = add_conj(v[u], zm);
-            const cf o = cmul(tw3[u], sub_conj(v[u], zm));
-            const cf low = e + o, high = e - o;
-            power[u] = low.x * low.x + low.y * low.y;            // |X[k]|^2
-            power[4 + u] = high.x * high.x + high.y * high.y;    // |X[512 - k]|^2
+            for (int u = 4; u < 8; ++u)
+                ex[f][spectrum_slot(r1 + 8 * p0 + 64 * u) - kHighBase] = v[f][u];
+            frontend_fence();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = r1 + 8 * p0 + 64 * u;
+                // k = 0 pairs with itself: bins 0 and 512 come out of the same formulas
+                zm[f][u] = ex[f][spectrum_slot((512 - k) & 511 ? (512 - k) & 511 : 256) -
+                                 kHighBase];
+            }
+            frontend_fence();
+            frontend_section();
         }
-        // k = 256 pairs with itself: X[256] = conj(Z[256]) (lane 0 holds it, u = 4);
-        // the window's 1/2 has to be undone there
-        power[8] = 4.f * (v[4].x * v[4].x + v[4].y * v[4].y);
-        frontend_fence();
-
-        if (local == wave) EMPH_STAMP(6);
+        float power[kPair][9];
+#pragma unroll
+        for (int f = 0; f < kPair; ++f) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cf z = zm[f][u];
+                if (u == 0) z = lane == 0 ? v[f][0] : z;
+                const cf e = add_conj(v[f][u], z);
+                const cf o = cmul(tw3[u], sub_conj(v[f][u], z));
+                const cf low = e + o, high = e - o;
+                power[f][u] = low.x * low.x + low.y * low.y;            // |X[k]|^2
+                power[f][4 + u] = high.x * high.x + high.y * high.y;    // |X[512 - k]|^2
+            }
+            // k = 256 pairs with itself: X[256] = conj(Z[256]) (lane 0 holds it, u = 4);
+            // the window's 1/2 has to be undone there
+            power[f][8] = 4.f * (v[f][4].x * v[f][4].x + v[f][4].y * v[f][4].y);
+        }
         if (kPeak) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) peak = fmaxf(peak, power[j]);
-            if (lane == 0) peak = fmaxf(peak, power[8]);
+            for (int f = 0; f < kPair; ++f) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) peak = fmaxf(peak, power[f][j]);
+                if (lane == 0) peak = fmaxf(peak, power[f][8]);
+            }
             continue;
         }
 
         if (kLoud) {
             // 10 log10(max(1e-10, |X|^2)) floored at peak - 80, + A-weight,
             // clamped at MIN_DB = -100, mean over the 513 bins
-            double total = 0.;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                if (j == 8 && lane != 0) break;
-                const int k = bin_of(j);
-                float db = 10.f * log10f(fmaxf(1e-10f, power[j]));
-                db = fmaxf(db, floor_db) + weights[k];
-                total += static_cast<double>(fmaxf(db, -100.f));
-            }
+            for (int f = 0; f < kPair; ++f) {
+                double total = 0.;
 #pragma unroll
-            for (int offset = 32; offset > 0; offset >>= 1)
-                total += __shfl_xor(total, offset);
-            if (lane == 0) {
-                float value = static_cast<float>(total / 513.);
-                if (normalize) value = (value + 100.f) / 100.f;
-                loud_tile[local] = value;
+                for (int j = 0; j < 9; ++j) {
+                    if (j == 8 && lane != 0) break;
+                    const int k = bin_of(j);
+                    float db = 10.f * log10f(fmaxf(1e-10f, power[f][j]));
+                    db = fmaxf(db, floor_db) + weights[k];
+                    total += static_cast<double>(fmaxf(db, -100.f));
+                }
+#pragma unroll
+                for (int offset = 32; offset > 0; offset >>= 1)
+                    total += __shfl_xor(total, offset);
+                if (lane == 0) {
+                    float value = static_cast<float>(total / 513.);
+                    if (normalize) value = (value + 100.f) / 100.f;
+                    loud_tile[min(local + f, valid - 1)] = value;
+                }
             }
         }
 
         if (kMel) {
-            float* mag = mel_sums + wave * kMagFloats;
+            // magnitudes over the frame's own exchange buffer (its last reads are
+            // behind us: a wave's LDS operations execute in program order)
 #pragma unroll
-            // v_sqrt_f32 (1 ulp; the argument is >= 1e-6, never denormal): the
-            // correctly rounded sqrtf is ten more instructions per bin
-            for (int j = 0; j < 8; ++j)
-                mag[bin_of(j)] = __builtin_amdgcn_sqrtf(power[j] + 1e-6f);
-            if (lane == 0) mag[256] = __builtin_amdgcn_sqrtf(power[8] + 1e-6f);
+            for (int f = 0; f < kPair; ++f) {
+                float* mag = exchange + f * kExFloats;
+                // v_sqrt_f32 (1 ulp; the argument is >= 1e-6, never denormal): the
+                // correctly rounded sqrtf is ten more instructions per bin
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    mag[bin_of(j)] = __builtin_amdgcn_sqrtf(power[f][j] + 1e-6f);
+                if (lane == 0) mag[256] = __builtin_amdgcn_sqrtf(power[f][8] + 1e-6f);
+                // zero tail: the fixed-length runs read past bin 512 (weight 0, but
+                // the buffer holds spectrum bits there: 0 * NaN would poison the sum)
+                if (lane < kMagFloats - kBins) mag[kBins + lane] = 0.f;
+            }
             frontend_fence();
-            float acc = 0.f;
+            if (local == 8) EMPH_STAMP(12);
 #pragma unroll
-            for (int piece = 0; piece < kRunA / 4; ++piece) {
-                const float4 four = *reinterpret_cast<const float4*>(mag + start_a + 4 * piece);
-                acc = fmaf(weight_a[4 * piece], four.x, acc);
-                acc = fmaf(weight_a[4 * piece + 1], four.y, acc);
-                acc = fmaf(weight_a[4 * piece + 2], four.z, acc);
-                acc = fmaf(weight_a[4 * piece + 3], four.w, acc);
-            }
-            // natural log on v_log_f32 (log2, 1 ulp; the argument is >= 1e-5);
-            // (x + 10) / 10 as one fma: both within 1e-7 of the exact forms
-            float value = kLn2 * __builtin_amdgcn_logf(fmaxf(acc, 1e-5f));
-            if (normalize) value = fmaf(value, 0.1f, 1.f);
-            tile[lane * kOutStride + local] = value;
-            acc = 0.f;
+            for (int f = 0; f < kPair; ++f) {
+                const float* mag = exchange + f * kExFloats;
+                const int column = min(local + f, valid - 1);
+                float acc = 0.f;
 #pragma unroll
-            for (int piece = 0; piece < kRunB / 4; ++piece) {
-                const float4 four = *reinterpret_cast<const float4*>(mag + start_b + 4 * piece);
-                acc = fmaf(weight_b[4 * piece], four.x, acc);
-                acc = fmaf(weight_b[4 * piece + 1], four.y, acc);
-                acc = fmaf(weight_b[4 * piece + 2], four.z, acc);
-                acc = fmaf(weight_b[4 * piece + 3], four.w, acc);
-            }
-            acc += __shfl_xor(acc, 1);
-            acc += __shfl_xor(acc, 2);
-            if ((lane & 3) == 0) {
-                value = kLn2 * __builtin_amdgcn_logf(fmaxf(acc, 1e-5f));
+                for (int piece = 0; piece < kRunA / 4; ++piece) {
+                    const float4 four =
+                        *reinterpret_cast<const float4*>(mag + start_a + 4 * piece);
+                    acc = fmaf(weight_a[4 * piece], four.x, acc);
+                    acc = fmaf(weight_a[4 * piece + 1], four.y, acc);
+                    acc = fmaf(weight_a[4 * piece + 2], four.z, acc);
+                    acc = fmaf(weight_a[4 * piece + 3], four.w, acc);
+                }
+                // natural log on v_log_f32 (log2, 1 ulp; the argument is >= 1e-5);
+                // (x + 10) / 10 as one fma: both within 1e-7 of the exact forms
+                float value = kLn2 * __builtin_amdgcn_logf(fmaxf(acc, 1e-5f));
                 if (normalize) value = fmaf(value, 0.1f, 1.f);
-                tile[(64 + (lane >> 2)) * kOutStride + local] = value;
+                tile[lane * kTileStride + column] = value;
+                acc = 0.f;
+#pragma unroll
+                for (int piece = 0; piece < kRunB / 4; ++piece) {
+                    const float4 four =
+                        *reinterpret_cast<const float4*>(mag + start_b + 4 * piece);
+                    acc = fmaf(weight_b[4 * piece], four.x, acc);
+                    acc = fmaf(weight_b[4 * piece + 1], four.y, acc);
+                    acc = fmaf(weight_b[4 * piece + 2], four.z, acc);
+                    acc = fmaf(weight_b[4 * piece + 3], four.w, acc);
+                }
+                acc = quad_sum(acc);
+                if ((lane & 3) == 0) {
+                    value = kLn2 * __builtin_amdgcn_logf(fmaxf(acc, 1e-5f));
+                    if (normalize) value = fmaf(value, 0.1f, 1.f);
+                    tile[(64 + (lane >> 2)) * kTileStride + column] = value;
+                }
+                if (local == 8) EMPH_STAMP(13 + f);
             }
             frontend_fence();
         }
-        if (local == wave) EMPH_STAMP(7);
     }
-    EMPH_STAMP(8);
+    EMPH_STAMP(15);
 
     if (!kPeak) {
-        __syncthreads();
-        const int valid = min(kBlockFrames, frames - frame0);
         if (kMel) {
-            // 80 rows x 32 frames: 8 rows per pass, 128-byte segments
-            const int column = tid & 31;
-            for (int m = tid >> 5; m < kMels; m += 8)
+            // 80 rows x kWaveFrames frames: 4 * kWaveFrames-byte row segments
+            const int column = lane & (kWaveFrames - 1);
+#pragma unroll 4
+            for (int m = lane / kWaveFrames; m < kMels; m += 64 / kWaveFrames) {
+                const float value = tile[m * kTileStride + column];
                 if (column < valid)
-                    out[static_cast<int64_t>(mel_row + m) * ld + frame_off + frame0 +
-                        column] = tile[m * kOutStride + column];
+                    out[static_cast<int64_t>(mel_row + m) * ld + frame_off + frame0 + column] =
+                        value;
+            }
         }
-        if (kLoud && tid < valid)
-            out[static_cast<int64_t>(loud_row) * ld + frame_off + frame0 + tid] =
-                loud_tile[tid];
+        if (kLoud && lane < valid)
+            out[static_cast<int64_t>(loud_row) * ld + frame_off + frame0 + lane] =
+                loud_tile[lane];
+        frontend_fence();      // the next tile's writes come after these reads
     }
-    EMPH_STAMP(9);
-    }   // blocks
-
+    }   // tiles
     if (kPeak && peak_segment >= 0) {
         peak = wave_max(peak);
         // non-negative floats order like their bit patterns
@@ -519,12 +645,19 @@ __global__ __launch_bounds__(256) void frontend_kernel(
     }
 }
 
-// two workgroups per CU (LDS), each looping over its share of the blocks
-inline int frontend_grid(int n_tiles) { return n_tiles < 512 ? n_tiles : 512; }
+// two workgroups per CU (registers), each wave looping over its share of the tiles
+inline int frontend_grid(int n_tiles) {
+    const int groups = (n_tiles + 3) / 4;
+    constexpr int resident = 256 * EMPH_FE_WAVES;
+    if (EMPH_FE_WAVES != 2) return groups < resident ? groups : resident;
+#ifdef EMPH_FE_GRID_ENV
+    if (const char* env = getenv("EMPH_FE_GRID")) return atoi(env);
+#endif
+    return groups < 512 ? groups : 512;
+}
 
 size_t frontend_lds_bytes(bool loud) {
-    size_t floats = kStage + 4 * kExFloats + kMels * kOutStride + kBlockFrames +
-                    4 * kMagFloats;
+    size_t floats = 4 * kWaveFloats;
     if (loud) floats += 516;
     return floats * sizeof(float);
 }
@@ -540,6 +673,8 @@ int emph_abi_version(void) { return EMPH_ABI_VERSION; }
 const char* emph_last_error(void) { return g_error; }
 
 int64_t emph_frontend_table_size(void) { return kTabSize; }
+
+int32_t emph_frontend_block(void) { return kWaveFrames; }
 
 int emph_frontend_table_fill(float* host_table) {
     EMPH_REQUIRE(host_table != nullptr, EMPH_EINVAL, "table is null");
@@ -572,17 +707,19 @@ int emph_frontend_table_fill(float* host_table) {
     return EMPH_OK;
 }
 
-int emph_logmel(const float* audio, const int64_t* seg, const int32_t* tiles,
-                int32_t n_tiles, const float* table, const int32_t* mel_start,
-                const int32_t* mel_count, const int32_t* mel_offset,
-                const float* mel_values, int32_t mel_nnz, float* out,
-                int64_t ld, int32_t mel_row, int32_t loud_row,
-                const float* seg_peak, const float* a_weights,
-                int32_t normalize, void* stream) {
+int emph_logmel(const void* audio, int32_t audio_format, const int64_t* seg,
+                const int32_t* tiles, int32_t n_tiles, const float* table,
+                const int32_t* mel_start, const int32_t* mel_count,
+                const int32_t* mel_offset, const float* mel_values, int32_t mel_nnz,
+                float* out, int64_t ld, int32_t mel_row, int32_t loud_row,
+                const float* seg_peak, const float* a_weights, int32_t normalize,
+                void* stream) {
     if (n_tiles == 0) return EMPH_OK;
     const bool mel = mel_row >= 0, loud = loud_row >= 0;
     EMPH_REQUIRE(audio && seg && tiles && table && out, EMPH_EINVAL,
                  "emph_logmel: null pointer");
+    EMPH_REQUIRE(audio_format == EMPH_AUDIO_F32 || audio_format == EMPH_AUDIO_PCM16,
+                 EMPH_EINVAL, "emph_logmel: unknown audio format %d", audio_format);
     EMPH_REQUIRE(mel || loud, EMPH_EINVAL, "emph_logmel: no output row selected");
     EMPH_REQUIRE(!mel || (mel_start && mel_count && mel_offset && mel_values),
                  EMPH_EINVAL, "emph_logmel: mel basis is null");
@@ -593,35 +730,48 @@ int emph_logmel(const float* audio, const int64_t* seg, const int32_t* tiles,
     const size_t lds = frontend_lds_bytes(loud);
     hipStream_t s = static_cast<hipStream_t>(stream);
     float* peak = const_cast<float*>(seg_peak);
-#define EMPH_FRONTEND(MODE)                                                    \
-    EMPH_LAUNCH(frontend_kernel<MODE>, dim3(frontend_grid(n_tiles)),    \
-                       dim3(256), lds, s, audio, seg, tiles, table, mel_start, \
-                       mel_count, mel_offset, mel_values, mel_nnz, out, ld,    \
-                       mel_row, loud_row, peak, a_weights, normalize, n_tiles)
+    const bool pcm = audio_format == EMPH_AUDIO_PCM16;
+#define EMPH_FRONTEND(MODE, PCM)                                                          \
+    do {                                                                                  \
+        auto kernel = frontend_kernel<MODE, PCM>;                                         \
+        static LdsReservation reserved;                                                   \
+        if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel),     \
+                                     lds, "emph_logmel"))                                 \
+            return status;                                                                \
+        EMPH_LAUNCH(kernel, dim3(frontend_grid(n_tiles)), dim3(256), lds, s, audio, seg,  \
+                    tiles, table, mel_start, mel_count, mel_offset, mel_values, mel_nnz,  \
+                    out, ld, mel_row, loud_row, peak, a_weights, normalize, n_tiles);     \
+    } while (0)
     if (mel && loud) {
-        EMPH_FRONTEND(2);
+        if (pcm) EMPH_FRONTEND(2, true); else EMPH_FRONTEND(2, false);
     } else if (mel) {
-        EMPH_FRONTEND(0);
+        if (pcm) EMPH_FRONTEND(0, true); else EMPH_FRONTEND(0, false);
     } else {
-        EMPH_FRONTEND(3);
+        if (pcm) EMPH_FRONTEND(3, true); else EMPH_FRONTEND(3, false);
     }
     return check_launch("emph_logmel");
 }
 
-int emph_frontend_peak(const float* audio, const int64_t* seg,
-                       const int32_t* tiles, int32_t n_tiles,
-                       const float* table, float* seg_peak, void* stream) {
+int emph_frontend_peak(const void* audio, int32_t audio_format, const int64_t* seg,
+                       const int32_t* tiles, int32_t n_tiles, const float* table,
+                       float* seg_peak, void* stream) {
     if (n_tiles == 0) return EMPH_OK;
     EMPH_REQUIRE(audio && seg && tiles && table && seg_peak, EMPH_EINVAL,
                  "emph_frontend_peak: null pointer");
+    EMPH_REQUIRE(audio_format == EMPH_AUDIO_F32 || audio_format == EMPH_AUDIO_PCM16,
+                 EMPH_EINVAL, "emph_frontend_peak: unknown audio format %d", audio_format);
     const size_t lds = frontend_lds_bytes(false);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int32_t* none_i = nullptr;
-    const float* none_f = nullptr;
-    float* none_o = nullptr;
-    EMPH_LAUNCH(frontend_kernel<1>, dim3(frontend_grid(n_tiles)), dim3(256), lds,
-                       s, audio, seg, tiles, table, none_i, none_i, none_i, none_f, 0,
-                       none_o, int64_t{0}, -1, -1, seg_peak, none_f, 0, n_tiles);
+    const int32_t* mel_start = nullptr;
+    const int32_t* mel_count = nullptr;
+    const int32_t* mel_offset = nullptr;
+    const float* mel_values = nullptr;
+    const float* a_weights = nullptr;
+    float* out = nullptr;
+    float* peak = seg_peak;
+    const int64_t ld = 0;
+    const int mel_nnz = 0, mel_row = -1, loud_row = -1, normalize = 0;
+    if (audio_format == EMPH_AUDIO_PCM16) EMPH_FRONTEND(1, true); else EMPH_FRONTEND(1, false);
     return check_launch("emph_frontend_peak");
 }
 #undef EMPH_FRONTEND

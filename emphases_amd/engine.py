@@ -26,7 +26,7 @@ from . import melbasis
 from . import runtime
 from . import weights as weights_module
 
-FRONTEND_BLOCK = 32     # frames per front-end workgroup (csrc/frontend.hip)
+FRONTEND_BLOCK = None   # frames per front-end tile: emph_frontend_block()
 ATTENTION_BLOCK = 64    # queries per attention wave (csrc/transformer.hip)
 WORD_TILE = 16
 WINOGRAD_LDS_BUDGET = 160 * 1024
@@ -87,6 +87,8 @@ class Engine:
         self.winograd = winograd
         self.device = runtime.require_gpu(device)
         self.lib = runtime.library()
+        global FRONTEND_BLOCK
+        FRONTEND_BLOCK = int(self.lib.emph_frontend_block())
         self.conv_tile = conv_tile
         # when a list, every kernel launch is bracketed by HIP events on the
         # launch stream: (name, algorithmic flops, start, end)
@@ -450,13 +452,15 @@ class Engine:
                 len(plan.segments), dtype=torch.float32, device=self.device)
             with self._timed('frontend_peak'):
                 runtime.check(self.lib.emph_frontend_peak(
-                    audio.data_ptr(), table.data_ptr(), tiles.data_ptr(),
+                    audio.data_ptr(), audio_format(audio), table.data_ptr(),
+                    tiles.data_ptr(),
                     count, self.table.data_ptr(), peak.data_ptr(),
                     runtime.stream()), 'emph_frontend_peak')
         if mel_row >= 0 or loud_row >= 0:
             with self._timed('frontend_logmel'):
                 runtime.check(self.lib.emph_logmel(
-                    audio.data_ptr(), table.data_ptr(), tiles.data_ptr(),
+                    audio.data_ptr(), audio_format(audio), table.data_ptr(),
+                    tiles.data_ptr(),
                     count, self.table.data_ptr(), self.mel_start.data_ptr(),
                     self.mel_count.data_ptr(), self.mel_offset.data_ptr(),
                     self.mel_values.data_ptr(), self.mel_nnz, out.data_ptr(),
@@ -568,7 +572,8 @@ class Engine:
                 tracks=None):
         """Scores of every word of every segment.
 
-        audio: float32 device tensor, all utterances back to back.
+        audio: float32 (or int16 PCM) device tensor, all utterances back to
+            back.
         Returns (scores, logits): float32 [ld_words] on the packed word axis
         (`plan.word_columns()` picks the valid entries; other entries are
         undefined).  The tensors are workspace buffers: they are overwritten
@@ -596,7 +601,8 @@ class Engine:
             word_tiles, word_size = meta[('tiles', words, self.word_block)]
             runtime.check(self.lib.emph_prominence_forward(
                 ctypes.byref(self.model), audio.data_ptr(),
-                meta['table'][0].data_ptr(), frontend_tiles.data_ptr(),
+                audio_format(audio), meta['table'][0].data_ptr(),
+                frontend_tiles.data_ptr(),
                 frontend_size // runtime.TILE_FIELDS, frame_tiles.data_ptr(),
                 frame_size // runtime.TILE_FIELDS, block,
                 word_tiles.data_ptr(), word_size // runtime.TILE_FIELDS,
@@ -733,6 +739,16 @@ class Engine:
             graph.replay()
             return held[0] is not None
         return replay, scores, logits
+
+
+def audio_format(audio):
+    """EMPH_AUDIO_* of a packed audio tensor: float32, or 16-bit PCM (the
+    front-end applies the x / 32768 of `load.wav` itself)."""
+    if audio.dtype == torch.float32:
+        return runtime.AUDIO_F32
+    if audio.dtype == torch.int16:
+        return runtime.AUDIO_PCM16
+    raise TypeError(f'packed audio must be float32 or int16, not {audio.dtype}')
 
 
 def check_bounds(plan, method):

@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 14
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -25,6 +25,7 @@ ACTIVATIONS = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2, 'silu': 3,
                'leaky_relu': 4}
 REDUCTIONS = {'sum': 0, 'average': 1, 'max': 2, 'center': 3}
 POSTPROCESS = {None: 0, 'bce': 1, 'mse': 2}
+AUDIO_F32, AUDIO_PCM16 = 0, 1
 
 _c = ctypes
 _ptr, _i32, _i64, _f32 = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_float
@@ -35,11 +36,12 @@ SIGNATURES = {
     'emph_last_error': (_c.c_char_p, []),
     'emph_frontend_table_size': (_i64, []),
     'emph_frontend_table_fill': (_c.c_int, [_ptr]),
+    'emph_frontend_block': (_i32, []),
     'emph_logmel': (_c.c_int, [
-        _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _i64,
-        _i32, _i32, _ptr, _ptr, _i32, _ptr]),
+        _ptr, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr,
+        _i64, _i32, _i32, _ptr, _ptr, _i32, _ptr]),
     'emph_frontend_peak': (_c.c_int, [
-        _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _ptr]),
+        _ptr, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr]),
     'emph_pitch_rows': (_c.c_int, [
         _ptr, _ptr, _ptr, _i64, _i32, _i32, _i32, _f32, _f32, _ptr]),
     'emph_conv_pack_size': (_i64, [_i32, _i32, _i32]),
@@ -73,7 +75,7 @@ SIGNATURES = {
         _ptr, _i64, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
     'emph_prominence_workspace_floats': (_i64, [_i32, _i32, _i64, _i64]),
     'emph_prominence_forward': (_c.c_int, [
-        _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _i32, _i32, _ptr, _i32, _ptr,
+        _ptr, _ptr, _i32, _ptr, _ptr, _i32, _ptr, _i32, _i32, _ptr, _i32, _ptr,
         _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
     'emph_gather_columns': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _i32, _ptr, _i32, _ptr]),

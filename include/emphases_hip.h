@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 12
+#define EMPH_ABI_VERSION 14
 
 /* Segment-table fields */
 enum {
@@ -81,6 +81,13 @@ enum {
     EMPH_REDUCE_CENTER = 3
 };
 
+/* Sample formats of the packed audio buffer.  The reference converts 16-bit
+ * PCM to float32 on the host when it loads a file (torchaudio.load,
+ * emphases/load.py:11-17); EMPH_AUDIO_PCM16 moves that x / 32768 into the
+ * front-end so that half the bytes cross PCIe and HBM.  Results are identical
+ * bit for bit (the scale is an exact power of two). */
+enum { EMPH_AUDIO_F32 = 0, EMPH_AUDIO_PCM16 = 1 };
+
 /* Postprocess (emphases/core.py:335-342) */
 enum { EMPH_POST_NONE = 0, EMPH_POST_SIGMOID = 1, EMPH_POST_CLAMP01 = 2 };
 
@@ -103,6 +110,10 @@ const char* emph_last_error(void);
  * library; fill it on the host once and upload it. */
 int64_t emph_frontend_table_size(void);
 
+/* Frames per tile of the frame-axis tile table emph_logmel / emph_frontend_peak
+ * walk (one wave transforms one tile at a time). */
+int32_t emph_frontend_block(void);
+
 /* Fill `host_table` (emph_frontend_table_size() floats), computed in double
  * precision.  Replaces torch.hann_window (emphases/data/preprocess/mels.py:
  * 19-29) and the FFT plan inside torch.stft (mels.py:39-47). */
@@ -116,9 +127,10 @@ int emph_frontend_table_fill(float* host_table);
  * (mels.py:51), mel projection + log(clamp(.,1e-5)) (mels.py:94-109) and the
  * optional (x+10)/10 (mels.py:57-58) — none of it materialised.
  *
- *   audio        float32 [*]        all utterances back to back
+ *   audio        float32 / int16 [*] all utterances back to back (audio_format)
  *   seg          int64 [n_seg][8]   segment table
- *   tiles        int32 [n_tiles][4] tile table of the frame axis, 32-frame blocks
+ *   tiles        int32 [n_tiles][4] tile table of the frame axis, blocks of
+ *                                   emph_frontend_block() frames
  *   table        float32            from emph_frontend_table_fill
  *   mel_start/mel_count/mel_offset  int32 [80] run of each filterbank row
  *   mel_values   float32 [nnz]      run values (librosa.filters.mel restated);
@@ -132,21 +144,22 @@ int emph_frontend_table_fill(float* host_table);
  *   a_weights    float32 [513]      A-weighting minus REF_DB (loudness only)
  *   normalize    0/1                emphases NORMALIZE switch
  */
-int emph_logmel(const float* audio, const int64_t* seg, const int32_t* tiles,
-                int32_t n_tiles, const float* table, const int32_t* mel_start,
-                const int32_t* mel_count, const int32_t* mel_offset,
-                const float* mel_values, int32_t mel_nnz, float* out,
-                int64_t ld, int32_t mel_row, int32_t loud_row,
-                const float* seg_peak, const float* a_weights,
-                int32_t normalize, void* stream);
+int emph_logmel(const void* audio, int32_t audio_format, const int64_t* seg,
+                const int32_t* tiles, int32_t n_tiles, const float* table,
+                const int32_t* mel_start, const int32_t* mel_count,
+                const int32_t* mel_offset, const float* mel_values,
+                int32_t mel_nnz, float* out, int64_t ld, int32_t mel_row,
+                int32_t loud_row, const float* seg_peak,
+                const float* a_weights, int32_t normalize, void* stream);
 
 /* Per-chunk max power spectrum value, needed by librosa.amplitude_to_db's
  * top_db=80 floor, which is relative to the max over the WHOLE chunk
  * (emphases/data/preprocess/loudness.py:84-93).  `seg_peak` float32 [n_seg]
  * must be zeroed by the caller before the launch. */
-int emph_frontend_peak(const float* audio, const int64_t* seg,
-                       const int32_t* tiles, int32_t n_tiles,
-                       const float* table, float* seg_peak, void* stream);
+int emph_frontend_peak(const void* audio, int32_t audio_format,
+                       const int64_t* seg, const int32_t* tiles,
+                       int32_t n_tiles, const float* table, float* seg_peak,
+                       void* stream);
 
 /* Pitch / periodicity rows of the feature matrix.
  *
@@ -444,11 +457,12 @@ int64_t emph_prominence_workspace_floats(int32_t features, int32_t channels,
  * (emphases/core.py:295-342) over emphases.Model.forward (emphases/model/
  * core.py:89-138) of the convolutional configurations with encoder
  * kernel_size 3 and mel features.  The tables are those of the individual
- * entry points: `frontend_tiles` with 32-frame blocks, `frame_tiles` with
+ * entry points: `frontend_tiles` with blocks of emph_frontend_block() frames, `frame_tiles` with
  * block `tile_n` (32 or 64; 64 for conv_variant 1), `word_tiles` with block
  * emph_word_decoder_block(...).  Enqueues on `stream`; allocates nothing. */
-int emph_prominence_forward(const emph_conv_model* model, const float* audio,
-                            const int64_t* seg, const int32_t* frontend_tiles,
+int emph_prominence_forward(const emph_conv_model* model, const void* audio,
+                            int32_t audio_format, const int64_t* seg,
+                            const int32_t* frontend_tiles,
                             int32_t n_frontend_tiles,
                             const int32_t* frame_tiles, int32_t n_frame_tiles,
                             int32_t tile_n, const int32_t* word_tiles,

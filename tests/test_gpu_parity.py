@@ -427,7 +427,7 @@ def test_fused_forward_equals_step_by_step(cases, default_engine):
     assert torch.equal(fused_logits[columns], stepped_logits[columns])
     library = runtime.library()
     assert library.emph_prominence_forward(
-        None, 0, 0, None, 0, None, 0, 32, None, 0, None, None, 0, 0, 0, None,
+        None, 0, 0, 0, None, 0, None, 0, 32, None, 0, None, None, 0, 0, 0, None,
         None, None) == -1
 
 

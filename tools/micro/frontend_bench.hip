@@ -6,11 +6,15 @@
 #include <vector>
 #include <math.h>
 __device__ unsigned long long* g_stamps = nullptr;
+#ifdef NO_STAMPS
+#define EMPH_STAMP(slot)
+#endif
 #ifdef STAMP_FIRST   // the first block of every workgroup instead of its last
 #define EMPH_STAMP_KEEP(p) (*(p) == 0)
 #else
 #define EMPH_STAMP_KEEP(p) true
 #endif
+#ifndef EMPH_STAMP
 #define EMPH_STAMP(slot)                                                          \
     do {                                                                          \
         if (g_stamps != nullptr && (threadIdx.x & 63) == 0) {                     \
@@ -19,6 +23,7 @@ __device__ unsigned long long* g_stamps = nullptr;
             if (EMPH_STAMP_KEEP(p_)) *p_ = __builtin_amdgcn_s_memrealtime();      \
         }                                                                         \
     } while (0)
+#endif
 #include "../../emphases_amd/csrc/frontend.hip"
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -33,7 +38,7 @@ int main() {
         hseg[s * 8 + 0] = static_cast<int64_t>(s) * samples; hseg[s * 8 + 1] = samples;
         hseg[s * 8 + 2] = 0; hseg[s * 8 + 3] = samples;
         hseg[s * 8 + 4] = 16 + s * 1008; hseg[s * 8 + 5] = frames;
-        for (int t = 0; t < frames; t += 32) { tiles.push_back(s); tiles.push_back(t); tiles.push_back(16 + s * 1008); tiles.push_back(frames); }
+        for (int t = 0; t < frames; t += emph_frontend_block()) { tiles.push_back(s); tiles.push_back(t); tiles.push_back(16 + s * 1008); tiles.push_back(frames); }
     }
     // a plausible sparse basis: 80 rows, runs like the real one
     std::vector<int32_t> start(80), count(80), offset(80);
@@ -58,8 +63,9 @@ int main() {
     CHECK(hipMalloc(&dcount, 320)); CHECK(hipMemcpy(dcount, count.data(), 320, hipMemcpyHostToDevice));
     CHECK(hipMalloc(&doffset, 320)); CHECK(hipMemcpy(doffset, offset.data(), 320, hipMemcpyHostToDevice));
     const int n_tiles = tiles.size() / 4;
+    int32_t* work; CHECK(hipMalloc(&work, 8)); CHECK(hipMemset(work, 0, 8));
     auto launch = [&]() {
-        int status = emph_logmel(audio, seg, dtiles, n_tiles, dtable, dstart, dcount, doffset, dvalues,
+        int status = emph_logmel(audio, 0, seg, dtiles, n_tiles, dtable, dstart, dcount, doffset, dvalues,
                                  (int)values.size(), out, ld, 0, -1, nullptr, nullptr, 0, nullptr);
         if (status) { printf("launch failed %d %s\n", status, emph_last_error()); exit(1); }
     };
@@ -77,8 +83,8 @@ int main() {
     launch(); CHECK(hipDeviceSynchronize());
     std::vector<unsigned long long> host(slots);
     CHECK(hipMemcpy(host.data(), stamps, slots * 8, hipMemcpyDeviceToHost));
-    const char* names[16] = {"start", "staged", "f0 loaded", "f0 pass1", "f0 pass2", "f0 pass3", "f0 split", "f0 mel", "frames", "stored", "", "", "", "", "", ""};
-    for (int slot = 1; slot < 10; ++slot) {
+    const char* names[16] = {"start", "tile", "top", "windowed", "nextload", "A T1", "B T1", "A T2", "B T2", "A hi", "B hi", "power", "mag wr", "A mel", "B mel", ""};
+    for (int slot = 1; slot < 15; ++slot) {
         std::vector<double> values2;
         for (size_t i = 0; i < slots; i += 16) if (host[i] && host[i + slot]) values2.push_back((host[i + slot] - host[i]) * 0.01);
         if (values2.empty()) continue;
