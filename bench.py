@@ -49,6 +49,8 @@ def parse_args():
                         choices=['conv', 'transformer'])
     parser.add_argument('--tile', type=int, default=None)
     parser.add_argument('--no-cpu-baseline', action='store_true')
+    parser.add_argument('--no-api', action='store_true',
+                        help='skip the end-to-end public-API measurement')
     parser.add_argument('--streams', type=int, default=2,
                         help='batches in flight: consecutive steps alternate '
                              'between this many HIP streams (each with its '
@@ -126,6 +128,59 @@ def cpu_baseline(audios, bounds, seconds=12.0):
                   f'time (B=1) through oracle/prominence.py, torch CPU fp32, '
                   f'{cores} threads of {os.cpu_count()} logical cores, '
                   f'{cpu_model()}'}
+
+
+def end_to_end_api(audios, alignments, rounds=40):
+    """SURVEY.md §8(d) protocol (ii): the public batch API on the same 64
+    utterances, host tensors in, scores out - chunk planning, staging, H2D,
+    kernels, D2H and the split into per-utterance tensors all inside the
+    clock.  `call` = one synchronous `from_alignments_and_audios` after the
+    other; `pipelined` = `Session.submit` with two batches in flight (what
+    `from_files_to_files` does).  float32 = the reference's input type
+    (pageable CPU tensors); pcm16 = the same audio as 16-bit PCM tensors."""
+    floats = [torch.from_numpy(a) for a in audios]
+    pcm = [torch.from_numpy(np.rint(a * 32768.).astype(np.int16))
+           for a in audios]
+    session = emphases_amd.get_session(None, 0)
+    result = {}
+    reference = None
+    for name, tensors in (('float32', floats), ('pcm16', pcm)):
+        for _ in range(8):          # both lanes: buffers, layout cache, graph
+            scores = emphases_amd.from_alignments_and_audios(
+                alignments, tensors, 16000)
+        torch.cuda.synchronize()
+        laps = []
+        for _ in range(rounds):
+            start = time.perf_counter()
+            scores = emphases_amd.from_alignments_and_audios(
+                alignments, tensors, 16000)
+            laps.append(time.perf_counter() - start)
+        call = float(np.mean(laps))
+        start = time.perf_counter()
+        previous = None
+        for _ in range(rounds):
+            pending = session.submit(alignments, tensors, 16000)
+            if previous is not None:
+                previous.result()
+            previous = pending
+        scores = previous.result()
+        piped = (time.perf_counter() - start) / rounds
+        flat = torch.cat([s.reshape(-1) for s in scores])
+        if reference is None:
+            reference = flat
+        result[name] = {
+            'ms_per_call': call * 1e3,
+            'ms_per_call_median': float(np.median(laps)) * 1e3,
+            'ms_per_call_worst': float(np.max(laps)) * 1e3,
+            'utterances_per_s': len(audios) / call,
+            'ms_per_call_pipelined': piped * 1e3,
+            'utterances_per_s_pipelined': len(audios) / piped,
+            'bit_identical_to_float32': bool(torch.equal(flat, reference))}
+    result['what'] = (
+        'emphases_amd.from_alignments_and_audios on 64 x 10 s host tensors: '
+        'planning + staging + H2D + kernels + D2H; pipelined = 2 batches in '
+        'flight (session.Session)')
+    return result
 
 
 def main():
@@ -297,6 +352,8 @@ def main():
         }
         check = float(scores[columns].sum().item())
         result['checksum'] = check
+        if world == 1 and args.config == 'conv' and not args.no_api:
+            result['end_to_end_api'] = end_to_end_api(audios, alignments)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(audios, bounds)
         print(json.dumps(result), flush=True)

@@ -16,9 +16,10 @@ from . import runtime  # noqa: F401
 from . import synth  # noqa: F401
 from . import weights  # noqa: F401
 from . import engine  # noqa: F401
+from . import session  # noqa: F401
 from .alignment import Alignment, Word  # noqa: F401
 from .core import (  # noqa: F401
     Model, active_config, configure, downsample, from_alignment_and_audio,
     from_alignments_and_audios, from_file, from_file_to_file,
-    from_files_to_files, from_text_and_audio, get_engine, infer,
+    from_files_to_files, from_text_and_audio, get_engine, get_session, infer,
     inference_context, postprocess, preprocess, resample)

@@ -107,6 +107,19 @@ class Alignment:
     def words(self):
         return list(self._words)
 
+    def times(self):
+        """float64 [W, 2] (start, end) seconds of every word (cached: the
+        batch planner reads all words of all utterances as arrays)."""
+        cached = getattr(self, '_times', None)
+        if cached is None or cached.shape[0] != len(self._words):
+            import numpy as np
+            cached = np.array(
+                [(word._start, word._end) if isinstance(word, Word)
+                 else (word.start(), word.end()) for word in self._words],
+                dtype=np.float64).reshape(len(self._words), 2)
+            self._times = cached
+        return cached
+
     def word_bounds(self, sample_rate, hopsize=1, silences=False):
         words = [
             word for word in self._words

@@ -19,6 +19,7 @@ import dataclasses
 
 import numpy as np
 
+from . import alignment as alignment_module
 from . import config as cfg
 from . import convert
 from . import runtime
@@ -42,8 +43,25 @@ class Segment:
 
 
 def _word_times(alignment):
-    return [(word.start(), word.end()) for word in
-            (alignment[i] for i in range(len(alignment)))]
+    """float64 [W, 2] (start, end) seconds of the words of an alignment that
+    follows the pypar protocol (`len()`, `[i]`, `.start()`, `.end()`)."""
+    if hasattr(alignment, 'times'):
+        return alignment.times()
+    return np.array(
+        [(word.start(), word.end()) for word in
+         (alignment[i] for i in range(len(alignment)))],
+        dtype=np.float64).reshape(len(alignment), 2)
+
+
+def _foreign(alignment):
+    """An alignment object that is not ours but carries its own
+    `word_bounds` (a real `pypar.Alignment`): the reference takes the chunk's
+    bounds from `alignment[start:end].word_bounds(...)` (`core.py:384-392`),
+    so whatever that method returns is what the model must see."""
+    return type(alignment) is not alignment_module.Alignment and \
+        not isinstance(alignment, (list, np.ndarray,
+                                   alignment_module.Alignment)) and \
+        hasattr(alignment, 'word_bounds')
 
 
 def chunk_utterance(alignment, num_samples, batch_size=None, utterance=0):
@@ -52,8 +70,9 @@ def chunk_utterance(alignment, num_samples, batch_size=None, utterance=0):
     The reference's per-word Python loops (`core.py:361-400`) as float64 array
     operations with the same IEEE steps: floor division, a sequential running
     sum (`np.cumsum`), truncation."""
-    times = alignment if isinstance(alignment, list) else \
+    times = alignment if isinstance(alignment, (list, np.ndarray)) else \
         _word_times(alignment)
+    foreign = _foreign(alignment)
     padded = num_samples + 2 * cfg.PADDING
     total_frames = int(padded / cfg.HOPSIZE)                     # core.py:359
     limit = total_frames if batch_size is None else batch_size
@@ -75,8 +94,14 @@ def chunk_utterance(alignment, num_samples, batch_size=None, utterance=0):
         over = np.nonzero(running.astype(np.int64) > limit)[0]
         end = start + 1 + int(over[0]) if over.size else count
         origin = int(start_frames[start])
-        bounds = np.stack(
-            [start_frames[start:end], end_frames[start:end]]) - origin
+        if foreign:
+            # core.py:384-392, verbatim: the caller's own slicing and bounds
+            bounds = np.asarray(alignment[start:end].word_bounds(
+                cfg.SAMPLE_RATE, cfg.HOPSIZE, silences=True),
+                dtype=np.int64).reshape(-1, 2).T
+        else:
+            bounds = np.stack(
+                [start_frames[start:end], end_frames[start:end]]) - origin
         start_sample = int(convert.frames_to_samples(
             int(convert.seconds_to_frames(float(starts[start])))))  # core.py:395
         end_sample = int(convert.frames_to_samples(
@@ -92,6 +117,67 @@ def chunk_utterance(alignment, num_samples, batch_size=None, utterance=0):
                 bounds))
         start = end
     return segments
+
+
+def plan_batch(alignments, lengths, batch_size=None):
+    """`Plan` of a whole batch: utterance u has `lengths[u]` samples at offset
+    sum(lengths[:u]) of the packed audio.  One vectorised pass over all words
+    of all utterances when no utterance needs more than one chunk (the default
+    `batch_size=None`); the per-utterance planner otherwise."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    offsets = np.cumsum(lengths) - lengths
+    slow = batch_size is not None or any(_foreign(a) for a in alignments)
+    if not slow and len(alignments):
+        tables = [a.times() if type(a) is alignment_module.Alignment else
+                  np.asarray(a, dtype=np.float64).reshape(-1, 2)
+                  if isinstance(a, (list, np.ndarray)) else _word_times(a)
+                  for a in alignments]
+        counts = np.array([len(t) for t in tables], dtype=np.int64)
+        keep = counts > 0
+        times = np.concatenate(tables) if counts.sum() else \
+            np.zeros((0, 2), dtype=np.float64)
+        starts, ends = times[:, 0], times[:, 1]
+        word_frames = convert.seconds_to_frames(ends - starts)
+        first = (np.cumsum(counts) - counts)[keep]
+        last = first + counts[keep] - 1
+        # one chunk holds the whole utterance unless the running frame count of
+        # its words (the last one never counts, core.py:369-381) passes the
+        # limit; the counts are whole numbers, so any summation order is exact
+        running = np.concatenate([[0.], np.cumsum(word_frames)])
+        padded = lengths[keep] + 2 * cfg.PADDING
+        limit = (padded / cfg.HOPSIZE).astype(np.int64)          # core.py:359
+        # the largest partial sum of an utterance is its last one (durations
+        # are not negative in a gap-free alignment; if they are, plan slowly)
+        slow = bool(np.any(
+            (running[last] - running[first]).astype(np.int64) > limit)) or \
+            bool(np.any(word_frames < 0))
+    if slow or not len(alignments):
+        segments = []
+        for index, (alignment, length) in enumerate(zip(alignments, lengths)):
+            segments.extend(
+                chunk_utterance(alignment, int(length), batch_size, index))
+        return Plan(segments, offsets, lengths)
+    start_frames = (starts * cfg.SAMPLE_RATE / cfg.HOPSIZE).astype(np.int64)
+    end_frames = (ends * cfg.SAMPLE_RATE / cfg.HOPSIZE).astype(np.int64)
+    start_sample = convert.seconds_to_frames(starts[first]).astype(np.int64) \
+        * cfg.HOPSIZE                                            # core.py:395
+    end_sample = convert.seconds_to_frames(ends[last]).astype(np.int64) \
+        * cfg.HOPSIZE                                            # core.py:398
+    start_sample = np.clip(start_sample, 0, padded)
+    end_sample = np.clip(end_sample, 0, padded)                  # slice clamps
+    length = np.maximum(0, end_sample - start_sample)
+    # reflect padding needs more than PADDING samples (mels.py:31-36)
+    alive = length > cfg.PADDING
+    utterance = np.nonzero(keep)[0][alive]
+    words = counts[keep][alive]
+    selected = np.repeat(alive, counts[keep])
+    origin = np.repeat(start_frames[first], counts[keep])
+    bounds = np.stack([start_frames, end_frames]) - origin
+    frames = 1 + (length + 2 * cfg.PADDING - cfg.NUM_FFT) // cfg.HOPSIZE
+    return Plan.from_columns(
+        utterance, np.zeros(len(utterance), dtype=np.int64),
+        start_sample[alive], length[alive], frames[alive], words,
+        bounds[:, selected], offsets, lengths)
 
 
 def _round_up(value, multiple):
@@ -118,16 +204,42 @@ class Plan:
     def __init__(self, segments, audio_offsets, audio_lengths):
         """`audio_offsets[u]`, `audio_lengths[u]`: where utterance `u` sits in
         the packed audio buffer."""
-        self.segments = segments
         count = len(segments)
-        frames = np.array([s.frames for s in segments], dtype=np.int64)
+        column = lambda name: np.array(  # noqa: E731
+            [getattr(s, name) for s in segments], dtype=np.int64)
         words = np.array([s.bounds.shape[1] for s in segments], dtype=np.int64)
+        bounds = np.concatenate([s.bounds for s in segments], axis=1) \
+            if count else np.zeros((2, 0), dtype=np.int64)
+        self._build(
+            column('utterance'), column('start_word'), column('start_sample'),
+            column('length'), column('frames'), words, bounds,
+            np.asarray(audio_offsets, dtype=np.int64),
+            np.asarray(audio_lengths, dtype=np.int64))
+        self._segments = list(segments)
+
+    @classmethod
+    def from_columns(cls, utterance, start_word, start_sample, length, frames,
+                     words, bounds, audio_offsets, audio_lengths):
+        """Plan from per-segment arrays (`bounds`: int64 [2, sum(words)], the
+        segments' chunk-relative word bounds back to back)."""
+        plan = cls.__new__(cls)
+        plan._build(utterance, start_word, start_sample, length, frames, words,
+                    bounds, np.asarray(audio_offsets, dtype=np.int64),
+                    np.asarray(audio_lengths, dtype=np.int64))
+        plan._segments = None
+        return plan
+
+    def _build(self, utterance, start_word, start_sample, length, frames,
+               words, bounds, audio_offsets, audio_lengths):
+        count = len(frames)
         frame_off = LEAD + np.concatenate(
             [[0], np.cumsum(_round_up(frames, ALIGN))[:-1]]) \
             if count else np.zeros(0, dtype=np.int64)
         word_off = LEAD + np.concatenate(
             [[0], np.cumsum(_round_up(words, ALIGN))[:-1]]) \
             if count else np.zeros(0, dtype=np.int64)
+        self.utterance = utterance
+        self.start_word = start_word
         self.frames = frames
         self.words = words
         self.frame_off = frame_off.astype(np.int64)
@@ -138,30 +250,54 @@ class Plan:
             LEAD + _round_up(words, ALIGN).sum() + TAIL) if count else TAIL
         self.total_frames = int(frames.sum())
         self.total_words = int(words.sum())
+        self.segment_bounds = bounds          # [2, total_words], packed
 
         table = np.zeros((count, runtime.SEG_FIELDS), dtype=np.int64)
-        for i, segment in enumerate(segments):
-            table[i, runtime.SEG_AUDIO_OFF] = audio_offsets[segment.utterance]
-            table[i, runtime.SEG_AUDIO_LEN] = audio_lengths[segment.utterance]
-            table[i, runtime.SEG_START] = segment.start_sample
-            table[i, runtime.SEG_LENGTH] = segment.length
+        if count:
+            table[:, runtime.SEG_AUDIO_OFF] = audio_offsets[utterance]
+            table[:, runtime.SEG_AUDIO_LEN] = audio_lengths[utterance]
+            table[:, runtime.SEG_START] = start_sample
+            table[:, runtime.SEG_LENGTH] = length
         table[:, runtime.SEG_FRAME_OFF] = self.frame_off
         table[:, runtime.SEG_FRAMES] = frames
         table[:, runtime.SEG_WORD_OFF] = self.word_off
         table[:, runtime.SEG_WORDS] = words
         self.table = table
 
-        bounds = np.zeros((2, self.ld_words), dtype=np.int32)
-        word_segment = np.full(self.ld_words, -1, dtype=np.int32)
-        for i, segment in enumerate(segments):
-            lo = int(self.word_off[i])
-            hi = lo + int(words[i])
-            bounds[:, lo:hi] = segment.bounds
-            word_segment[lo:hi] = i
-        self.bounds = bounds
-        self.word_segment = word_segment
+        # packed word-axis column of every word, in segment order
+        first = np.cumsum(words) - words
+        self._columns = (
+            np.repeat(self.word_off - first, words) +
+            np.arange(self.total_words, dtype=np.int64)) if count else \
+            np.zeros(0, dtype=np.int64)
+        self.bounds = np.zeros((2, self.ld_words), dtype=np.int32)
+        self.word_segment = np.full(self.ld_words, -1, dtype=np.int32)
+        if self.total_words:
+            self.bounds[:, self._columns] = bounds
+            self.word_segment[self._columns] = np.repeat(
+                np.arange(count, dtype=np.int32), words)
         self._tiles = {}
         self._pieces = {}
+
+    @property
+    def segments(self):
+        """The segments as `Segment` objects (built on demand: the batch
+        planner works on arrays)."""
+        if self._segments is None:
+            first = np.cumsum(self.words) - self.words
+            self._segments = [
+                Segment(int(self.utterance[i]), int(self.start_word[i]),
+                        int(self.start_word[i] + self.words[i]),
+                        int(self.table[i, runtime.SEG_START]),
+                        int(self.table[i, runtime.SEG_LENGTH]),
+                        int(self.frames[i]),
+                        self.segment_bounds[
+                            :, first[i]:first[i] + self.words[i]])
+                for i in range(len(self.frames))]
+        return self._segments
+
+    def __len__(self):
+        return len(self.frames)
 
     def tiles(self, axis, block):
         key = (axis, block)
@@ -183,11 +319,7 @@ class Plan:
 
     def word_columns(self):
         """Packed word-axis column of every word, in segment order."""
-        if not len(self.segments):
-            return np.zeros(0, dtype=np.int64)
-        return np.concatenate([
-            np.arange(off, off + n) for off, n in
-            zip(self.word_off, self.words)])
+        return self._columns
 
     def pack_metadata(self, tile_requests):
         """All integer metadata as one int32 array plus the element offset of
@@ -264,6 +396,8 @@ def chunk_audio(audio, segment):
     front-end does this indexing on the fly)."""
     import torch
     audio = audio.reshape(-1)
+    if audio.dtype == torch.int16:                     # 16-bit PCM
+        audio = audio.to(torch.float32) / 32768.
     first = segment.start_sample - cfg.PADDING
     last = first + segment.length
     lo, hi = max(first, 0), min(last, int(audio.shape[0]))

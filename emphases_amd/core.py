@@ -99,44 +99,39 @@ def _tracks(engine, plan, audios, pitch_tracker, gpu):
     return packed.pin_memory().to(engine.device, non_blocking=True)
 
 
+@functools.lru_cache(maxsize=8)
+def _session(checkpoint, device_index, config):
+    from . import session
+    return session.Session(_engine(checkpoint, device_index, config), depth=2)
+
+
+def get_session(checkpoint=None, gpu=None, config=None):
+    """Cached `session.Session` (batches in flight on their own streams) of
+    the cached engine."""
+    device = runtime.require_gpu(gpu)
+    index = device.index if device.index is not None else \
+        torch.cuda.current_device()
+    checkpoint = None if checkpoint is None else os.fspath(checkpoint)
+    return _session(checkpoint, index, config or active_config())
+
+
 def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
                                checkpoint=None, batch_size=None, gpu=None,
                                config=None, pitch_tracker=None):
     """Scores for many utterances in one ragged batch.
 
+    audios: float tensors [1, S] (or [S]); int16 tensors are taken as 16-bit
+        PCM (x / 32768, what `load.audio(file, raw=True)` returns) and travel
+        to the device as they are.
     pitch_tracker: for configurations with PITCH_FEATURE / PERIODICITY_FEATURE,
         the stand-in for `penn.from_audio` (`data/preprocess/core.py:84-92`):
         `(chunk audio [1, Sc]) -> (pitch [1, Fc] Hz, periodicity [1, Fc])`;
         default: `penn` itself, if installed.
     Returns a list of float32 tensors [1, W_i] (CPU if `gpu is None`)."""
-    engine = get_engine(checkpoint, gpu, config)
-    device = engine.device
-    audios = [resample(audio, sample_rate)[:1].reshape(-1) for audio in audios]
-    lengths = [int(audio.shape[0]) for audio in audios]
-    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]]).astype(np.int64) \
-        if lengths else np.zeros(0, dtype=np.int64)
-    segments = []
-    for index, (item, length) in enumerate(zip(alignments, lengths)):
-        segments.extend(
-            batch.chunk_utterance(item, length, batch_size, index))
-    results = [torch.zeros((1, 0)) for _ in audios]
-    if segments:
-        plan = batch.Plan(segments, offsets, lengths)
-        # forward() returns workspace buffers of a cached engine: hold its
-        # lock until the result is detached from them
-        with torch.cuda.device(device), engine.lock:
-            tracks = _tracks(engine, plan, audios, pitch_tracker, gpu)
-            packed = engine.pack_audio(audios)
-            scores, _ = engine.forward(packed, plan, tracks=tracks)
-            scores = scores.clone() if gpu is not None else scores.cpu()
-        pieces = [[] for _ in audios]
-        for segment, off, count in zip(
-                plan.segments, plan.word_off, plan.words):
-            pieces[segment.utterance].append(scores[off:off + count])
-        results = [
-            torch.cat(piece)[None] if piece else result
-            for piece, result in zip(pieces, results)]
-    return results
+    session = get_session(checkpoint, gpu, config)
+    return session.run(
+        alignments, audios, sample_rate, batch_size,
+        on_device=gpu is not None, pitch_tracker=pitch_tracker)
 
 
 def from_alignment_and_audio(alignment, audio, sample_rate, checkpoint=None,
@@ -199,7 +194,9 @@ def from_files_to_files(text_files, audio_files, output_prefixes=None,
                         checkpoint=None, batch_size=None, gpu=None,
                         utterances_per_batch=64):
     """`core.py:115-179`, but the files are processed in ragged batches of
-    `utterances_per_batch` instead of one at a time."""
+    `utterances_per_batch` instead of one at a time, two batches in flight:
+    the files of batch i+1 are read and staged while batch i computes, and
+    16-bit PCM files travel to the device as 16-bit PCM."""
     from pathlib import Path
     text_files, audio_files = list(text_files), list(audio_files)
     if output_prefixes is None:
@@ -207,17 +204,27 @@ def from_files_to_files(text_files, audio_files, output_prefixes=None,
     for file in text_files:
         if not str(file).endswith(('.TextGrid', '.json')):
             from_text_and_audio(None, None, None)
+    session = get_session(checkpoint, gpu)
+    in_flight = None
+
+    def finish(job):
+        pending, alignments, prefixes = job
+        for item, scores, prefix in zip(alignments, pending.result(), prefixes):
+            _save(item, scores, prefix)
+
     for first in range(0, len(text_files), utterances_per_batch):
         last = first + utterances_per_batch
         alignments = [
             alignment_module.Alignment(file)
             for file in text_files[first:last]]
-        audios = [load.audio(file) for file in audio_files[first:last]]
-        results = from_alignments_and_audios(
-            alignments, audios, cfg.SAMPLE_RATE, checkpoint, batch_size, gpu)
-        for item, scores, prefix in zip(
-                alignments, results, output_prefixes[first:last]):
-            _save(item, scores, prefix)
+        audios = [load.audio(file, raw=True) for file in audio_files[first:last]]
+        pending = session.submit(
+            alignments, audios, cfg.SAMPLE_RATE, batch_size)
+        if in_flight is not None:
+            finish(in_flight)
+        in_flight = (pending, alignments, output_prefixes[first:last])
+    if in_flight is not None:
+        finish(in_flight)
 
 
 ###############################################################################

@@ -94,6 +94,7 @@ class Engine:
         # launch stream: (name, algorithmic flops, start, end)
         self.timers = None
         self._workspace = {}
+        self._staging = {}
         # forward() returns workspace buffers: callers that may run on several
         # host threads hold this lock from pack_audio() until they have cloned
         # the scores (core.from_alignments_and_audios does)
@@ -148,6 +149,17 @@ class Engine:
             config.architecture == 'convolution' and \
             all(layer.winograd4 is not None for layer in frame_layers)
         self.model = self._conv_model()
+
+    def lane(self):
+        """A second handle on the same weights with its own workspace (and
+        lock): what a batch in flight on another stream runs through."""
+        import copy
+        other = copy.copy(self)
+        other._workspace = {}
+        other._staging = {}
+        other.timers = None
+        other.lock = threading.RLock()
+        return other
 
     def _conv_model(self):
         """`emph_conv_model` for emph_prominence_forward (the whole path in one
@@ -281,6 +293,27 @@ class Engine:
                 best = (trips * cost[tile], tile)
         return best[1]
 
+    def _pinned(self, name, array):
+        """`array` (int32 numpy) in a reusable pinned staging tensor: a fresh
+        `pin_memory()` per batch costs up to milliseconds (hipHostMalloc).  The
+        previous copy out of the buffer must have been consumed - the API
+        paths synchronise on a batch before they reuse its engine - so the
+        buffers rotate over a few slots to stay clear of copies in flight."""
+        slots = self._staging.setdefault(name, [[], 0])
+        ring, cursor = slots
+        if len(ring) < 4:
+            ring.append(None)
+        index = cursor % len(ring)
+        slots[1] = cursor + 1
+        tensor = ring[index]
+        if tensor is None or tensor.numel() < array.size:
+            tensor = torch.empty(
+                max(array.size, 1) * 3 // 2, dtype=torch.int32).pin_memory()
+            ring[index] = tensor
+        view = tensor[:array.size]
+        np.copyto(view.numpy(), array)
+        return view
+
     def upload(self, plan, tile=None, nested=False):
         """One H2D copy of all integer metadata; returns device views.
         (`nested`: the layout of the word pieces of another plan.)"""
@@ -295,9 +328,7 @@ class Engine:
                 requests += [(runtime.AXIS_WORDS, ATTENTION_BLOCK)]
         requests = list(dict.fromkeys(requests))
         host, offsets = plan.pack_metadata(requests)
-        pinned = torch.from_numpy(host)
-        if self.device.type == 'cuda':
-            pinned = pinned.pin_memory()
+        pinned = self._pinned(('meta', nested), host)
         device_buffer = pinned.to(self.device, non_blocking=True)
         views = {'_buffer': device_buffer, '_pinned': pinned, 'tile': tile,
                  'positions': (plan.total_frames, plan.total_words)}
@@ -309,12 +340,10 @@ class Engine:
             pieces = plan.pieces(self.config.downsample_method)
             piece_meta = self.upload(
                 pieces.plan, self.frame_tile(pieces.plan), nested=True)
-            extra = torch.from_numpy(np.concatenate([
+            extra = self._pinned('pieces', np.concatenate([
                 pieces.gather.view(np.int32).ravel(),
                 pieces.bounds.ravel(), pieces.word_piece,
                 pieces.gather[:, 1].astype(np.int32)]))
-            if self.device.type == 'cuda':
-                extra = extra.pin_memory()
             extra = extra.to(self.device, non_blocking=True)
             cut = pieces.gather.size * 2
             piece_meta['gather'] = extra[:cut]

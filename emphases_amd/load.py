@@ -17,8 +17,10 @@ import torch
 from . import config as cfg
 
 
-def wav(file):
-    """Read a RIFF/WAVE file -> (float32 tensor [channels, samples], rate)."""
+def wav(file, raw=False):
+    """Read a RIFF/WAVE file -> (float32 tensor [channels, samples], rate).
+    `raw`: 16-bit PCM comes back as an int16 tensor (x / 32768 is what the
+    float form holds; the HIP front-end applies it on the device)."""
     with open(file, 'rb') as handle:
         data = handle.read()
     if data[:4] != b'RIFF' or data[8:12] != b'WAVE':
@@ -45,6 +47,8 @@ def wav(file):
     if code == 1 and bits == 8:
         values = (np.frombuffer(samples, dtype=np.uint8).astype(np.float32)
                   - 128.) / 128.
+    elif code == 1 and bits == 16 and raw:
+        values = np.frombuffer(samples, dtype='<i2').astype(np.int16)
     elif code == 1 and bits == 16:
         values = np.frombuffer(samples, dtype='<i2').astype(np.float32) / 32768.
     elif code == 1 and bits == 24:
@@ -82,9 +86,15 @@ def save_wav(file, audio, sample_rate=cfg.SAMPLE_RATE):
         handle.write(header + body)
 
 
-def audio(file):
-    """Load audio and maybe resample (`emphases/load.py:11-17`)."""
-    samples, rate = wav(file)
+def audio(file, raw=False):
+    """Load audio and maybe resample (`emphases/load.py:11-17`).  `raw`: a
+    16 kHz 16-bit PCM file is returned as int16 (no conversion, half the
+    bytes); anything else as float32 like the reference."""
+    samples, rate = wav(file, raw)
+    if samples.dtype == torch.int16:
+        if rate == cfg.SAMPLE_RATE:
+            return samples
+        samples = samples.to(torch.float32) / 32768.
     return resample(samples, rate)
 
 

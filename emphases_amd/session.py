@@ -1,0 +1,294 @@
+"""Batches in flight: host staging, H2D, kernels and D2H of consecutive
+batches overlap.
+
+The reference processes one file at a time, synchronously
+(`emphases/core.py:169-179`; audio goes to the device inside
+`data/preprocess/core.py:74`, scores come back in `core.py:112`).  A `Session`
+keeps `depth` lanes, each with its own HIP stream, engine workspace, pinned
+staging buffer and pinned result buffer:
+
+    submit(batch i+1)   plan on the host, gather the utterances into pinned
+                        memory with a few copy threads, enqueue ONE
+                        host-to-device copy + the kernels + the copy of the
+                        scores back, all on the lane's stream, and return
+    result(batch i)     wait for that lane's event, split the scores
+
+so the PCIe transfer and the host planning of one batch run under the kernels
+of the previous one.  16-bit PCM tensors (what a WAV file holds; `load.pcm`)
+are staged and transferred as they are - half the bytes - and converted by the
+front-end kernel (identical scores: x / 32768 is exact).
+"""
+import collections
+import concurrent.futures
+import threading
+
+import numpy as np
+import torch
+
+from . import batch
+from . import config as cfg
+from . import load
+
+COPY_THREADS = 16
+_POOL = None
+_POOL_LOCK = threading.Lock()
+
+
+def _pool():
+    global _POOL
+    with _POOL_LOCK:
+        if _POOL is None:
+            _POOL = concurrent.futures.ThreadPoolExecutor(
+                COPY_THREADS, thread_name_prefix='emphases-stage')
+    return _POOL
+
+
+def mono(audio, sample_rate):
+    """1-D tensor of channel 0 at 16 kHz (`mels.py:48` featurises channel 0
+    only; `core.py:353-354` resamples).  int16 stays int16."""
+    if sample_rate != cfg.SAMPLE_RATE:
+        if audio.dtype == torch.int16:
+            audio = audio.to(torch.float32) / 32768.
+        audio = load.resample(audio, sample_rate, cfg.SAMPLE_RATE)
+    audio = audio[0] if audio.dim() == 2 else audio.reshape(-1)
+    if audio.dtype not in (torch.float32, torch.int16):
+        audio = audio.to(torch.float32)
+    return audio
+
+
+class _Lane:
+    """One batch in flight."""
+
+    def __init__(self, engine):
+        self.engine = engine.lane()
+        self.device = engine.device
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.done = torch.cuda.Event()
+        self.staging = None           # pinned uint8
+        self.audio = None             # device uint8
+        self.result = None            # pinned float32
+        self.pending = None
+        # recurring batch layouts: key -> _Layout (plan, device metadata and,
+        # from the second sighting on, the captured HIP graph of the forward)
+        self.layouts = collections.OrderedDict()
+
+    def _reserve(self, nbytes, words):
+        if self.staging is None or self.staging.numel() < nbytes:
+            size = max(nbytes, 1) * 5 // 4
+            self.staging = torch.empty(size, dtype=torch.uint8).pin_memory()
+            self.audio = torch.empty(
+                size, dtype=torch.uint8, device=self.device)
+            self.layouts.clear()      # captured graphs point at the old buffer
+        if self.result is None or self.result.numel() < words:
+            self.result = torch.empty(
+                max(words, 1) * 5 // 4, dtype=torch.float32).pin_memory()
+
+    def stage(self, audios, lengths, dtype):
+        """Packed device tensor of all utterances (dtype float32 or int16),
+        enqueued on this lane's stream."""
+        item = 2 if dtype == torch.int16 else 4
+        total = int(sum(lengths))
+        offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
+        device_view = self.audio[:max(total, 1) * item].view(dtype)[:total]
+        on_host = [i for i, a in enumerate(audios) if not a.is_cuda]
+        host_view = self.staging[:max(total, 1) * item].view(dtype)[:total]
+        # numpy does the gather: np.copyto releases the GIL and runs at memory
+        # speed, while torch's CPU copy_ into a slice of a large tensor is 10x
+        # slower here (tools/h2d_paths.py: 15 ms against 1.4 ms for 41 MB)
+        target = host_view.numpy()
+        sources = {i: audios[i].contiguous().numpy() for i in on_host}
+
+        def gather(indices):
+            for i in indices:
+                np.copyto(target[offsets[i]:offsets[i + 1]], sources[i])
+            return indices[0], indices[-1]
+
+        # contiguous runs of host utterances, a few per copy thread; each run
+        # goes to the device as soon as its thread is done with it, so the DMA
+        # of one piece runs under the gather of the next
+        runs, run = [], []
+        for i in on_host:
+            if run and i != run[-1] + 1:
+                runs.append(run)
+                run = []
+            run.append(i)
+        if run:
+            runs.append(run)
+        pieces = []
+        for run in runs:
+            step = max(1, -(-len(run) // COPY_THREADS))
+            pieces += [run[k:k + step] for k in range(0, len(run), step)]
+        if len(pieces) > 1 and total * item > (1 << 20):
+            futures = [_pool().submit(gather, piece) for piece in pieces]
+            spans = (future.result() for future in futures)
+        else:
+            spans = (gather(piece) for piece in pieces)
+        for first, last in spans:
+            lo, hi = int(offsets[first]), int(offsets[last + 1])
+            device_view[lo:hi].copy_(host_view[lo:hi], non_blocking=True)
+        for i, audio in enumerate(audios):
+            if audio.is_cuda:
+                device_view[offsets[i]:offsets[i + 1]].copy_(
+                    audio, non_blocking=True)
+        return device_view
+
+
+class _Layout:
+    """What can be kept when the same batch layout (word times, utterance
+    lengths, batch_size, sample format) comes back: the plan, its metadata on
+    the device, and the forward captured into a HIP graph."""
+    KEEP = 8
+
+    def __init__(self, plan):
+        self.plan = plan
+        self.meta = None
+        self.replay = None
+        self.scores = None
+        self.seen = 0
+
+
+def layout_key(alignments, lengths, batch_size, dtype):
+    """Hashable identity of a batch layout, or None when an alignment is not
+    one whose word times can be read as an array."""
+    from . import alignment as alignment_module
+    tables = []
+    for item in alignments:
+        if type(item) is alignment_module.Alignment:
+            tables.append(item.times())
+        elif isinstance(item, np.ndarray):
+            tables.append(np.asarray(item, dtype=np.float64).reshape(-1, 2))
+        else:
+            return None
+    times = np.concatenate(tables) if tables else np.zeros((0, 2))
+    return (hash(times.tobytes()), tuple(len(t) for t in tables),
+            tuple(lengths), batch_size, dtype)
+
+
+class Pending:
+    """Scores of a submitted batch; `result()` waits for them."""
+
+    def __init__(self, lane, plan, count, on_device, ld_words):
+        self._lane = lane
+        self._plan = plan
+        self._count = count
+        self._on_device = on_device
+        self._ld_words = ld_words
+        self._scores = None
+        self._value = None
+
+    def result(self):
+        if self._value is not None:
+            return self._value
+        lane, plan = self._lane, self._plan
+        empty = torch.zeros((1, 0))
+        if plan is None or not len(plan):
+            self._value = [
+                empty.to(lane.device) if self._on_device else empty.clone()
+                for _ in range(self._count)]
+            return self._value
+        lane.done.synchronize()
+        if self._on_device:
+            packed = self._scores
+        else:
+            packed = lane.result[:self._ld_words].clone()
+        if lane.pending is self:
+            lane.pending = None
+        # one gather of the valid word columns, one split: per-utterance views
+        # [1, W_u] of a dense row (an utterance's chunks are consecutive)
+        columns = torch.from_numpy(plan.word_columns())
+        dense = packed[columns.to(packed.device)][None]
+        counts = np.bincount(
+            plan.utterance, weights=plan.words, minlength=self._count)
+        self._value = list(
+            dense.split(counts.astype(np.int64).tolist(), dim=1))
+        self._scores = None
+        return self._value
+
+
+class Session:
+    """`depth` batches in flight on one device."""
+
+    def __init__(self, engine, depth=2):
+        self.engine = engine
+        self.lanes = [_Lane(engine) for _ in range(max(1, depth))]
+        self._cursor = 0
+        self._lock = threading.Lock()
+
+    def submit(self, alignments, audios, sample_rate=cfg.SAMPLE_RATE,
+               batch_size=None, on_device=False, pitch_tracker=None):
+        """Enqueue a batch; returns a `Pending`.  The lane it takes is the one
+        whose batch was submitted `depth` submissions ago: that batch's
+        results are extracted first if the caller has not done so."""
+        with self._lock:
+            lane = self.lanes[self._cursor % len(self.lanes)]
+            self._cursor += 1
+            if lane.pending is not None:
+                lane.pending.result()
+            alignments = list(alignments)
+            audios = [mono(audio, sample_rate) for audio in audios]
+            pcm = bool(audios) and all(
+                audio.dtype == torch.int16 for audio in audios)
+            dtype = torch.int16 if pcm else torch.float32
+            if not pcm:
+                audios = [audio.to(torch.float32) if audio.dtype != torch.float32
+                          else audio for audio in audios]
+            lengths = [int(audio.shape[0]) for audio in audios]
+            layout = None
+            key = layout_key(alignments, lengths, batch_size, dtype) \
+                if audios else None
+            if key is not None:
+                layout = lane.layouts.get(key)
+                if layout is not None:
+                    lane.layouts.move_to_end(key)
+            if layout is None and audios:
+                layout = _Layout(
+                    batch.plan_batch(alignments, lengths, batch_size))
+                if key is not None:
+                    lane.layouts[key] = layout
+                    while len(lane.layouts) > _Layout.KEEP:
+                        lane.layouts.popitem(last=False)
+            plan = layout.plan if layout is not None else None
+            pending = Pending(
+                lane, plan, len(audios), on_device,
+                plan.ld_words if plan is not None else 0)
+            if plan is None or not len(plan):
+                return pending
+            engine = lane.engine
+            lane._reserve(
+                sum(lengths) * (2 if pcm else 4), plan.ld_words)
+            with torch.cuda.device(lane.device), \
+                    torch.cuda.stream(lane.stream):
+                tracks = None
+                if engine.config.pitch_feature or \
+                        engine.config.periodicity_feature:
+                    from . import core
+                    tracks = core._tracks(
+                        engine, plan, audios, pitch_tracker, lane.device.index)
+                packed = lane.stage(audios, lengths, dtype)
+                layout.seen += 1
+                if tracks is None and layout.replay is None and \
+                        layout.seen >= 2 and key in lane.layouts:
+                    # the layout came back: from now on one graph launch
+                    layout.meta = engine.upload(plan)
+                    layout.replay, layout.scores, _ = engine.capture(
+                        packed, plan, layout.meta)
+                if tracks is None and layout.replay is not None:
+                    layout.replay()
+                    scores = layout.scores
+                else:
+                    scores, _ = engine.forward(packed, plan, tracks=tracks)
+                if on_device:
+                    pending._scores = scores.clone()
+                else:
+                    lane.result[:plan.ld_words].copy_(
+                        scores, non_blocking=True)
+                lane.done.record(lane.stream)
+            lane.pending = pending
+            return pending
+
+    def run(self, alignments, audios, sample_rate=cfg.SAMPLE_RATE,
+            batch_size=None, on_device=False, pitch_tracker=None):
+        """submit + result: one synchronous batch."""
+        return self.submit(
+            alignments, audios, sample_rate, batch_size, on_device,
+            pitch_tracker).result()

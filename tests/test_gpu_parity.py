@@ -541,3 +541,64 @@ def test_file_api_and_cli(tmp_path, cases):
          str(tmp_path / 'utt.wav'), '--output_prefixes',
          str(tmp_path / 'cli'), '--gpu', '0'], check=True, cwd=ROOT)
     assert torch.equal(torch.load(tmp_path / 'cli.pt'), scores)
+
+
+def test_session_pipeline_pcm_and_layout_cache(default_engine):
+    """session.Session: batches in flight on alternating lanes, 16-bit PCM
+    input (x / 32768 on the device: identical bits), and the layout cache -
+    the same word times with DIFFERENT audio must replay the captured graph on
+    the new audio, and a different layout must not hit it."""
+    from emphases_amd import session as session_module
+    session = session_module.Session(default_engine, depth=2)
+    frames = [500, 1000, 33, 720]
+    aligns = [emphases_amd.Alignment.from_frames(synth.word_frames(60 + i, n))
+              for i, n in enumerate(frames)]
+    batches = []
+    for round_index in range(5):
+        audios = [synth.audio(70 + 10 * round_index + i, n)
+                  for i, n in enumerate(frames)]
+        batches.append(audios)
+    # reference: every batch on its own through the step-by-step engine path
+    want = []
+    for audios in batches:
+        plan = batch.plan_batch(aligns, [a.shape[1] for a in audios])
+        packed = torch.cat(
+            [torch.from_numpy(a).reshape(-1) for a in audios]).to(
+                default_engine.device)
+        scores = default_engine.forward(packed, plan)[0]
+        want.append(scores[plan.word_columns()].cpu().clone())
+    pending = [session.submit(
+        aligns, [torch.from_numpy(a) for a in audios]) for audios in batches]
+    for job, expect in zip(pending, want):
+        got = torch.cat([s.reshape(-1) for s in job.result()])
+        assert torch.equal(got, expect)
+    assert any(layout.replay is not None
+               for lane in session.lanes for layout in lane.layouts.values())
+    # 16-bit PCM tensors: same bits as their float form
+    for audios, expect in zip(batches[:2], want[:2]):
+        pcm = [torch.from_numpy(np.rint(a * 32768.).astype(np.int16))
+               for a in audios]
+        got = torch.cat([s.reshape(-1) for s in session.run(aligns, pcm)])
+        assert torch.equal(got, expect)
+    # another layout (one word moved by a frame) misses the cache
+    moved = synth.word_frames(60, frames[0]).copy()
+    moved[1, 0] += 1
+    moved[0, 1] += 1
+    other = [emphases_amd.Alignment.from_frames(moved)] + aligns[1:]
+    audios = batches[0]
+    plan = batch.plan_batch(other, [a.shape[1] for a in audios])
+    packed = torch.cat([torch.from_numpy(a).reshape(-1) for a in audios]).to(
+        default_engine.device)
+    expect = default_engine.forward(packed, plan)[0][
+        plan.word_columns()].cpu()
+    got = torch.cat([s.reshape(-1) for s in session.run(
+        other, [torch.from_numpy(a) for a in audios])])
+    assert torch.equal(got, expect)
+    assert not torch.equal(got, want[0])
+    # device results and device inputs
+    on_device = session.run(
+        aligns, [torch.from_numpy(a).cuda() for a in batches[0]],
+        on_device=True)
+    assert all(s.is_cuda for s in on_device)
+    assert torch.equal(
+        torch.cat([s.reshape(-1) for s in on_device]).cpu(), want[0])
