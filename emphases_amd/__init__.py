@@ -17,6 +17,7 @@ from . import synth  # noqa: F401
 from . import weights  # noqa: F401
 from . import engine  # noqa: F401
 from . import session  # noqa: F401
+from . import metrics  # noqa: F401
 from .alignment import Alignment, Word  # noqa: F401
 from .core import (  # noqa: F401
     Model, active_config, configure, downsample, from_alignment_and_audio,

@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -26,6 +26,9 @@ ACTIVATIONS = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2, 'silu': 3,
 REDUCTIONS = {'sum': 0, 'average': 1, 'max': 2, 'center': 3}
 POSTPROCESS = {None: 0, 'bce': 1, 'mse': 2}
 AUDIO_F32, AUDIO_PCM16 = 0, 1
+(METRIC_COUNT, METRIC_BCE, METRIC_SQUARED_ERROR, METRIC_COVARIANCE,
+ METRIC_SUM_PREDICTED, METRIC_SUMSQ_PREDICTED, METRIC_SUM_TARGET,
+ METRIC_SUMSQ_TARGET, METRIC_FIELDS) = range(9)
 
 _c = ctypes
 _ptr, _i32, _i64, _f32 = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_float
@@ -89,6 +92,8 @@ SIGNATURES = {
         _ptr, _i64, _ptr, _i32, _i32, _ptr, _i32, _i32, _ptr]),
     'emph_attention': (_c.c_int, [
         _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i32, _ptr, _ptr]),
+    'emph_word_metrics': (_c.c_int, [
+        _ptr, _ptr, _ptr, _i64, _i32, _f32, _f32, _ptr, _ptr]),
     'emph_add_layernorm': (_c.c_int, [
         _ptr, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _f32, _i64, _i64, _ptr]),
 }

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 14
+#define EMPH_ABI_VERSION 15
 
 /* Segment-table fields */
 enum {
@@ -413,6 +413,46 @@ int emph_qkv_projection(const float* x, int64_t ld, float* qk, float* v,
                         int32_t channels, const float* packs,
                         const float* bias, const int32_t* tiles,
                         int32_t n_tiles, int32_t tile_n, void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Evaluation metrics at word resolution                                     */
+/* ------------------------------------------------------------------------ */
+
+/* Accumulator fields of emph_word_metrics (float64 each) */
+enum {
+    EMPH_METRIC_COUNT = 0,           /* words seen                              */
+    EMPH_METRIC_BCE = 1,             /* sum of per-word binary cross entropy    */
+    EMPH_METRIC_SQUARED_ERROR = 2,   /* sum of (score - target)^2               */
+    EMPH_METRIC_COVARIANCE = 3,      /* sum of (score - mean_p)(target - mean_t) */
+    EMPH_METRIC_SUM_PREDICTED = 4,   /* sum / sum of squares of the scores ...  */
+    EMPH_METRIC_SUMSQ_PREDICTED = 5,
+    EMPH_METRIC_SUM_TARGET = 6,      /* ... and of the targets (Statistics)     */
+    EMPH_METRIC_SUMSQ_TARGET = 7,
+    EMPH_METRIC_FIELDS = 8
+};
+
+/* accumulators[i] += the masked sums over every word of the batch.
+ *
+ * Replaces Metrics.update of emphases/evaluate/metrics.py:27-46 (the
+ * mask_from_lengths + boolean indexing, BinaryCrossEntropy.update 59-76,
+ * MeanSquaredError.update 80-92, torchutil's PearsonCorrelation.update) and the
+ * sums behind Statistics (metrics.py:101-110), for one packed batch.
+ *
+ *   logits, targets  float32 [total]  packed word axis (emph_word_decoder's
+ *                                     `logits`; targets laid out the same way)
+ *   word_segment     int32 [total]    >= 0 on real words, -1 on padding columns
+ *   post             EMPH_POST_*      emphases.postprocess / the LOSS switch:
+ *                                     SIGMOID = 'bce' (BCE from logits), CLAMP01 =
+ *                                     'mse' (BCE from clamped probabilities)
+ *   predicted_mean, target_mean       the dataset statistics the reference hands
+ *                                     to PearsonCorrelation (metrics.py:15-17)
+ *   accumulators     float64 [EMPH_METRIC_FIELDS], zeroed by the caller before
+ *                                     the first batch
+ */
+int emph_word_metrics(const float* logits, const float* targets,
+                      const int32_t* word_segment, int64_t total, int32_t post,
+                      float predicted_mean, float target_mean,
+                      double* accumulators, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* The whole convolutional path in one call                                  */

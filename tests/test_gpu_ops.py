@@ -1,5 +1,7 @@
 """GPU: every C-ABI operator on seeded random ragged inputs against a plain
 torch CPU fp32 reference of the same op (one segment at a time, B=1)."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -703,3 +705,64 @@ def test_word_decoder(kernel_size, layers, activation, post):
             assert float((scores[off:off + count] -
                           want.clamp(0., 1.)).abs().max()) < 2e-5 * scale
     assert float(logits[~torch.from_numpy(valid)].min()) == 9.0
+
+
+###############################################################################
+# evaluation metrics
+###############################################################################
+
+
+@pytest.mark.parametrize('loss', ['bce', 'mse'])
+def test_word_metrics(loss):
+    """emphases_amd.metrics (emph_word_metrics) against the CPU restatement
+    of emphases/evaluate/metrics.py over several ragged batches."""
+    from emphases_amd import metrics as metrics_module
+    from oracle import metrics as oracle_metrics
+    generator = torch.Generator().manual_seed(5)
+    batches = []
+    for lengths in ([31, 7, 1, 19], [64, 2], [5]):
+        lengths = torch.tensor(lengths)
+        width = int(lengths.max())
+        logits = torch.randn(len(lengths), 1, width, generator=generator) * 2
+        targets = torch.rand(len(lengths), 1, width, generator=generator)
+        batches.append((logits, targets, lengths))
+    # dataset statistics first (evaluate/core.py:31-46), then the metrics
+    predicted = metrics_module.Statistics(0)
+    target = metrics_module.Statistics(0)
+    flat_p, flat_t = [], []
+    for logits, targets, lengths in batches:
+        scores = oracle_metrics.postprocess(logits, loss)
+        predicted.update(scores, lengths)
+        target.update(targets, lengths)
+        mask = oracle_metrics.mask_from_lengths(lengths)
+        flat_p += scores[mask].tolist()
+        flat_t += targets[mask].tolist()
+    for got, want in ((predicted(), oracle_metrics.mean_std(flat_p)),
+                      (target(), oracle_metrics.mean_std(flat_t))):
+        assert abs(got[0] - want[0]) < 1e-6 and abs(got[1] - want[1]) < 1e-6
+    mine = metrics_module.Metrics(predicted, target, gpu=0, loss=loss)
+    theirs = oracle_metrics.Metrics(predicted(), target(), loss)
+    for logits, targets, lengths in batches:
+        mine.update(logits, targets, lengths)
+        theirs.update(logits, targets, lengths)
+    got, want = mine(), theirs()
+    assert set(got) == {'pearson_correlation', 'bce', 'mse'}
+    for key in want:
+        assert abs(got[key] - want[key]) < 2e-6 * max(1., abs(want[key])), key
+    mine.reset()
+    assert math.isnan(mine()['bce'])
+    # the engine's own layout: packed rows + word_segment, no padding round trip
+    plan = ragged_plan([40, 9, 77], [np.stack([np.arange(n), np.arange(n) + 1])
+                                     for n in (12, 1, 30)])
+    logits = random_packed(1, plan, runtime.AXIS_WORDS, 91)[0] * 3.0
+    targets = torch.rand(plan.ld_words, generator=generator)
+    mine.update_packed(
+        logits.to(DEVICE), targets.to(DEVICE),
+        torch.from_numpy(plan.word_segment).to(DEVICE))
+    theirs.reset()
+    columns = torch.from_numpy(plan.word_columns())
+    theirs.update(logits[columns][None, None], targets[columns][None, None],
+                  torch.tensor([len(columns)]))
+    got, want = mine(), theirs()
+    for key in want:
+        assert abs(got[key] - want[key]) < 2e-6 * max(1., abs(want[key])), key

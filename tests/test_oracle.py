@@ -130,3 +130,28 @@ def test_variant_matrix_matches_reference(variants):
                 else variants[f'{name}/features'], atol=2e-4)
         checked += 1
     assert checked == len(variants["names"]) == 39
+
+
+def test_metrics_restatement_known_answers():
+    """oracle/metrics.py (emphases/evaluate/metrics.py:12-110) on values that
+    can be checked by hand."""
+    from oracle import metrics
+    logits = torch.tensor([[[0., 2., -1.]], [[1., 9., 9.]]])
+    targets = torch.tensor([[[0.5, 1., 0.]], [[0., 7., 7.]]])
+    lengths = torch.tensor([3, 1])
+    m = metrics.Metrics((0.5, 0.25), (0.25, 0.5), 'bce')
+    m.update(logits, targets, lengths)
+    p = torch.sigmoid(torch.tensor([0., 2., -1., 1.]))
+    t = torch.tensor([0.5, 1., 0., 0.])
+    want_bce = float(-(t * torch.log(p) + (1 - t) * torch.log(1 - p)).mean())
+    got = m()
+    assert abs(got['bce'] - want_bce) < 1e-6
+    assert abs(got['mse'] - float(((p - t) ** 2).mean())) < 1e-7
+    want_r = float(((p - 0.5) * (t - 0.25)).sum()) / 4 / (0.25 * 0.5)
+    assert abs(got['pearson_correlation'] - want_r) < 1e-6
+    mean, std = metrics.mean_std([1., 2., 3., 4.])
+    assert mean == 2.5 and abs(std - 1.2909944487358056) < 1e-12
+    clamped = metrics.Metrics((0., 1.), (0., 1.), 'mse')
+    clamped.update(torch.tensor([[[2., -3.]]]), torch.tensor([[[1., 0.]]]),
+                   torch.tensor([2]))
+    assert abs(clamped()['mse']) < 1e-12          # clamp(2)=1, clamp(-3)=0
