@@ -28,6 +28,7 @@ from . import weights as weights_module
 
 FRONTEND_BLOCK = None   # frames per front-end tile: emph_frontend_block()
 ATTENTION_BLOCK = 64    # queries per attention wave (csrc/transformer.hip)
+ATTENTION_GROUP = 256   # queries per attention workgroup (LDS-staged keys/values)
 WORD_TILE = 16
 WINOGRAD_LDS_BUDGET = 160 * 1024
 
@@ -323,7 +324,8 @@ class Engine:
             (runtime.AXIS_FRAMES, tile),
             (runtime.AXIS_WORDS, self.word_block)]
         if self.config.architecture == 'transformer':
-            requests += [(runtime.AXIS_FRAMES, ATTENTION_BLOCK)]
+            requests += [(runtime.AXIS_FRAMES, ATTENTION_BLOCK),
+                         (runtime.AXIS_FRAMES, ATTENTION_GROUP)]
             if not nested:
                 requests += [(runtime.AXIS_WORDS, ATTENTION_BLOCK)]
         requests = list(dict.fromkeys(requests))
@@ -526,6 +528,15 @@ class Engine:
         projected = self._buffer(tag + '_projected', channels, ld)
         attention_flops = 4. * channels * float(
             (counts.astype(np.float64) ** 2).sum())
+        # long segments: a workgroup of four waves shares each key / value
+        # block through LDS; short ones (the word axis, word pieces): one wave
+        # per 64 queries straight from L2
+        grouped = axis == runtime.AXIS_FRAMES and len(counts) and \
+            ('tiles', axis, ATTENTION_GROUP) in meta and \
+            float(counts.mean()) >= ATTENTION_GROUP / 2
+        if grouped:
+            group_tiles, group_size = meta[('tiles', axis, ATTENTION_GROUP)]
+            group_count = group_size // runtime.TILE_FIELDS
 
         def add_layernorm(norm):
             with self._timed('add_layernorm'):
@@ -554,7 +565,10 @@ class Engine:
             with self._timed('attention', attention_flops):
                 runtime.check(self.lib.emph_attention(
                     qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld,
-                    channels, config.heads, att_tiles.data_ptr(), att_count,
+                    channels, config.heads,
+                    (group_tiles if grouped else att_tiles).data_ptr(),
+                    group_count if grouped else att_count,
+                    ATTENTION_GROUP if grouped else ATTENTION_BLOCK,
                     None if key_counts is None else key_counts.data_ptr(),
                     runtime.stream()), 'emph_attention')
             if layer['block'] is not None and block <= 32:

@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -91,7 +91,7 @@ SIGNATURES = {
     'emph_add_position': (_c.c_int, [
         _ptr, _i64, _ptr, _i32, _i32, _ptr, _i32, _i32, _ptr]),
     'emph_attention': (_c.c_int, [
-        _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i32, _ptr, _ptr]),
+        _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i32, _i32, _ptr, _ptr]),
     'emph_word_metrics': (_c.c_int, [
         _ptr, _ptr, _ptr, _i64, _i32, _f32, _f32, _ptr, _ptr]),
     'emph_add_layernorm': (_c.c_int, [

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 15
+#define EMPH_ABI_VERSION 16
 
 /* Segment-table fields */
 enum {
@@ -359,7 +359,11 @@ int emph_add_position(float* x, int64_t ldx, const float* table,
  *   qk   float32 [2*channels, ld]   rows 0..c-1 = Q, c..2c-1 = K
  *   v    float32 [ld, channels]     position-major V
  *   out  float32 [channels, ld]
- *   tiles int32 [n_tiles][4]        tile table, block = 64 queries
+ *   tiles int32 [n_tiles][4]        tile table, block = tile_n queries
+ *   tile_n 64: one wave per tile, keys / values read from L2 by every wave
+ *              (short segments: the word axis);
+ *          256: a workgroup of four waves per tile with the key / value blocks
+ *              staged ONCE per workgroup in LDS (long segments: the frame axis)
  *   key_counts int32 [n_seg] or NULL  src_key_padding_mask (transformer.py:
  *                                   26-29) as the number of leading positions
  *                                   of each segment that are real keys; the
@@ -371,7 +375,8 @@ int emph_add_position(float* x, int64_t ldx, const float* table,
  */
 int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
                    int32_t channels, int32_t heads, const int32_t* tiles,
-                   int32_t n_tiles, const int32_t* key_counts, void* stream);
+                   int32_t n_tiles, int32_t tile_n, const int32_t* key_counts,
+                   void* stream);
 
 /* y = LayerNorm(x + r) over channels for columns [first_column,
  * first_column + columns) (post-LN residual of nn.TransformerEncoderLayer,

@@ -400,21 +400,22 @@ def test_output_layer(kernel_size, post):
 ###############################################################################
 
 
+@pytest.mark.parametrize('tile_n', [64, 256])
 @pytest.mark.parametrize('channels,heads', [(80, 2), (64, 2), (128, 2)])
-def test_attention(channels, heads):
+def test_attention(channels, heads, tile_n):
     lib = runtime.library()
     plan = ragged_plan([130, 16, 1, 700, 65])
     axis = runtime.AXIS_FRAMES
-    meta = Meta(plan, [(axis, 64)])
+    meta = Meta(plan, [(axis, tile_n)])
     ld = plan.ld_frames
     qk = random_packed(2 * channels, plan, axis, 21) * 3.0
     v = torch.from_numpy(synth.weights(22, (ld, channels), 1.0))
     out = torch.zeros((channels, ld), device=DEVICE)
-    tiles, size = meta.view(('tiles', axis, 64))
+    tiles, size = meta.view(('tiles', axis, tile_n))
     qk_dev, v_dev = qk.to(DEVICE), v.to(DEVICE)
     runtime.check(lib.emph_attention(
         qk_dev.data_ptr(), v_dev.data_ptr(), out.data_ptr(), ld,
-        channels, heads, tiles.data_ptr(), size // 4, None, None),
+        channels, heads, tiles.data_ptr(), size // 4, tile_n, None, None),
         'emph_attention')
     out = out.cpu()
     d = channels // heads
@@ -438,8 +439,8 @@ def test_attention(channels, heads):
     out = torch.zeros((channels, ld), device=DEVICE)
     runtime.check(lib.emph_attention(
         qk_dev.data_ptr(), v_dev.data_ptr(), out.data_ptr(), ld,
-        channels, heads, tiles.data_ptr(), size // 4, counts_dev.data_ptr(),
-        None), 'emph_attention')
+        channels, heads, tiles.data_ptr(), size // 4, tile_n,
+        counts_dev.data_ptr(), None), 'emph_attention')
     out = out.cpu()
     for (off, count), keys in zip(spans(plan, axis), key_counts):
         want = reference(off, count, int(keys))

@@ -454,3 +454,117 @@ def test_word_pieces_layout():
         [batch.Segment(0, 0, 1, 0, 0, 10, np.array([[4], [12]]))], [0], [0])
     with pytest.raises(ValueError):
         bad.pieces('sum')
+
+
+def test_foreign_alignment_supplies_its_own_bounds():
+    """An alignment object that is not ours (a real `pypar.Alignment`) keeps
+    the last word on what the model sees: the reference takes the chunk's
+    bounds from `alignment[start:end].word_bounds(16000, 160, silences=True)`
+    (`emphases/core.py:384-392`), so the planner must call exactly that - and
+    still do its own float-floor arithmetic for the chunking and the audio
+    slice (`core.py:365-381,395-401`)."""
+    from emphases_amd import batch
+
+    class Word:
+        def __init__(self, start, end):
+            self._start, self._end = start, end
+
+        def start(self):
+            return self._start
+
+        def end(self):
+            return self._end
+
+        def duration(self):
+            return self._end - self._start
+
+    calls = []
+
+    class Foreign:
+        """pypar-like; word_bounds deliberately differs from ours (+1 on every
+        end frame) so that the test can tell who computed the bounds."""
+
+        def __init__(self, words):
+            self.words = words
+
+        def __len__(self):
+            return len(self.words)
+
+        def __getitem__(self, index):
+            if isinstance(index, slice):
+                return Foreign(self.words[index])
+            return self.words[index]
+
+        def word_bounds(self, sample_rate, hopsize=1, silences=False):
+            calls.append((sample_rate, hopsize, silences, len(self.words)))
+            origin = int(self.words[0].start() * sample_rate / hopsize)
+            return [(int(w.start() * sample_rate / hopsize) - origin,
+                     int(w.end() * sample_rate / hopsize) - origin + 1)
+                    for w in self.words]
+
+    frames = synth.word_frames(5, 900, 8, 40)
+    words = [Word(int(s) / 100., int(e) / 100.) for s, e in frames.T]
+    ours = emphases_amd.Alignment.from_frames(frames)
+    for batch_size in (None, 300):
+        calls.clear()
+        mine = batch.chunk_utterance(ours, 900 * 160, batch_size)
+        theirs = batch.chunk_utterance(Foreign(words), 900 * 160, batch_size)
+        assert len(mine) == len(theirs) == len(calls)
+        assert all(call[:3] == (16000, 160, True) for call in calls)
+        for a, b in zip(mine, theirs):
+            assert (a.start_word, a.end_word, a.start_sample, a.length,
+                    a.frames) == (b.start_word, b.end_word, b.start_sample,
+                                  b.length, b.frames)
+            assert np.array_equal(b.bounds[0], a.bounds[0])
+            assert np.array_equal(b.bounds[1], a.bounds[1] + 1)
+    plan = batch.plan_batch([Foreign(words), ours], [900 * 160] * 2)
+    assert plan.words.tolist() == [frames.shape[1]] * 2
+    first = plan.segment_bounds[:, :frames.shape[1]]
+    second = plan.segment_bounds[:, frames.shape[1]:]
+    assert np.array_equal(first[1], second[1] + 1)
+
+
+def test_batch_planner_equals_per_utterance_planner():
+    """plan_batch's vectorised pass against chunk_utterance + Plan, incl. an
+    empty alignment, a dropped chunk and an alignment longer than its audio
+    (which must fall back to real chunking)."""
+    from emphases_amd import batch
+    frames = [1000, 612, 37, 250, 1000, 999, 161, 16, 3]
+    aligns = [emphases_amd.Alignment.from_frames(synth.word_frames(i, n, 2, 30))
+              for i, n in enumerate(frames)]
+    aligns.append(emphases_amd.Alignment.from_frames(
+        np.zeros((2, 0), dtype=np.int64)))
+    lengths = [n * 160 for n in frames] + [1600]
+    # the alignment of utterance 1 describes far more audio than there is
+    lengths[1] = 200 * 160
+    for batch_size in (None, 400):
+        fast = batch.plan_batch(aligns, lengths, batch_size)
+        segments = []
+        for index, (item, length) in enumerate(zip(aligns, lengths)):
+            segments.extend(
+                batch.chunk_utterance(item, length, batch_size, index))
+        offsets = np.cumsum(lengths) - np.array(lengths)
+        slow = batch.Plan(segments, offsets, lengths)
+        for name in ('table', 'bounds', 'word_segment', 'frames', 'words',
+                     'frame_off', 'word_off', 'utterance'):
+            assert np.array_equal(getattr(fast, name), getattr(slow, name)), \
+                (name, batch_size)
+        assert (fast.ld_frames, fast.ld_words) == (slow.ld_frames, slow.ld_words)
+        assert [s.frames for s in fast.segments] == \
+            [s.frames for s in slow.segments]
+
+
+def test_dropout_checkpoints_load():
+    """Checkpoints of the dropout configs keep layer i at Sequential index 3 i
+    (`convolution.py:25-33`, `config/hparam-search/dropout-*.py`)."""
+    from emphases_amd import config as cfg
+    state = weights.random_state(cfg.DEFAULT, 1)
+    raw = {}
+    for name, value in state.items():
+        parts = name.split('.')
+        if parts[0] in ('frame_encoder', 'word_decoder'):
+            parts[1] = str(int(parts[1]) // 2 * 3)
+        raw['.'.join(parts)] = value
+    assert 'frame_encoder.3.weight' in raw
+    loaded = weights.load(raw)
+    assert all(np.array_equal(loaded[name], state[name]) for name in state)
