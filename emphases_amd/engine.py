@@ -550,7 +550,7 @@ class Engine:
             if layer['qkv'] is not None and block <= 32:
                 packs, bias = layer['qkv']
                 tiles, size = meta[('tiles', axis, block)]
-                with self._timed('qkv_projection', 6. * channels * channels *
+                with self._timed(f'qkv_projection_{tag}', 6. * channels * channels *
                                  meta['positions'][axis]):
                     runtime.check(self.lib.emph_qkv_projection(
                         x.data_ptr(), ld, qk.data_ptr(), v.data_ptr(),
@@ -562,7 +562,7 @@ class Engine:
                            None)
                 self._conv(layer['v'], x, ld, v, channels, meta, axis, block,
                            None, transpose_out=True)
-            with self._timed('attention', attention_flops):
+            with self._timed(f'attention_{tag}', attention_flops):
                 runtime.check(self.lib.emph_attention(
                     qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld,
                     channels, config.heads,
@@ -574,7 +574,7 @@ class Engine:
             if layer['block'] is not None and block <= 32:
                 packs, vectors = layer['block']
                 tiles, size = meta[('tiles', axis, block)]
-                with self._timed('transformer_block', 6. * channels *
+                with self._timed(f'transformer_block_{tag}', 6. * channels *
                                  channels * meta['positions'][axis]):
                     runtime.check(self.lib.emph_transformer_block(
                         attended.data_ptr(), x.data_ptr(), ld, channels,

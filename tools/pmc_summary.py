@@ -26,22 +26,64 @@ KERNELS = {
     'word_decoder_kernel': (
         'word_decoder', CHANNELS * WORDS * 4 + 6 * 76800 + 2 * WORDS * 4),
 }
+# --config transformer (BASELINE configs[2]): per launch of the frame-rate
+# kernels (the word-rate launches of the same kernels are averaged in by
+# rocprofv3, so the summary keeps the larger group only: see `select`)
+TRANSFORMER = {
+    'attention_group_kernel': (
+        'attention_frames', 4 * CHANNELS * FRAMES * 4),      # Q, K, V read + O written
+    'qkv_kernel': ('qkv_projection_frames', 4 * CHANNELS * FRAMES * 4 + 3 * 25600),
+    'transformer_block_kernel': (
+        'transformer_block_frames', 3 * CHANNELS * FRAMES * 4 + 3 * 25600),
+}
 
 
-def means(path):
-    total = collections.defaultdict(float)
-    count = collections.Counter()
+def means(path, kernels=None):
+    """Mean counter value per dispatch; for kernels launched at two very
+    different sizes (frame axis and word axis) the mean over the larger half."""
+    kernels = KERNELS if kernels is None else kernels
+    values = collections.defaultdict(list)
     for row in csv.DictReader(open(path)):
-        for key in KERNELS:
+        for key in kernels:
             if key in row['Kernel_Name']:
-                total[key] += float(row['Counter_Value'])
-                count[key] += 1
+                values[key].append(float(row['Counter_Value']))
                 break
-    return {key: total[key] / count[key] for key in total}
+    result = {}
+    for key, series in values.items():
+        series.sort()
+        if series[-1] > 4 * max(series[0], 1e-9):
+            series = series[len(series) // 2:]
+        result[key] = sum(series) / len(series)
+    return result
 
 
 def main():
     directory, tag = sys.argv[1], sys.argv[2]
+    if len(sys.argv) > 3 and sys.argv[3] == 'transformer':
+        fetch = means(f'{directory}/{tag}_transformer_pmc_fetch_size.csv',
+                      TRANSFORMER)
+        write = means(f'{directory}/{tag}_transformer_pmc_write_size.csv',
+                      TRANSFORMER)
+        summary = {'_comment': (
+            'HBM traffic per frame-rate launch on BASELINE configs[2] (64 x '
+            '10 s, Transformer config) from rocprofv3 --pmc FETCH_SIZE / '
+            'WRITE_SIZE (separate passes, KiB); traffic_bytes doubles '
+            'FETCH_SIZE (gfx950 tallies 128-byte requests at 64 bytes).')}
+        for key, (name, algorithmic) in TRANSFORMER.items():
+            if key not in fetch:
+                continue
+            summary[name] = {
+                'fetch_size_kib': round(fetch[key], 1),
+                'write_size_kib': round(write.get(key, 0.), 1),
+                'traffic_bytes_raw': int(
+                    (fetch[key] + write.get(key, 0.)) * 1024),
+                'traffic_bytes': int(
+                    (2 * fetch[key] + write.get(key, 0.)) * 1024),
+                'algorithmic_bytes': algorithmic}
+        with open(f'{directory}/{tag}_transformer_pmc_summary.json', 'w') as f:
+            json.dump(summary, f, indent=2)
+        print(json.dumps(summary, indent=2))
+        return
     fetch = means(f'{directory}/{tag}_bench_pmc_fetch_size.csv')
     write = means(f'{directory}/{tag}_bench_pmc_write_size.csv')
     summary = {'_comment': (
