@@ -142,6 +142,19 @@ class Engine:
         if config.architecture == 'transformer':
             self.position = to(weights_module.positional_encoding(
                 cfg.MAX_POSITIONS, config.channels))
+        # the whole word-rate Transformer decoder as one launch (segments of
+        # at most 64 words): csrc/word_transformer.hip
+        self.word_transformer = None
+        if config.architecture == 'transformer' and config.has_decoder and \
+                config.channels in (64, 80) and config.heads == 2 and all(
+                    tuple(state[f'word_decoder.model.layers.{i}.{name}.weight']
+                          .shape) == (config.channels, config.channels)
+                    for i in range(config.layers)
+                    for name in ('linear1', 'linear2')):
+            self.word_transformer = to(np.concatenate([
+                runtime.word_transformer_pack(
+                    state, f'word_decoder.model.layers.{i}.', config.channels,
+                    config.heads) for i in range(config.layers)]))
         # F(4,3) when every frame-rate k=3 layer has a pack and the activation
         # is one its register epilogue handles
         frame_layers = [self.input_layer] + (
@@ -603,6 +616,19 @@ class Engine:
                 self._conv(layer, x, ld, other, ld, meta, axis, block,
                            config.activation)
                 x, other = other, x
+            return x
+        if axis == runtime.AXIS_WORDS and self.word_transformer is not None \
+                and key_counts is None and len(plan.words) and \
+                int(plan.words.max()) <= 64:
+            tiles, size = meta[('tiles', axis, ATTENTION_BLOCK)]
+            with self._timed('word_transformer'):
+                runtime.check(self.lib.emph_word_transformer(
+                    x.data_ptr(), ld, self.position.data_ptr(),
+                    cfg.MAX_POSITIONS, config.channels, config.heads,
+                    self.word_transformer.data_ptr(), len(layers),
+                    config.layer_norm_eps, tiles.data_ptr(),
+                    size // runtime.TILE_FIELDS, runtime.stream()),
+                    'emph_word_transformer')
             return x
         return self._transformer(
             layers, x, ld, plan, meta, axis, block, tag, key_counts)

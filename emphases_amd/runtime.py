@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -92,6 +92,10 @@ SIGNATURES = {
         _ptr, _i64, _ptr, _i32, _i32, _ptr, _i32, _i32, _ptr]),
     'emph_attention': (_c.c_int, [
         _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i32, _i32, _ptr, _ptr]),
+    'emph_word_transformer_pack_size': (_i64, [_i32, _i32]),
+    'emph_word_transformer_pack': (_c.c_int, [_ptr] * 12 + [_i32, _i32, _ptr]),
+    'emph_word_transformer': (_c.c_int, [
+        _ptr, _i64, _ptr, _i32, _i32, _i32, _ptr, _i32, _f32, _ptr, _i32, _ptr]),
     'emph_word_metrics': (_c.c_int, [
         _ptr, _ptr, _ptr, _i64, _i32, _f32, _f32, _ptr, _ptr]),
     'emph_add_layernorm': (_c.c_int, [
@@ -191,6 +195,24 @@ def linear_chain_pack(weight, natural):
     check(lib.emph_linear_chain_pack(
         weight.ctypes.data, channels, int(natural), pack.ctypes.data),
         'emph_linear_chain_pack')
+    return pack
+
+
+def word_transformer_pack(state, prefix, channels, heads):
+    """emph_word_transformer's image of one encoder layer (`state`: numpy
+    float32 arrays under `prefix`, the names of nn.TransformerEncoderLayer)."""
+    lib = library()
+    names = ('self_attn.in_proj_weight', 'self_attn.in_proj_bias',
+             'self_attn.out_proj.weight', 'self_attn.out_proj.bias',
+             'linear1.weight', 'linear1.bias', 'linear2.weight', 'linear2.bias',
+             'norm1.weight', 'norm1.bias', 'norm2.weight', 'norm2.bias')
+    arrays = [np.ascontiguousarray(state[prefix + name], dtype=np.float32)
+              for name in names]
+    pack = np.zeros(lib.emph_word_transformer_pack_size(channels, heads),
+                    dtype=np.float32)
+    check(lib.emph_word_transformer_pack(
+        *[array.ctypes.data for array in arrays], channels, heads,
+        pack.ctypes.data), 'emph_word_transformer_pack')
     return pack
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 16
+#define EMPH_ABI_VERSION 17
 
 /* Segment-table fields */
 enum {
@@ -418,6 +418,35 @@ int emph_qkv_projection(const float* x, int64_t ld, float* qk, float* v,
                         int32_t channels, const float* packs,
                         const float* bias, const int32_t* tiles,
                         int32_t n_tiles, int32_t tile_n, void* stream);
+
+/* The word-rate Transformer decoder in ONE launch: positional encoding + all
+ * `layers` post-LN encoder layers (transformer.py:13-52 as the word decoder,
+ * emphases/model/core.py:26-30,105-107) for segments of at most 64 words (a
+ * segment is one workgroup; the residual stream stays in registers between
+ * layers).  Replaces emph_add_position + layers x (emph_qkv_projection +
+ * emph_attention + emph_transformer_block) on the word axis.
+ *
+ *   x        float32 [channels, ld]   word embeddings, updated in place
+ *   position float32 [max_positions][channels] sinusoidal table
+ *   packs    `layers` images of emph_word_transformer_pack, back to back
+ *   tiles    word-axis tile table with block 64; every segment must have at most
+ *            64 words (the caller checks; longer segments take the three-kernel
+ *            path)
+ * channels 64 or 80, 2 heads, dim_feedforward = channels, ReLU. */
+int64_t emph_word_transformer_pack_size(int32_t channels, int32_t heads);
+int emph_word_transformer_pack(
+    const float* in_proj_weight, const float* in_proj_bias,
+    const float* out_weight, const float* out_bias,
+    const float* linear1_weight, const float* linear1_bias,
+    const float* linear2_weight, const float* linear2_bias,
+    const float* norm1_weight, const float* norm1_bias,
+    const float* norm2_weight, const float* norm2_bias, int32_t channels,
+    int32_t heads, float* host_pack);
+int emph_word_transformer(float* x, int64_t ld, const float* position,
+                          int32_t max_positions, int32_t channels,
+                          int32_t heads, const float* packs, int32_t layers,
+                          float eps, const int32_t* tiles, int32_t n_tiles,
+                          void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Evaluation metrics at word resolution                                     */

@@ -602,3 +602,44 @@ def test_session_pipeline_pcm_and_layout_cache(default_engine):
     assert all(s.is_cuda for s in on_device)
     assert torch.equal(
         torch.cat([s.reshape(-1) for s in on_device]).cpu(), want[0])
+
+
+@pytest.mark.parametrize('channels', [80, 64])
+def test_word_transformer_equals_three_kernel_path(channels):
+    """emph_word_transformer (positional encoding + all decoder layers in one
+    launch, a segment per workgroup) against the per-layer path
+    (emph_add_position, emph_qkv_projection, emph_attention,
+    emph_transformer_block) on segments of 1 .. 64 words, and against torch's
+    nn.TransformerEncoder on one of them."""
+    config = cfg.Config(architecture='transformer', channels=channels)
+    state = weights.random_state(config, seed=11)
+    engine = engine_module.Engine(config, state, 0)
+    assert engine.word_transformer is not None
+    words = [64, 1, 16, 17, 33, 48, 2, 63]
+    segments = [batch.Segment(
+        i, 0, n, 0, 0, 4 * n, np.stack([4 * np.arange(n), 4 * np.arange(n) + 4]))
+        for i, n in enumerate(words)]
+    plan = batch.Plan(segments, [0] * len(words), [0] * len(words))
+    meta = engine.upload(plan)
+    x = torch.from_numpy(synth.weights(
+        5, (channels, plan.ld_words), 1.0)).to(engine.device)
+    fused = engine._stack_forward(
+        engine.word_decoder, x.clone(), None, plan.ld_words, plan, meta,
+        runtime.AXIS_WORDS, engine.word_block, 'words')
+    packs, engine.word_transformer = engine.word_transformer, None
+    try:
+        stepped = engine._stack_forward(
+            engine.word_decoder, x.clone(), None, plan.ld_words, plan, meta,
+            runtime.AXIS_WORDS, engine.word_block, 'words')
+    finally:
+        engine.word_transformer = packs
+    columns = plan.word_columns()
+    a, b = fused[:, columns].cpu(), stepped[:, columns].cpu()
+    assert torch.isfinite(a).all()
+    assert float((a - b).abs().max()) < 2e-5
+    # torch reference for the 33-word segment
+    torch_state = {k: torch.from_numpy(v) for k, v in state.items()}
+    off, n = int(plan.word_off[4]), 33
+    want = oracle.transformer_stack(
+        x[:, off:off + n].cpu(), torch_state, 'word_decoder', config.layers)
+    assert float((fused[:, off:off + n].cpu() - want).abs().max()) < 2e-5
