@@ -643,3 +643,55 @@ def test_word_transformer_equals_three_kernel_path(channels):
     want = oracle.transformer_stack(
         x[:, off:off + n].cpu(), torch_state, 'word_decoder', config.layers)
     assert float((fused[:, off:off + n].cpu() - want).abs().max()) < 2e-5
+
+
+@pytest.mark.timeout(900)
+def test_corpus_slice_and_long_form_batch(default_engine):
+    """Larger slices of BASELINE configs[3] and [4] on the one GPU of the test
+    box: 600 utterances of 2-30 s as ONE ragged batch (about a million frames,
+    several trips of every kernel over the chip), and eight 5-minute utterances
+    chunked at batch_size = 3000 in one batch.  Size-independent properties
+    (determinism, range, order independence) plus sampled utterances against
+    the oracle."""
+    state = {k: torch.from_numpy(v) for k, v in weights.load().items()}
+    frames = synth.corpus_frames(600, 200, 3000)
+    assert int(frames.sum()) > 900000
+    audios = [torch.from_numpy(synth.audio(2000 + i, int(n)))
+              for i, n in enumerate(frames)]
+    aligns = [emphases_amd.Alignment.from_frames(
+        synth.word_frames(2000 + i, int(n))) for i, n in enumerate(frames)]
+    scores = emphases_amd.from_alignments_and_audios(aligns, audios)
+    again = emphases_amd.from_alignments_and_audios(aligns, audios)
+    order = np.random.default_rng(3).permutation(len(audios))
+    shuffled = emphases_amd.from_alignments_and_audios(
+        [aligns[i] for i in order], [audios[i] for i in order])
+    back = [None] * len(audios)
+    for position, index in enumerate(order):
+        back[index] = shuffled[position]
+    for index, (a, b, c) in enumerate(zip(scores, again, back)):
+        assert a.shape == (1, len(aligns[index]))
+        assert torch.equal(a, b)
+        assert torch.isfinite(a).all() and (a > 0).all() and (a < 1).all()
+        # an utterance's scores do not depend on its place in the batch
+        assert torch.equal(a, c)
+        if index % 100 == 7:
+            times = [(w.start(), w.end()) for w in aligns[index]]
+            want = oracle.from_alignment_and_audio(times, audios[index], state)
+            assert np.abs(a.numpy() - want.numpy()).max() < SCORE_TOLERANCE
+
+    frames = 30000
+    audios = [torch.from_numpy(synth.audio(3000 + i, frames)) for i in range(8)]
+    bounds = [synth.word_frames(3000 + i, frames) for i in range(8)]
+    aligns = [emphases_amd.Alignment.from_frames(b) for b in bounds]
+    got = emphases_amd.from_alignments_and_audios(
+        aligns, audios, batch_size=3000)
+    for index in (0, 5):
+        want = oracle.from_alignment_and_audio(
+            seconds(bounds[index]), audios[index], state, batch_size=3000)
+        assert got[index].shape == want.shape and got[index].shape[1] > 500
+        assert np.abs(got[index].numpy() - want.numpy()).max() < SCORE_TOLERANCE
+    # (a small batch takes 16-position direct-form conv tiles, a large one the
+    # Winograd F(4,3) kernel - `Engine.frame_tile` - so not bit for bit)
+    single = emphases_amd.from_alignment_and_audio(
+        aligns[3], audios[3], 16000, batch_size=3000)
+    assert np.abs(single.numpy() - got[3].numpy()).max() < 1e-6
