@@ -351,8 +351,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 
-// The same attention for LONG segments: a workgroup is four waves = 256
-// consecutive queries of one segment and head, and the key / value blocks every
+// The same attention for LONG segments: a workgroup is eight waves of 32 queries
+// (126 VGPRs: four waves per SIMD; four waves of 64 queries at two per SIMD are
+// 6 % slower) = 256 consecutive queries of one segment and head, and the key / value blocks every
 // one of them needs travel L2 -> registers -> LDS ONCE per workgroup (the
 // one-wave kernel above reads them from L2 once per wave: 1.3 GB per layer on
 // 64 x 1000 frames).  Stages of 64 keys, double buffered: while the MFMAs run
@@ -362,20 +363,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // 32 distinct banks):
 //     K[d][64 keys]   row stride 80 floats  (A fragment: K[4 s + kk][key0 + col])
 //     V[key][D]       row stride D + 4      (A fragment: V[key0 + 4 kk + r][16 m + col])
+#ifndef EMPH_ATT_QT
+#define EMPH_ATT_QT 2        // 16-query tiles per wave: 4 (four waves) or 2 (eight)
+#endif
+constexpr int kGroupThreads = 256 * 4 / EMPH_ATT_QT;
 template <int D>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(kGroupThreads)
+__attribute__((amdgpu_waves_per_eu(8 / EMPH_ATT_QT, 8 / EMPH_ATT_QT)))
 void attention_group_kernel(
     const float* __restrict__ qk, const float* __restrict__ v, float* __restrict__ out,
     int64_t ld, int channels, const int32_t* __restrict__ tiles,
     const int32_t* __restrict__ key_counts) {
-    constexpr int QT = 4;                 // 16-query tiles per wave
+    constexpr int QT = EMPH_ATT_QT;       // 16-query tiles per wave
+    constexpr int THREADS = kGroupThreads;
     constexpr int KSTEPS = D / 4;
     constexpr int MT = (D + 15) / 16;
     constexpr int STAGE = 64;             // keys per stage
     constexpr int KROW = 80;              // floats per K row (64 keys + pad)
     constexpr int VROW = D + 4;           // floats per V row
     constexpr int KFLOATS = D * KROW, VFLOATS = STAGE * VROW;
-    constexpr int PIECES = (D * STAGE / 4 + 255) / 256;     // 16-byte pieces per thread
+    constexpr int PIECES = (D * STAGE / 4 + THREADS - 1) / THREADS;     // 16-byte pieces per thread
     __shared__ __align__(16) float stage_k[2][KFLOATS];
     __shared__ __align__(16) float stage_v[2][VFLOATS];
 
@@ -386,7 +393,7 @@ void attention_group_kernel(
     const int kk = lane >> 4;
     const int head = blockIdx.y;
     const Tile span = load_tile(tiles, blockIdx.x);
-    const int q0 = span.first + 64 * wave;
+    const int q0 = span.first + 16 * QT * wave;
     const int queries = span.count;
     const int length = key_counts != nullptr ? min(key_counts[span.segment], span.count)
                                              : span.count;
@@ -403,7 +410,7 @@ void attention_group_kernel(
     auto fetch = [&](int key0) {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int piece = tid + 256 * i;
+            const int piece = tid + THREADS * i;
             if (piece < D * STAGE / 4) {
                 // K: piece = (d, 4 keys); clamped keys (masked or never used)
                 const int d = piece / (STAGE / 4), quad = piece - d * (STAGE / 4);
@@ -429,7 +436,7 @@ void attention_group_kernel(
     auto deposit = [&](int buffer) {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
-            const int piece = tid + 256 * i;
+            const int piece = tid + THREADS * i;
             if (piece < D * STAGE / 4) {
                 const int d = piece / (STAGE / 4), quad = piece - d * (STAGE / 4);
                 *reinterpret_cast<f32x4*>(&stage_k[buffer][d * KROW + 4 * quad]) = hold_k[i];
@@ -466,7 +473,7 @@ void attention_group_kernel(
     // no vector instruction adds probabilities up.
     constexpr bool kOnes = D % 16 != 0;
     if (kOnes) {
-        for (int index = tid; index < 2 * STAGE; index += 256)
+        for (int index = tid; index < 2 * STAGE; index += THREADS)
             stage_v[index / STAGE][(index % STAGE) * VROW + D] = 1.f;
     }
 
@@ -671,15 +678,15 @@ int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
     if (tile_n == 256) {
         switch (d) {
             case 32:
-                EMPH_LAUNCH(attention_group_kernel<32>, grid, dim3(256), 0, s, qk, v, out, ld,
+                EMPH_LAUNCH(attention_group_kernel<32>, grid, dim3(kGroupThreads), 0, s, qk, v, out, ld,
                             channels, tiles, key_counts);
                 break;
             case 40:
-                EMPH_LAUNCH(attention_group_kernel<40>, grid, dim3(256), 0, s, qk, v, out, ld,
+                EMPH_LAUNCH(attention_group_kernel<40>, grid, dim3(kGroupThreads), 0, s, qk, v, out, ld,
                             channels, tiles, key_counts);
                 break;
             case 64:
-                EMPH_LAUNCH(attention_group_kernel<64>, grid, dim3(256), 0, s, qk, v, out, ld,
+                EMPH_LAUNCH(attention_group_kernel<64>, grid, dim3(kGroupThreads), 0, s, qk, v, out, ld,
                             channels, tiles, key_counts);
                 break;
             default:
