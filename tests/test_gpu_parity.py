@@ -695,3 +695,29 @@ def test_corpus_slice_and_long_form_batch(default_engine):
     single = emphases_amd.from_alignment_and_audio(
         aligns[3], audios[3], 16000, batch_size=3000)
     assert np.abs(single.numpy() - got[3].numpy()).max() < 1e-6
+
+
+def test_odd_lengths_and_offsets(default_engine):
+    """Utterances whose sample counts are odd put the next utterance at an odd
+    offset of the packed buffer: 4-byte-aligned (float32) and 2-byte-aligned
+    (16-bit PCM) 8- and 4-byte loads in the front-end.  Float and PCM inputs
+    must agree bit for bit, and with the oracle."""
+    state = {k: torch.from_numpy(v) for k, v in weights.load().items()}
+    lengths = [16001, 12345, 48000, 7777, 160 * 300 + 159]
+    audios, aligns = [], []
+    for index, samples in enumerate(lengths):
+        frames = samples // 160
+        full = synth.audio(400 + index, frames + 1)[:, :samples]
+        audios.append(torch.from_numpy(np.ascontiguousarray(full)))
+        aligns.append(emphases_amd.Alignment.from_frames(
+            synth.word_frames(400 + index, frames, 3, 40)))
+    floats = emphases_amd.from_alignments_and_audios(aligns, audios)
+    pcm = emphases_amd.from_alignments_and_audios(
+        aligns, [torch.from_numpy(np.rint(a.numpy() * 32768.).astype(np.int16))
+                 for a in audios])
+    for index, (a, b) in enumerate(zip(floats, pcm)):
+        assert torch.equal(a, b)
+        times = [(w.start(), w.end()) for w in aligns[index]]
+        want = oracle.from_alignment_and_audio(times, audios[index], state)
+        assert a.shape == want.shape
+        assert np.abs(a.numpy() - want.numpy()).max() < SCORE_TOLERANCE
