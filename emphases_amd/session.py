@@ -20,6 +20,7 @@ front-end kernel (identical scores: x / 32768 is exact).
 """
 import collections
 import concurrent.futures
+import os
 import threading
 
 import numpy as np
@@ -29,7 +30,7 @@ from . import batch
 from . import config as cfg
 from . import load
 
-COPY_THREADS = 16
+COPY_THREADS = int(os.environ.get('EMPHASES_COPY_THREADS', 16))
 _POOL = None
 _POOL_LOCK = threading.Lock()
 
@@ -114,9 +115,13 @@ class _Lane:
             run.append(i)
         if run:
             runs.append(run)
+        # about 3 MB per copy thread: more threads than that cost more in
+        # dispatch than they gain (tools/api_throughput.py: 8 threads for 20 MB
+        # of PCM, 16 for 41 MB of float32)
+        threads = max(1, min(COPY_THREADS, total * item // (3 << 20)))
         pieces = []
         for run in runs:
-            step = max(1, -(-len(run) // COPY_THREADS))
+            step = max(1, -(-len(run) // threads))
             pieces += [run[k:k + step] for k in range(0, len(run), step)]
         if len(pieces) > 1 and total * item > (1 << 20):
             futures = [_pool().submit(gather, piece) for piece in pieces]
