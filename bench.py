@@ -384,6 +384,10 @@ def main():
                 'algorithmic_flops_per_launch': flops / launches,
                 # Winograd F(2,3) executes 2/3, F(4,3) 1/2 of the direct form's
                 # MFMA work
+                # SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of this
+                # kernel, profiles/r2_pmc_utilisation.md
+                'mfma_pipe_busy_pmc': 0.49 if 'winograd4' in dominant else (
+                    0.74 if dominant == 'attention_frames' else None),
                 'executed_mfma_flops_per_launch': flops / launches * (
                     .5 if 'winograd4' in dominant else
                     2. / 3. if 'winograd' in dominant else 1.)},
