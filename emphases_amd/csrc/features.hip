@@ -50,6 +50,40 @@ __global__ __launch_bounds__(256) void pitch_rows_kernel(
     if (periodicity_out != nullptr) row(periodicity, periodicity_out, false);
 }
 
+// Polyphase windowed-sinc resampling of every utterance of a batch
+// (emphases/core.py:613-619 -> torchaudio.transforms.Resample, whose strided
+// conv1d this restates): output sample m = i * new_rate + phase of an utterance
+// is sum_k kernel[phase][k] * x[i * orig + k - width], zero outside the
+// utterance.  One thread per output sample, the taps of a phase streamed from
+// L2 (a warp's lanes hold consecutive phases: the kernel table is read once per
+// 64 outputs, the audio window is shared).  grid = (blocks, utterances).
+template <bool PCM>
+__global__ __launch_bounds__(256) void resample_kernel(
+    const void* __restrict__ audio, const int64_t* __restrict__ table,
+    const float* __restrict__ kernel, int orig, int fresh, int width, int taps,
+    float* __restrict__ out) {
+    const int64_t* row = table + static_cast<int64_t>(blockIdx.y) * 4;
+    const int64_t source = row[0], length = row[1], target = row[2], count = row[3];
+    for (int64_t m = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; m < count;
+         m += static_cast<int64_t>(gridDim.x) * 256) {
+        const int64_t i = m / fresh;
+        const int phase = static_cast<int>(m - i * fresh);
+        const int64_t base = i * orig - width;
+        const float* weights = kernel + static_cast<int64_t>(phase) * taps;
+        float acc = 0.f;
+        for (int k = 0; k < taps; ++k) {
+            const int64_t at = base + k;
+            if (at < 0 || at >= length) continue;
+            const float x = PCM ? static_cast<float>(
+                                      static_cast<const int16_t*>(audio)[source + at]) *
+                                      (1.f / 32768.f)
+                                : static_cast<const float*>(audio)[source + at];
+            acc = fmaf(weights[k], x, acc);
+        }
+        out[target + m] = acc;
+    }
+}
+
 }  // namespace emph
 
 using namespace emph;
@@ -78,6 +112,29 @@ int emph_pitch_rows(const float* pitch, const float* periodicity, float* out, in
         periodicity_row < 0 ? nullptr : out + static_cast<int64_t>(periodicity_row) * ld, ld,
         normalize, logfmin, logfmax - logfmin);
     return check_launch("emph_pitch_rows");
+}
+
+int emph_resample(const void* audio, int32_t audio_format, const int64_t* table,
+                  int32_t n_utterances, int64_t most_samples, const float* kernel,
+                  int32_t orig, int32_t fresh, int32_t width, float* out, void* stream) {
+    if (n_utterances == 0 || most_samples == 0) return EMPH_OK;
+    EMPH_REQUIRE(audio && table && kernel && out, EMPH_EINVAL, "emph_resample: null pointer");
+    EMPH_REQUIRE(audio_format == EMPH_AUDIO_F32 || audio_format == EMPH_AUDIO_PCM16,
+                 EMPH_EINVAL, "emph_resample: unknown audio format %d", audio_format);
+    EMPH_REQUIRE(orig > 0 && fresh > 0 && width >= 0, EMPH_EINVAL,
+                 "emph_resample: rates %d -> %d, width %d", orig, fresh, width);
+    const int taps = 2 * width + orig;
+    const int64_t blocks = (most_samples + 255) / 256;
+    dim3 grid(static_cast<unsigned>(blocks < 4096 ? blocks : 4096),
+              static_cast<unsigned>(n_utterances));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (audio_format == EMPH_AUDIO_PCM16)
+        EMPH_LAUNCH(resample_kernel<true>, grid, dim3(256), 0, s, audio, table, kernel, orig,
+                    fresh, width, taps, out);
+    else
+        EMPH_LAUNCH(resample_kernel<false>, grid, dim3(256), 0, s, audio, table, kernel, orig,
+                    fresh, width, taps, out);
+    return check_launch("emph_resample");
 }
 
 }  // extern "C"

@@ -98,12 +98,13 @@ def audio(file, raw=False):
     return resample(samples, rate)
 
 
-def resample(audio, sample_rate, target_rate=cfg.SAMPLE_RATE,
-             lowpass_filter_width=6, rolloff=0.99):
-    """Windowed-sinc resampling (torchaudio.transforms.Resample defaults)."""
+def resample_kernel(sample_rate, target_rate=cfg.SAMPLE_RATE,
+                    lowpass_filter_width=6, rolloff=0.99):
+    """Polyphase windowed-sinc kernel of torchaudio.transforms.Resample's
+    defaults, restated from its published algorithm (third-party,
+    parity-unpinned): `(kernel float32 [new, 1, 2 width + orig], orig, new,
+    width)` with the two rates divided by their gcd."""
     sample_rate, target_rate = int(sample_rate), int(target_rate)
-    if sample_rate == target_rate:
-        return audio
     gcd = math.gcd(sample_rate, target_rate)
     orig, new = sample_rate // gcd, target_rate // gcd
     base = min(orig, new) * rolloff
@@ -117,11 +118,28 @@ def resample(audio, sample_rate, target_rate=cfg.SAMPLE_RATE,
     t = t * math.pi
     kernel = torch.where(t == 0, torch.ones_like(t), t.sin() / t)
     kernel = (kernel * window * (base / orig)).to(torch.float32)
+    return kernel, orig, new, width
+
+
+def resampled_length(length, orig, new):
+    return int(math.ceil(new * length / orig))
+
+
+def resample(audio, sample_rate, target_rate=cfg.SAMPLE_RATE,
+             lowpass_filter_width=6, rolloff=0.99):
+    """Windowed-sinc resampling on the HOST (torchaudio.transforms.Resample
+    defaults): file plumbing and the checker of the device version
+    (`emph_resample`, which the batch API uses)."""
+    sample_rate, target_rate = int(sample_rate), int(target_rate)
+    if sample_rate == target_rate:
+        return audio
+    kernel, orig, new, width = resample_kernel(
+        sample_rate, target_rate, lowpass_filter_width, rolloff)
     shape = audio.shape
     flat = audio.reshape(-1, shape[-1]).to(torch.float32).cpu()
     length = flat.shape[-1]
     flat = torch.nn.functional.pad(flat, (width, width + orig))
     result = torch.nn.functional.conv1d(flat[:, None], kernel, stride=orig)
     result = result.transpose(1, 2).reshape(flat.shape[0], -1)
-    target = int(math.ceil(new * length / orig))
+    target = resampled_length(length, orig, new)
     return result[..., :target].reshape(shape[:-1] + (target,))

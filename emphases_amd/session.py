@@ -44,13 +44,9 @@ def _pool():
     return _POOL
 
 
-def mono(audio, sample_rate):
-    """1-D tensor of channel 0 at 16 kHz (`mels.py:48` featurises channel 0
-    only; `core.py:353-354` resamples).  int16 stays int16."""
-    if sample_rate != cfg.SAMPLE_RATE:
-        if audio.dtype == torch.int16:
-            audio = audio.to(torch.float32) / 32768.
-        audio = load.resample(audio, sample_rate, cfg.SAMPLE_RATE)
+def mono(audio):
+    """1-D tensor of channel 0 (`mels.py:48` featurises channel 0 only), at
+    the caller's sample rate; int16 stays int16."""
     audio = audio[0] if audio.dim() == 2 else audio.reshape(-1)
     if audio.dtype not in (torch.float32, torch.int16):
         audio = audio.to(torch.float32)
@@ -67,6 +63,7 @@ class _Lane:
         self.done = torch.cuda.Event()
         self.staging = None           # pinned uint8
         self.audio = None             # device uint8
+        self.raw = None               # device uint8: audio before resampling
         self.result = None            # pinned float32
         self.pending = None
         # recurring batch layouts: key -> _Layout (plan, device metadata and,
@@ -84,13 +81,22 @@ class _Lane:
             self.result = torch.empty(
                 max(words, 1) * 5 // 4, dtype=torch.float32).pin_memory()
 
-    def stage(self, audios, lengths, dtype):
+    def stage(self, audios, lengths, dtype, raw=False):
         """Packed device tensor of all utterances (dtype float32 or int16),
-        enqueued on this lane's stream."""
+        enqueued on this lane's stream.  `raw`: into the buffer that holds
+        audio at the caller's rate, in front of the resampler."""
         item = 2 if dtype == torch.int16 else 4
         total = int(sum(lengths))
         offsets = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int64)
-        device_view = self.audio[:max(total, 1) * item].view(dtype)[:total]
+        if raw:
+            if self.raw is None or self.raw.numel() < total * item:
+                self.raw = torch.empty(
+                    max(total * item, 1) * 5 // 4, dtype=torch.uint8,
+                    device=self.device)
+            buffer = self.raw
+        else:
+            buffer = self.audio
+        device_view = buffer[:max(total, 1) * item].view(dtype)[:total]
         on_host = [i for i, a in enumerate(audios) if not a.is_cuda]
         host_view = self.staging[:max(total, 1) * item].view(dtype)[:total]
         # numpy does the gather: np.copyto releases the GIL and runs at memory
@@ -218,6 +224,37 @@ class Session:
         self.lanes = [_Lane(engine) for _ in range(max(1, depth))]
         self._cursor = 0
         self._lock = threading.Lock()
+        self._kernels = {}        # sample rate -> resampling kernel on the device
+
+    def _resample(self, lane, audios, lengths, dtype, sample_rate):
+        """`emphases.resample` (`core.py:613-619`) for the whole batch on the
+        device: stage the audio at its own rate, one `emph_resample` launch
+        into the lane's packed 16 kHz buffer.  Returns (packed float32 device
+        tensor, lengths at 16 kHz)."""
+        from . import runtime
+        if sample_rate not in self._kernels:
+            kernel, orig, new, width = load.resample_kernel(sample_rate)
+            self._kernels[sample_rate] = (
+                kernel.reshape(new, -1).contiguous().to(lane.device),
+                orig, new, width)
+        kernel, orig, new, width = self._kernels[sample_rate]
+        targets = [load.resampled_length(n, orig, new) for n in lengths]
+        source = np.cumsum([0] + lengths)
+        target = np.cumsum([0] + targets)
+        table = np.stack(
+            [source[:-1], lengths, target[:-1], targets], axis=1).astype(np.int64)
+        raw = lane.stage(audios, lengths, dtype, raw=True)
+        table_device = lane.engine._pinned(
+            'resample', table.view(np.int32).ravel()).to(
+                lane.device, non_blocking=True)
+        out = lane.audio[:max(int(target[-1]), 1) * 4].view(torch.float32)[
+            :int(target[-1])]
+        runtime.check(runtime.library().emph_resample(
+            raw.data_ptr(), 1 if dtype == torch.int16 else 0,
+            table_device.data_ptr(), len(lengths), max(targets + [0]),
+            kernel.data_ptr(), orig, new, width, out.data_ptr(),
+            runtime.stream()), 'emph_resample')
+        return out, targets
 
     def submit(self, alignments, audios, sample_rate=cfg.SAMPLE_RATE,
                batch_size=None, on_device=False, pitch_tracker=None):
@@ -230,14 +267,21 @@ class Session:
             if lane.pending is not None:
                 lane.pending.result()
             alignments = list(alignments)
-            audios = [mono(audio, sample_rate) for audio in audios]
+            audios = [mono(audio) for audio in audios]
+            resampling = int(sample_rate) != cfg.SAMPLE_RATE
             pcm = bool(audios) and all(
                 audio.dtype == torch.int16 for audio in audios)
             dtype = torch.int16 if pcm else torch.float32
             if not pcm:
                 audios = [audio.to(torch.float32) if audio.dtype != torch.float32
                           else audio for audio in audios]
-            lengths = [int(audio.shape[0]) for audio in audios]
+            raw_lengths = [int(audio.shape[0]) for audio in audios]
+            lengths = raw_lengths
+            if resampling:
+                _, orig, new, _ = load.resample_kernel(sample_rate)
+                lengths = [load.resampled_length(n, orig, new)
+                           for n in raw_lengths]
+                dtype_in, dtype = dtype, torch.float32
             layout = None
             key = layout_key(alignments, lengths, batch_size, dtype) \
                 if audios else None
@@ -260,16 +304,28 @@ class Session:
                 return pending
             engine = lane.engine
             lane._reserve(
-                sum(lengths) * (2 if pcm else 4), plan.ld_words)
+                max(sum(lengths) * (2 if dtype == torch.int16 else 4),
+                    sum(raw_lengths) * 4 if resampling else 0),
+                plan.ld_words)
             with torch.cuda.device(lane.device), \
                     torch.cuda.stream(lane.stream):
                 tracks = None
                 if engine.config.pitch_feature or \
                         engine.config.periodicity_feature:
                     from . import core
+                    # (the tracker runs on the host and wants 16 kHz audio)
+                    heard = audios if not resampling else [
+                        load.resample(
+                            (a.to(torch.float32) / 32768.
+                             if a.dtype == torch.int16 else a).cpu(),
+                            sample_rate) for a in audios]
                     tracks = core._tracks(
-                        engine, plan, audios, pitch_tracker, lane.device.index)
-                packed = lane.stage(audios, lengths, dtype)
+                        engine, plan, heard, pitch_tracker, lane.device.index)
+                if resampling:
+                    packed, _ = self._resample(
+                        lane, audios, raw_lengths, dtype_in, sample_rate)
+                else:
+                    packed = lane.stage(audios, lengths, dtype)
                 layout.seen += 1
                 if tracks is None and layout.replay is None and \
                         layout.seen >= 2 and key in lane.layouts:

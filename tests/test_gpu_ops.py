@@ -767,3 +767,54 @@ def test_word_metrics(loss):
     got, want = mine(), theirs()
     for key in want:
         assert abs(got[key] - want[key]) < 2e-6 * max(1., abs(want[key])), key
+
+
+@pytest.mark.parametrize('rate', [8000, 22050, 44100, 48000])
+def test_resample(rate):
+    """emph_resample against the host restatement of torchaudio's Resample
+    (`load.resample`: strided conv1d with the same kernel table), float32 and
+    16-bit PCM input, a ragged batch of three utterances."""
+    import emphases_amd
+    from emphases_amd import load
+    lib = runtime.library()
+    kernel, orig, new, width = load.resample_kernel(rate)
+    lengths = [rate // 3 + 17, 5, rate // 2]
+    audios = [torch.from_numpy(synth.weights(200 + i, (n,), 0.9))
+              for i, n in enumerate(lengths)]
+    targets = [load.resampled_length(n, orig, new) for n in lengths]
+    table = np.stack([np.cumsum([0] + lengths)[:-1], lengths,
+                      np.cumsum([0] + targets)[:-1], targets], axis=1)
+    table_dev = torch.from_numpy(table.astype(np.int64)).to(DEVICE)
+    kernel_dev = kernel.reshape(new, -1).contiguous().to(DEVICE)
+    for pcm in (False, True):
+        if pcm:
+            host = [torch.from_numpy(np.rint(a.numpy() * 32767.).astype(np.int16))
+                    for a in audios]
+            source = torch.cat(host).to(DEVICE)
+            reference = [h.to(torch.float32) / 32768. for h in host]
+        else:
+            source = torch.cat(audios).to(DEVICE)
+            reference = audios
+        out = torch.full((sum(targets) + 8,), 7.0, device=DEVICE)
+        runtime.check(lib.emph_resample(
+            source.data_ptr(), int(pcm), table_dev.data_ptr(), len(lengths),
+            max(targets), kernel_dev.data_ptr(), orig, new, width,
+            out.data_ptr(), None), 'emph_resample')
+        out = out.cpu()
+        assert float(out[sum(targets):].min()) == 7.0
+        cursor = 0
+        for audio, count in zip(reference, targets):
+            want = load.resample(audio[None], rate)[0]
+            assert want.shape == (count,)
+            got = out[cursor:cursor + count]
+            assert float((got - want).abs().max()) < 2e-6
+            cursor += count
+    # through the public API: device resampling == host resampling first
+    frames = 240
+    words = emphases_amd.Alignment.from_frames(synth.word_frames(9, frames))
+    native = torch.from_numpy(synth.weights(77, (1, frames * rate // 100), 0.3))
+    on_device = emphases_amd.from_alignment_and_audio(words, native, rate)
+    on_host = emphases_amd.from_alignment_and_audio(
+        words, load.resample(native, rate), 16000)
+    assert on_device.shape == on_host.shape == (1, len(words))
+    assert float((on_device - on_host).abs().max()) < 1e-5
