@@ -13,6 +13,9 @@ __device__ unsigned long long* g_stamps = nullptr;
     } while (0)
 #include "../../emphases_amd/csrc/decoder.hip"
 #include "../../emphases_amd/csrc/conv.hip"
+// stub for the library's error slot (lives in frontend.hip)
+namespace emph { void set_error(const char*, ...) {} }
+extern "C" const char* emph_last_error(void) { return ""; }
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 int main(int argc, char** argv) {
