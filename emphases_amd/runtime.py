@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -45,6 +45,7 @@ SIGNATURES = {
         _i64, _i32, _i32, _ptr, _ptr, _i32, _ptr]),
     'emph_frontend_peak': (_c.c_int, [
         _ptr, _i32, _ptr, _ptr, _i32, _ptr, _ptr, _ptr]),
+    'emph_host_gather': (_c.c_int, [_ptr, _ptr, _ptr, _i32, _ptr, _i32]),
     'emph_resample': (_c.c_int, [
         _ptr, _i32, _ptr, _i32, _i64, _ptr, _i32, _i32, _i32, _ptr, _ptr]),
     'emph_pitch_rows': (_c.c_int, [

@@ -8,9 +8,10 @@ keeps `depth` lanes, each with its own HIP stream, engine workspace, pinned
 staging buffer and pinned result buffer:
 
     submit(batch i+1)   plan on the host, gather the utterances into pinned
-                        memory with a few copy threads, enqueue ONE
-                        host-to-device copy + the kernels + the copy of the
-                        scores back, all on the lane's stream, and return
+                        memory (`emph_host_gather`: the library's pool of copy
+                        threads), enqueue the host-to-device copy + the kernels
+                        + the copy of the scores back, all on the lane's
+                        stream, and return
     result(batch i)     wait for that lane's event, split the scores
 
 so the PCIe transfer and the host planning of one batch run under the kernels
@@ -19,7 +20,6 @@ are staged and transferred as they are - half the bytes - and converted by the
 front-end kernel (identical scores: x / 32768 is exact).
 """
 import collections
-import concurrent.futures
 import os
 import threading
 
@@ -31,19 +31,6 @@ from . import config as cfg
 from . import load
 
 COPY_THREADS = int(os.environ.get('EMPHASES_COPY_THREADS', 16))
-_POOL = None
-_POOL_LOCK = threading.Lock()
-
-
-def _pool():
-    global _POOL
-    with _POOL_LOCK:
-        if _POOL is None:
-            _POOL = concurrent.futures.ThreadPoolExecutor(
-                COPY_THREADS, thread_name_prefix='emphases-stage')
-    return _POOL
-
-
 def mono(audio):
     """1-D tensor of channel 0 (`mels.py:48` featurises channel 0 only), at
     the caller's sample rate; int16 stays int16."""
@@ -99,44 +86,37 @@ class _Lane:
         device_view = buffer[:max(total, 1) * item].view(dtype)[:total]
         on_host = [i for i, a in enumerate(audios) if not a.is_cuda]
         host_view = self.staging[:max(total, 1) * item].view(dtype)[:total]
-        # numpy does the gather: np.copyto releases the GIL and runs at memory
-        # speed, while torch's CPU copy_ into a slice of a large tensor is 10x
-        # slower here (tools/h2d_paths.py: 15 ms against 1.4 ms for 41 MB)
-        target = host_view.numpy()
-        sources = {i: audios[i].contiguous().numpy() for i in on_host}
-
-        def gather(indices):
-            for i in indices:
-                np.copyto(target[offsets[i]:offsets[i + 1]], sources[i])
-            return indices[0], indices[-1]
-
-        # contiguous runs of host utterances, a few per copy thread; each run
-        # goes to the device as soon as its thread is done with it, so the DMA
-        # of one piece runs under the gather of the next
-        runs, run = [], []
-        for i in on_host:
-            if run and i != run[-1] + 1:
-                runs.append(run)
-                run = []
-            run.append(i)
-        if run:
-            runs.append(run)
-        # about 3 MB per copy thread: more threads than that cost more in
-        # dispatch than they gain (tools/api_throughput.py: 8 threads for 20 MB
-        # of PCM, 16 for 41 MB of float32)
+        # The gather runs in the library (`emph_host_gather`: a persistent pool
+        # of copy threads; numpy copies from a Python thread pool reach 58 GB/s
+        # and torch's CPU copy_ into a slice of a large tensor a tenth of that,
+        # tools/h2d_paths.py).  A few pieces, each sent to the device as soon as
+        # it is gathered, so the DMA of one runs under the gather of the next.
+        from . import runtime
+        lib = runtime.library()
+        sources = [audios[i].contiguous() for i in on_host]
+        pointers = np.array([a.data_ptr() for a in sources], dtype=np.int64)
+        nbytes = np.array([lengths[i] * item for i in on_host], dtype=np.int64)
+        where = np.array([offsets[i] * item for i in on_host], dtype=np.int64)
         threads = max(1, min(COPY_THREADS, total * item // (3 << 20)))
-        pieces = []
-        for run in runs:
-            step = max(1, -(-len(run) // threads))
-            pieces += [run[k:k + step] for k in range(0, len(run), step)]
-        if len(pieces) > 1 and total * item > (1 << 20):
-            futures = [_pool().submit(gather, piece) for piece in pieces]
-            spans = (future.result() for future in futures)
-        else:
-            spans = (gather(piece) for piece in pieces)
-        for first, last in spans:
-            lo, hi = int(offsets[first]), int(offsets[last + 1])
-            device_view[lo:hi].copy_(host_view[lo:hi], non_blocking=True)
+        pieces = max(1, min(4, len(on_host), total * item // (8 << 20)))
+        edges = np.linspace(0, len(on_host), pieces + 1).astype(int)
+        base = host_view.data_ptr()
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            if hi == lo:
+                continue
+            runtime.check(lib.emph_host_gather(
+                pointers[lo:hi].ctypes.data, nbytes[lo:hi].ctypes.data,
+                where[lo:hi].ctypes.data, int(hi - lo), base, int(threads)),
+                'emph_host_gather')
+            # contiguous runs of the piece go to the device
+            first = lo
+            for k in range(lo + 1, hi + 1):
+                if k == hi or on_host[k] != on_host[k - 1] + 1:
+                    start = int(offsets[on_host[first]])
+                    stop = int(offsets[on_host[k - 1] + 1])
+                    device_view[start:stop].copy_(
+                        host_view[start:stop], non_blocking=True)
+                    first = k
         for i, audio in enumerate(audios):
             if audio.is_cuda:
                 device_view[offsets[i]:offsets[i + 1]].copy_(

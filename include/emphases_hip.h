@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 18
+#define EMPH_ABI_VERSION 19
 
 /* Segment-table fields */
 enum {
@@ -100,6 +100,20 @@ enum {
 
 int emph_abi_version(void);
 const char* emph_last_error(void);
+
+/* ------------------------------------------------------------------------ */
+/* Host staging                                                              */
+/* ------------------------------------------------------------------------ */
+
+/* Copy `count` host buffers into one host destination (the pinned staging
+ * buffer of a ragged batch) with `threads` threads (a persistent pool; the
+ * caller's thread copies too).  All pointers are HOST pointers.  Replaces the
+ * per-utterance `audio.to(device)` of emphases/data/preprocess/core.py:74 on
+ * the way to ONE host-to-device copy per batch.
+ *   host_offsets[i]  byte offset of buffer i in the destination */
+int emph_host_gather(const void* const* host_sources, const int64_t* host_bytes,
+                     const int64_t* host_offsets, int32_t count,
+                     void* host_destination, int32_t threads);
 
 /* ------------------------------------------------------------------------ */
 /* Front-end: framed log-mel (+ optional A-weighted loudness row)            */
