@@ -222,6 +222,32 @@ def end_to_end_api(audios, alignments, rounds=40):
             'ms_per_call_pipelined': piped * 1e3,
             'utterances_per_s_pipelined': len(audios) / piped,
             'bit_identical_to_float32': bool(torch.equal(flat, reference))}
+    # every call a layout never seen before (what a stream of real utterances
+    # looks like: the layout cache and its captured graph never hit)
+    fresh = [[emphases_amd.Alignment.from_frames(
+        synth.word_frames(5000 + 64 * k + i, FRAMES),
+        synth.word_names(synth.word_frames(5000 + 64 * k + i, FRAMES).shape[1]))
+        for i in range(len(audios))] for k in range(24)]
+    for group in fresh[:4]:
+        emphases_amd.from_alignments_and_audios(group, floats, 16000)
+    laps = []
+    for group in fresh[4:]:
+        start = time.perf_counter()
+        emphases_amd.from_alignments_and_audios(group, floats, 16000)
+        laps.append(time.perf_counter() - start)
+    start = time.perf_counter()
+    previous = None
+    for group in fresh[4:]:
+        pending = session.submit(group, floats, 16000)
+        if previous is not None:
+            previous.result()
+        previous = pending
+    previous.result()
+    piped = (time.perf_counter() - start) / len(fresh[4:])
+    result['float32_new_layout_every_call'] = {
+        'ms_per_call': float(np.median(laps)) * 1e3,
+        'ms_per_call_pipelined': piped * 1e3,
+        'utterances_per_s_pipelined': len(audios) / piped}
     result['what'] = (
         'emphases_amd.from_alignments_and_audios on 64 x 10 s host tensors: '
         'planning + staging + H2D + kernels + D2H; pipelined = 2 batches in '

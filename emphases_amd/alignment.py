@@ -71,6 +71,8 @@ class Alignment:
                     f'Alignment file format of {path} is not supported')
         self._words = _fill_gaps(words)
         self._relative = relative
+        self._times = None
+        self.times()          # the batch planner reads the words as one array
 
     @classmethod
     def from_frames(cls, bounds, names=None, frames_per_second=100.0):
@@ -110,7 +112,7 @@ class Alignment:
     def times(self):
         """float64 [W, 2] (start, end) seconds of every word (cached: the
         batch planner reads all words of all utterances as arrays)."""
-        cached = getattr(self, '_times', None)
+        cached = self._times
         if cached is None or cached.shape[0] != len(self._words):
             import numpy as np
             cached = np.array(
