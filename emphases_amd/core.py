@@ -169,9 +169,12 @@ def from_file(text_file, audio_file, checkpoint=None, batch_size=None,
             return from_text_and_audio(
                 file.read(), load.audio(audio_file), cfg.SAMPLE_RATE,
                 checkpoint, batch_size, gpu)
+    # the file's own rate: a file that is not at 16 kHz is resampled on the
+    # device with the rest of the path (`core.py:44` does it on the host)
+    samples, rate = load.wav(audio_file, raw=True)
     return from_alignment_and_audio(
-        alignment_module.Alignment(text_file), load.audio(audio_file),
-        cfg.SAMPLE_RATE, checkpoint, batch_size, gpu)
+        alignment_module.Alignment(text_file), samples, rate, checkpoint,
+        batch_size, gpu)
 
 
 def _save(alignment, scores, output_prefix):
@@ -205,26 +208,34 @@ def from_files_to_files(text_files, audio_files, output_prefixes=None,
         if not str(file).endswith(('.TextGrid', '.json')):
             from_text_and_audio(None, None, None)
     session = get_session(checkpoint, gpu)
-    in_flight = None
+    in_flight = []
 
-    def finish(job):
-        pending, alignments, prefixes = job
-        for item, scores, prefix in zip(alignments, pending.result(), prefixes):
-            _save(item, scores, prefix)
+    def finish(jobs):
+        for pending, alignments, prefixes in jobs:
+            for item, scores, prefix in zip(
+                    alignments, pending.result(), prefixes):
+                _save(item, scores, prefix)
 
     for first in range(0, len(text_files), utterances_per_batch):
         last = first + utterances_per_batch
         alignments = [
             alignment_module.Alignment(file)
             for file in text_files[first:last]]
-        audios = [load.audio(file, raw=True) for file in audio_files[first:last]]
-        pending = session.submit(
-            alignments, audios, cfg.SAMPLE_RATE, batch_size)
-        if in_flight is not None:
-            finish(in_flight)
-        in_flight = (pending, alignments, output_prefixes[first:last])
-    if in_flight is not None:
+        loaded = [load.wav(file, raw=True) for file in audio_files[first:last]]
+        prefixes = output_prefixes[first:last]
+        # one submission per sample rate (files that are not at 16 kHz are
+        # resampled on the device, a rate at a time)
+        jobs = []
+        for rate in sorted({rate for _, rate in loaded}):
+            chosen = [i for i, (_, r) in enumerate(loaded) if r == rate]
+            picked = [alignments[i] for i in chosen]
+            jobs.append((
+                session.submit(
+                    picked, [loaded[i][0] for i in chosen], rate, batch_size),
+                picked, [prefixes[i] for i in chosen]))
         finish(in_flight)
+        in_flight = jobs
+    finish(in_flight)
 
 
 ###############################################################################
