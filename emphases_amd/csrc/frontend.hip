@@ -83,9 +83,12 @@ constexpr int kExRow = 72;                                     // complex per ex
 // odd step 9 spreads t (or p0) over those 16: both directions are conflict free
 // (with rows of 8 the reads were 4-way conflicts: SQ_LDS_BANK_CONFLICT was 42 %
 // of the LDS-active cycles of this kernel).
-constexpr int kExRowB = 88;
+#ifndef EMPH_FE_ROWB
+#define EMPH_FE_ROWB 88
+#endif
+constexpr int kExRowB = EMPH_FE_ROWB;
 constexpr int kExStepB = 9;
-constexpr int kExFloats = 2 * 8 * kExRowB;                     // 1408 floats per wave
+constexpr int kExFloats = 2 * 8 * kExRowB;                     // floats per frame slot
 // natural-order spectrum: 4 complex of padding after every 32 so that the
 // stride-8 writes of the last pass (lanes t and t + 4 used to collide) and the
 // contiguous reads of the real-FFT split are both conflict free
@@ -445,12 +448,23 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
     // samples of the first pair; every later pair is requested one iteration
     // ahead (a global load takes 1-2 us under load: far longer than a pair's
     // arithmetic could hide behind the transform's own LDS round trips)
+#ifndef EMPH_FE_PREFETCH
+#define EMPH_FE_PREFETCH 1
+#endif
+    constexpr bool kPrefetch = EMPH_FE_PREFETCH != 0;
     cf raw[kPair][8];
+    if (kPrefetch) {
 #pragma unroll
-    for (int f = 0; f < kPair; ++f)
-        // an odd tail repeats the last frame (its result is written twice)
-        load_frame<PCM>(chunk, frame0 + min(f, valid - 1), p, raw[f]);
+        for (int f = 0; f < kPair; ++f)
+            // an odd tail repeats the last frame (its result is written twice)
+            load_frame<PCM>(chunk, frame0 + min(f, valid - 1), p, raw[f]);
+    }
     for (int local = 0; local < valid; local += kPair) {
+        if (!kPrefetch) {
+#pragma unroll
+            for (int f = 0; f < kPair; ++f)
+                load_frame<PCM>(chunk, frame0 + min(local + f, valid - 1), p, raw[f]);
+        }
         cf v[kPair][8];
         cf* ex[kPair];
         if (local == 8) EMPH_STAMP(2);
@@ -462,7 +476,7 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
                 v[f][q] = raw[f][q] * cf{window[2 * q], window[2 * q + 1]};
         }
         if (local == 8) EMPH_STAMP(3);
-        if (local + kPair < valid) {          // wave-uniform
+        if (kPrefetch && local + kPair < valid) {          // wave-uniform
 #pragma unroll
             for (int f = 0; f < kPair; ++f)
                 load_frame<PCM>(chunk, frame0 + min(local + kPair + f, valid - 1), p, raw[f]);
