@@ -9,8 +9,9 @@
 //   mel basis matmul, log(clamp(., 1e-5))             mels.py:94-109
 //   librosa loudness (always on CPU in the reference) data/preprocess/loudness.py:59-107
 //
-// Design (gfx950): a wave owns tiles of 16 consecutive frames and transforms
-// them two at a time.  A frame's 1024 samples come straight from the packed
+// Design (gfx950): a wave owns tiles of 8 consecutive frames (kWaveFrames) and
+// transforms them one at a time (kPair), three waves per SIMD covering each
+// other's LDS round trips.  A frame's 1024 samples come straight from the packed
 // audio as eight coalesced 8-byte loads per lane (float32; 4-byte loads for
 // 16-bit PCM) - consecutive frames overlap by 864 samples, so all but the first
 // touch of a sample is an L1/L2 hit and HBM sees each sample about once; the
@@ -19,8 +20,8 @@
 // points per lane - three radix-8 passes in registers with two wave-private LDS
 // transposes - followed by the real-FFT split on bin pairs (only the high half
 // of the spectrum crosses lanes), magnitudes, the 1001-non-zero sparse mel
-// projection and the log.  The wave's [80 x 16] result tile is staged in LDS and
-// written as 64-byte row segments.  There is no workgroup barrier anywhere, and
+// projection and the log.  The wave's [80 x 8] result tile is staged in LDS and
+// written as 32-byte row segments.  There is no workgroup barrier anywhere, and
 // nothing of the 513 x F complex spectrogram ever reaches HBM.
 #include <math.h>
 #include <stdarg.h>
@@ -310,7 +311,9 @@ __device__ __forceinline__ void load_frame(const Chunk& chunk, int frame, int p,
 //
 // A workgroup is four INDEPENDENT waves (no workgroup barrier anywhere): each
 // owns tiles of kWaveFrames consecutive frames and transforms them kPair at a
-// time, so that one frame's arithmetic covers the other's LDS round trips.
+// time (kPair = 2 lets one frame's arithmetic cover the other's LDS round trips
+// at 253 VGPRs; kPair = 1 at 164 VGPRs puts three waves on a SIMD instead and is
+// what ships: 66.5 vs 68.7 us).
 template <int MODE, bool PCM>
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend_kernel(
