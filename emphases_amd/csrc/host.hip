@@ -20,20 +20,35 @@
 
 namespace {
 
+// A source is copied in pieces of at most kPiece bytes, so that a batch of a
+// few long utterances (BASELINE configs[4]: eight of 19 MB) spreads over the
+// threads like one of many short ones.
+constexpr int64_t kPiece = 1 << 20;
+
+struct Piece {
+    const char* source;
+    char* destination;
+    size_t bytes;
+};
+
 struct Job {
-    const void* const* sources = nullptr;
-    const int64_t* bytes = nullptr;
-    const int64_t* offsets = nullptr;
-    char* destination = nullptr;
+    std::vector<Piece> pieces;
     int count = 0;
+    int workers = 0;                  // pool threads that take part (the rest sleep on)
+    int active = 0;                   // ... and are inside drain() (guarded by the pool mutex)
     std::atomic<int> next{0};
     std::atomic<int> done{0};
 };
 
 class Pool {
   public:
-    explicit Pool(int threads) {
-        for (int i = 0; i < threads; ++i) workers_.emplace_back([this] { work(); });
+    explicit Pool(int threads) { grow(threads); }
+    // (the pool only grows: a call that asks for fewer threads leaves the others asleep)
+    void grow(int threads) {
+        while (size() < threads) {
+            const int index = size();
+            workers_.emplace_back([this, index] { work(index); });
+        }
     }
     ~Pool() {
         {
@@ -53,7 +68,8 @@ class Pool {
         wake_.notify_all();
         drain(job);                               // the caller copies too
         std::unique_lock<std::mutex> lock(mutex_);
-        finished_.wait(lock, [&] { return job->done.load() >= job->count; });
+        // (the job lives on the caller's stack: nobody may still hold it)
+        finished_.wait(lock, [&] { return job->done.load() >= job->count && job->active == 0; });
         job_ = nullptr;
     }
 
@@ -62,13 +78,13 @@ class Pool {
         for (;;) {
             const int index = job->next.fetch_add(1);
             if (index >= job->count) return;
-            memcpy(job->destination + job->offsets[index], job->sources[index],
-                   static_cast<size_t>(job->bytes[index]));
+            const Piece& piece = job->pieces[index];
+            memcpy(piece.destination, piece.source, piece.bytes);
             job->done.fetch_add(1);
         }
     }
-    void work() {
-        uint64_t seen = 0;
+    void work(int index) {
+        uint64_t seen = generation_at_start();
         for (;;) {
             Job* job;
             {
@@ -77,12 +93,20 @@ class Pool {
                 if (stop_) return;
                 seen = generation_;
                 job = job_;
+                if (job == nullptr || index >= job->workers) continue;
+                ++job->active;
             }
-            if (job == nullptr) continue;
             drain(job);
             std::lock_guard<std::mutex> lock(mutex_);
+            --job->active;
             finished_.notify_all();
         }
+    }
+    // a thread added by grow() must not take the generation that was current
+    // before it existed for a new job
+    uint64_t generation_at_start() {
+        std::lock_guard<std::mutex> lock(mutex_);
+        return generation_;
     }
     std::vector<std::thread> workers_;
     std::mutex mutex_;
@@ -108,16 +132,22 @@ int emph_host_gather(const void* const* host_sources, const int64_t* host_bytes,
     EMPH_REQUIRE(threads >= 1 && threads <= 64, EMPH_EINVAL,
                  "emph_host_gather: %d threads (1 .. 64)", threads);
     std::lock_guard<std::mutex> guard(g_pool_mutex);       // one gather at a time
-    if (g_pool == nullptr || g_pool->size() != threads - 1) {
-        delete g_pool;
-        g_pool = new Pool(threads - 1);
-    }
+    if (g_pool == nullptr) g_pool = new Pool(threads - 1);
+    g_pool->grow(threads - 1);
     Job job;
-    job.sources = host_sources;
-    job.bytes = host_bytes;
-    job.offsets = host_offsets;
-    job.destination = static_cast<char*>(host_destination);
-    job.count = count;
+    for (int32_t i = 0; i < count; ++i) {
+        EMPH_REQUIRE(host_bytes[i] >= 0 && host_offsets[i] >= 0, EMPH_EINVAL,
+                     "emph_host_gather: source %d has a negative size or offset", i);
+        const char* source = static_cast<const char*>(host_sources[i]);
+        char* destination = static_cast<char*>(host_destination) + host_offsets[i];
+        for (int64_t at = 0; at < host_bytes[i]; at += kPiece) {
+            const int64_t bytes = host_bytes[i] - at < kPiece ? host_bytes[i] - at : kPiece;
+            job.pieces.push_back({source + at, destination + at, static_cast<size_t>(bytes)});
+        }
+    }
+    job.count = static_cast<int>(job.pieces.size());
+    job.workers = threads - 1;
+    if (job.count == 0) return EMPH_OK;
     g_pool->run(&job);
     return EMPH_OK;
 }

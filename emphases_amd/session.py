@@ -31,6 +31,13 @@ from . import config as cfg
 from . import load
 
 COPY_THREADS = int(os.environ.get('EMPHASES_COPY_THREADS', 16))
+# A synchronous call with more audio than twice this is run as consecutive
+# sub-batches of about this size over the lanes, so that the kernels of one
+# run under the PCIe transfer of the next (a rank's 1.28 GB share of BASELINE
+# configs[3]: 23 ms of DMA at 55 GB/s in front of 5.4 ms of kernels).
+SPLIT_BYTES = int(os.environ.get('EMPHASES_SPLIT_BYTES', 256 << 20))
+
+
 def mono(audio):
     """1-D tensor of channel 0 (`mels.py:48` featurises channel 0 only), at
     the caller's sample rate; int16 stays int16."""
@@ -269,13 +276,10 @@ class Session:
                 layout = lane.layouts.get(key)
                 if layout is not None:
                     lane.layouts.move_to_end(key)
-            if layout is None and audios:
+            fresh = layout is None and bool(audios)
+            if fresh:
                 layout = _Layout(
                     batch.plan_batch(alignments, lengths, batch_size))
-                if key is not None:
-                    lane.layouts[key] = layout
-                    while len(lane.layouts) > _Layout.KEEP:
-                        lane.layouts.popitem(last=False)
             plan = layout.plan if layout is not None else None
             pending = Pending(
                 lane, plan, len(audios), on_device,
@@ -283,10 +287,16 @@ class Session:
             if plan is None or not len(plan):
                 return pending
             engine = lane.engine
+            # (growing the buffers drops the cached layouts, whose graphs point
+            # into the old ones: so before this layout joins the cache)
             lane._reserve(
                 max(sum(lengths) * (2 if dtype == torch.int16 else 4),
                     sum(raw_lengths) * 4 if resampling else 0),
                 plan.ld_words)
+            if fresh and key is not None:
+                lane.layouts[key] = layout
+                while len(lane.layouts) > _Layout.KEEP:
+                    lane.layouts.popitem(last=False)
             with torch.cuda.device(lane.device), \
                     torch.cuda.stream(lane.stream):
                 tracks = None
@@ -329,7 +339,34 @@ class Session:
 
     def run(self, alignments, audios, sample_rate=cfg.SAMPLE_RATE,
             batch_size=None, on_device=False, pitch_tracker=None):
-        """submit + result: one synchronous batch."""
-        return self.submit(
-            alignments, audios, sample_rate, batch_size, on_device,
-            pitch_tracker).result()
+        """submit + result: one synchronous batch (very large ones as a few
+        sub-batches in flight, see SPLIT_BYTES; an utterance's scores do not
+        depend on its neighbours in a batch)."""
+        alignments, audios = list(alignments), list(audios)
+        groups = self._groups(audios)
+        pendings = [
+            self.submit(alignments[lo:hi], audios[lo:hi], sample_rate,
+                        batch_size, on_device, pitch_tracker)
+            for lo, hi in groups]
+        if len(pendings) == 1:
+            return pendings[0].result()
+        return [scores for pending in pendings for scores in pending.result()]
+
+    def _groups(self, audios):
+        """[(first, last + 1)] of the sub-batches of a synchronous call."""
+        whole = [(0, len(audios))]
+        if len(self.lanes) < 2 or len(audios) < 2:
+            return whole
+        sizes = np.array(
+            [int(a.shape[-1]) * (2 if a.dtype == torch.int16 else 4)
+             for a in audios], dtype=np.int64)
+        total = int(sizes.sum())
+        if total <= 2 * SPLIT_BYTES:
+            return whole
+        count = -(-total // SPLIT_BYTES)
+        # equal shares of the bytes, cut at utterance boundaries
+        ends = np.searchsorted(
+            np.cumsum(sizes), total * np.arange(1, count + 1) / count, 'left') + 1
+        ends = np.unique(np.minimum(ends, len(audios)))
+        return list(zip(np.concatenate([[0], ends[:-1]]).tolist(),
+                        ends.tolist()))

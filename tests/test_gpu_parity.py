@@ -622,6 +622,46 @@ def test_session_pipeline_pcm_and_layout_cache(default_engine):
         torch.cat([s.reshape(-1) for s in on_device]).cpu(), want[0])
 
 
+def test_large_call_runs_as_sub_batches(default_engine, monkeypatch):
+    """A synchronous call with more audio than 2 x session.SPLIT_BYTES runs as
+    consecutive sub-batches over the lanes (kernels of one under the transfer
+    of the next): same scores, same order, every utterance present - also when
+    the sub-batches outnumber the lanes and when the call repeats (cached
+    layouts and graphs per lane)."""
+    from emphases_amd import session as session_module
+    state = {k: torch.from_numpy(v) for k, v in weights.load().items()}
+    frames = synth.corpus_frames(90, 200, 3000, seed=77)
+    audios = [torch.from_numpy(synth.audio(600 + i, int(n)))
+              for i, n in enumerate(frames)]
+    aligns = [emphases_amd.Alignment.from_frames(
+        synth.word_frames(600 + i, int(n))) for i, n in enumerate(frames)]
+    whole = session_module.Session(default_engine, depth=2)
+    assert whole._groups(audios) == [(0, len(audios))]
+    want = whole.run(aligns, audios)
+    monkeypatch.setattr(session_module, 'SPLIT_BYTES', 12 << 20)
+    split = session_module.Session(default_engine, depth=2)
+    groups = split._groups(audios)
+    assert len(groups) >= 5 and groups[0][0] == 0
+    assert groups[-1][1] == len(audios)
+    assert all(a[1] == b[0] and a[0] < a[1] for a, b in zip(groups, groups[1:]))
+    for _ in range(3):
+        got = split.run(aligns, audios)
+        assert len(got) == len(want)
+        for index, (a, b) in enumerate(zip(got, want)):
+            assert a.shape == b.shape == (1, len(aligns[index]))
+            # (sub-batches of another size may take another conv tile variant)
+            assert float((a - b).abs().max()) < 1e-6
+    index = 41
+    times = [(w.start(), w.end()) for w in aligns[index]]
+    expect = oracle.from_alignment_and_audio(times, audios[index], state)
+    assert np.abs(got[index].numpy() - expect.numpy()).max() < SCORE_TOLERANCE
+    # one sub-batch per lane is the least that pays: a single-lane session
+    # and a single utterance are never split
+    assert session_module.Session(default_engine, depth=1)._groups(audios) \
+        == [(0, len(audios))]
+    assert split._groups(audios[:1]) == [(0, 1)]
+
+
 @pytest.mark.parametrize('channels', [80, 64])
 def test_word_transformer_equals_three_kernel_path(channels):
     """emph_word_transformer (positional encoding + all decoder layers in one
