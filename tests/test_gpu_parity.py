@@ -755,6 +755,43 @@ def test_corpus_slice_and_long_form_batch(default_engine):
     assert np.abs(single.numpy() - got[3].numpy()).max() < 1e-6
 
 
+@pytest.mark.timeout(900)
+def test_full_size_corpus():
+    """BASELINE configs[3] at FULL size on the one GPU of the test box: 10 000
+    utterances of 2-30 s (16 M frames, 10 GB of audio) through the public API
+    in one call.  The audio of utterance i is a prefix of one of 24 distinct
+    30 s signals (generating 2.6 G distinct samples would take minutes); the
+    alignments are all distinct.  Size-independent properties - one score per
+    word, range, independence of the order of the batch - plus sampled
+    utterances against the oracle."""
+    state = {k: torch.from_numpy(v) for k, v in weights.load().items()}
+    frames = synth.corpus_frames(10000, 200, 3000)
+    assert 15_000_000 < int(frames.sum()) < 17_000_000
+    pool = [torch.from_numpy(synth.audio(7000 + i, 3000)) for i in range(24)]
+    audios = [pool[i % len(pool)][:, :int(n) * 160]
+              for i, n in enumerate(frames)]
+    aligns = [emphases_amd.Alignment.from_frames(
+        synth.word_frames(5000 + i, int(n))) for i, n in enumerate(frames)]
+    scores = emphases_amd.from_alignments_and_audios(aligns, audios)
+    assert len(scores) == len(aligns)
+    total = 0
+    for index, a in enumerate(scores):
+        assert a.shape == (1, len(aligns[index]))
+        total += a.shape[1]
+    assert total > 450_000
+    flat = torch.cat([a.reshape(-1) for a in scores])
+    assert torch.isfinite(flat).all() and (flat > 0).all() and (flat < 1).all()
+    # the corpus back to front: other neighbours, other sub-batches
+    again = emphases_amd.from_alignments_and_audios(aligns[::-1], audios[::-1])
+    back = torch.cat([a.reshape(-1) for a in again[::-1]])
+    assert float((flat - back).abs().max()) < 1e-6
+    for index in (0, 1234, 4321, 7777, 9999):
+        times = [(w.start(), w.end()) for w in aligns[index]]
+        want = oracle.from_alignment_and_audio(times, audios[index], state)
+        assert np.abs(scores[index].numpy() - want.numpy()).max() \
+            < SCORE_TOLERANCE
+
+
 def test_odd_lengths_and_offsets(default_engine):
     """Utterances whose sample counts are odd put the next utterance at an odd
     offset of the packed buffer: 4-byte-aligned (float32) and 2-byte-aligned
