@@ -47,11 +47,15 @@ struct Run6 {
 
 // M_TILES = ceil(c_out / 16) (compile time: the LDS offsets of the 6 M_TILES
 // fragments of an iteration are immediates)
-template <int M_TILES>
+// POSITION: the layer is followed by PositionalEncoding (transformer.py:45-52) -
+// `position[c][t]`, channel-major with `max_positions` columns, is added to the
+// output at position t of its segment (after the activation).
+template <int M_TILES, bool POSITION>
 __global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
     const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
     const float* __restrict__ pack, const float* __restrict__ bias, int c_in, int c_out,
-    int act, const int32_t* __restrict__ tiles, int n_tiles, int bias_offset) {
+    int act, const int32_t* __restrict__ tiles, int n_tiles, int bias_offset,
+    const float* __restrict__ position, int max_positions) {
     EMPH_STAMP(0);
     extern __shared__ __align__(16) float weights[];   // [groups][6][m_tiles][64]
     const int lane = threadIdx.x & 63;
@@ -217,6 +221,18 @@ __global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
                     out.w = out.w < 0.f ? 0.f : out.w;
                 }
                 if (channel0 + r >= c_out || t >= span.count) continue;
+                if (POSITION) {
+                    const float* encoding =
+                        position + static_cast<int64_t>(channel0 + r) * max_positions + t;
+                    if (t + 3 < max_positions) {
+                        const f32x4u e = *reinterpret_cast<const f32x4u*>(encoding);
+                        out.x += e[0], out.y += e[1], out.z += e[2], out.w += e[3];
+                    } else {
+                        if (t < max_positions) out.x += encoding[0];
+                        if (t + 1 < max_positions) out.y += encoding[1];
+                        if (t + 2 < max_positions) out.z += encoding[2];
+                    }
+                }
                 float* target = y + static_cast<int64_t>(channel0 + r) * ldy + span.offset + t;
                 if (vector_ok && t + 3 < span.count) {
                     *reinterpret_cast<float4*>(target) = out;
@@ -278,10 +294,10 @@ int emph_conv_winograd4_pack(const float* host_weight, int32_t c_out, int32_t c_
     return EMPH_OK;
 }
 
-int emph_conv1d_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
-                          const float* pack, const float* bias, int32_t c_in, int32_t c_out,
-                          int32_t activation, const int32_t* tiles, int32_t n_tiles,
-                          void* stream) {
+static int launch_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
+                            const float* pack, const float* bias, int32_t c_in, int32_t c_out,
+                            int32_t activation, const int32_t* tiles, int32_t n_tiles,
+                            const float* position, int32_t max_positions, void* stream) {
     if (n_tiles == 0) return EMPH_OK;
     EMPH_REQUIRE(x && y && pack && tiles, EMPH_EINVAL, "emph_conv1d_winograd4: null pointer");
     EMPH_REQUIRE(activation == EMPH_ACT_NONE || activation == EMPH_ACT_RELU, EMPH_ERANGE,
@@ -289,6 +305,8 @@ int emph_conv1d_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
     EMPH_REQUIRE(c_in >= 4 && c_in % 4 == 0 && c_out >= 1 && c_out <= 96, EMPH_ERANGE,
                  "emph_conv1d_winograd4: channels %d -> %d (c_in a multiple of 4, c_out <= 96)",
                  c_in, c_out);
+    EMPH_REQUIRE(position == nullptr || max_positions > 0, EMPH_EINVAL,
+                 "emph_conv1d_winograd4_position: %d positions in the table", max_positions);
     const size_t lds = static_cast<size_t>(emph_conv_winograd4_lds_bytes(c_out, c_in));
     EMPH_REQUIRE(lds <= 160 * 1024, EMPH_ERANGE,
                  "emph_conv1d_winograd4: %zu bytes of LDS needed", lds);
@@ -297,15 +315,20 @@ int emph_conv1d_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int groups = (n_tiles + 3) / 4;
     dim3 grid(groups < 256 ? groups : 256);
-#define EMPH_W4(M_TILES)                                                                       \
-    do {                                                                                  \
-        auto kernel = conv1d_winograd4_kernel<M_TILES>;                                        \
+#define EMPH_W4_LAUNCH(M_TILES, POSITION)                                                      \
+    do {                                                                                       \
+        auto kernel = conv1d_winograd4_kernel<M_TILES, POSITION>;                              \
         static LdsReservation reserved;                                                        \
         if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,     \
                                      "emph_conv1d_winograd4"))                                 \
             return status;                                                                     \
-        EMPH_LAUNCH(kernel, grid, dim3(512), lds, s, x, ldx, y, ldy, pack, bias,   \
-                           c_in, c_out, activation, tiles, n_tiles, bias_offset);         \
+        EMPH_LAUNCH(kernel, grid, dim3(512), lds, s, x, ldx, y, ldy, pack, bias, c_in, c_out,  \
+                    activation, tiles, n_tiles, bias_offset, position, max_positions);         \
+    } while (0)
+#define EMPH_W4(M_TILES)                                                                       \
+    do {                                                                                       \
+        if (position != nullptr) EMPH_W4_LAUNCH(M_TILES, true);                                \
+        else EMPH_W4_LAUNCH(M_TILES, false);                                                   \
     } while (0)
     switch (m_tiles) {
         case 1: EMPH_W4(1); break;
@@ -319,7 +342,27 @@ int emph_conv1d_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
             return EMPH_ERANGE;
     }
 #undef EMPH_W4
+#undef EMPH_W4_LAUNCH
     return check_launch("emph_conv1d_winograd4");
+}
+
+int emph_conv1d_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
+                          const float* pack, const float* bias, int32_t c_in, int32_t c_out,
+                          int32_t activation, const int32_t* tiles, int32_t n_tiles,
+                          void* stream) {
+    return launch_winograd4(x, ldx, y, ldy, pack, bias, c_in, c_out, activation, tiles, n_tiles,
+                            nullptr, 0, stream);
+}
+
+int emph_conv1d_winograd4_position(const float* x, int64_t ldx, float* y, int64_t ldy,
+                                   const float* pack, const float* bias, int32_t c_in,
+                                   int32_t c_out, int32_t activation, const int32_t* tiles,
+                                   int32_t n_tiles, const float* position,
+                                   int32_t max_positions, void* stream) {
+    EMPH_REQUIRE(position != nullptr, EMPH_EINVAL,
+                 "emph_conv1d_winograd4_position: null position table");
+    return launch_winograd4(x, ldx, y, ldy, pack, bias, c_in, c_out, activation, tiles, n_tiles,
+                            position, max_positions, stream);
 }
 
 }  // extern "C"

@@ -142,6 +142,9 @@ class Engine:
         if config.architecture == 'transformer':
             self.position = to(weights_module.positional_encoding(
                 cfg.MAX_POSITIONS, config.channels))
+            # channel-major copy: what the input layer's epilogue adds when the
+            # encoding is fused into it (emph_conv1d_winograd4_position)
+            self.position_rows = self.position.t().contiguous()
         # the whole word-rate Transformer decoder as one launch (segments of
         # at most 64 words): csrc/word_transformer.hip
         self.word_transformer = None
@@ -160,7 +163,6 @@ class Engine:
         frame_layers = [self.input_layer] + (
             self.frame_encoder if config.architecture == 'convolution' else [])
         self.quad = winograd and config.activation in (None, 'relu') and \
-            config.architecture == 'convolution' and \
             all(layer.winograd4 is not None for layer in frame_layers)
         self.model = self._conv_model()
 
@@ -337,8 +339,11 @@ class Engine:
             (runtime.AXIS_FRAMES, tile),
             (runtime.AXIS_WORDS, self.word_block)]
         if self.config.architecture == 'transformer':
+            # (the fused projection / block kernels own 32 positions per wave,
+            # whatever tile the input layer's conv kernel takes)
             requests += [(runtime.AXIS_FRAMES, ATTENTION_BLOCK),
-                         (runtime.AXIS_FRAMES, ATTENTION_GROUP)]
+                         (runtime.AXIS_FRAMES, ATTENTION_GROUP),
+                         (runtime.AXIS_FRAMES, 32)]
             if not nested:
                 requests += [(runtime.AXIS_WORDS, ATTENTION_BLOCK)]
         requests = list(dict.fromkeys(requests))
@@ -418,7 +423,10 @@ class Engine:
         return packed
 
     def _conv(self, layer, x, ldx, y, ldy, meta, axis, block, activation,
-              transpose_out=False):
+              transpose_out=False, position=False):
+        """`position`: the layer feeds a Transformer encoder - add the
+        positional encoding in the same launch when the F(4,3) kernel takes
+        the layer.  Returns whether it did."""
         tiles, size = meta[('tiles', axis, block)]
         positions = meta['positions'][axis]
         name = (f'conv1d_{"frames" if axis == runtime.AXIS_FRAMES else "words"}'
@@ -429,13 +437,22 @@ class Engine:
                 block == 64 and self.quad and not transpose_out and \
                 activation in (None, 'relu'):
             with self._timed(name.replace('conv1d', 'conv1d_winograd4'), flops):
+                if position:
+                    runtime.check(self.lib.emph_conv1d_winograd4_position(
+                        x.data_ptr(), ldx, y.data_ptr(), ldy,
+                        layer.winograd4.data_ptr(), bias, layer.c_in,
+                        layer.c_out, runtime.ACTIVATIONS[activation],
+                        tiles.data_ptr(), size // runtime.TILE_FIELDS,
+                        self.position_rows.data_ptr(), cfg.MAX_POSITIONS,
+                        runtime.stream()), 'emph_conv1d_winograd4_position')
+                    return True
                 runtime.check(self.lib.emph_conv1d_winograd4(
                     x.data_ptr(), ldx, y.data_ptr(), ldy,
                     layer.winograd4.data_ptr(), bias, layer.c_in, layer.c_out,
                     runtime.ACTIVATIONS[activation], tiles.data_ptr(),
                     size // runtime.TILE_FIELDS, runtime.stream()),
                     'emph_conv1d_winograd4')
-            return
+            return False
         if layer.winograd is not None and axis == runtime.AXIS_FRAMES and \
                 block in (32, 64) and not transpose_out:
             # same algorithmic flops; the kernel executes two thirds of them
@@ -446,7 +463,7 @@ class Engine:
                     runtime.ACTIVATIONS[activation], tiles.data_ptr(),
                     size // runtime.TILE_FIELDS, block, runtime.stream()),
                     'emph_conv1d_winograd')
-            return
+            return False
         with self._timed(name, flops):
             runtime.check(self.lib.emph_conv1d(
                 x.data_ptr(), ldx, y.data_ptr(), ldy, layer.pack.data_ptr(),
@@ -454,6 +471,7 @@ class Engine:
                 runtime.ACTIVATIONS[activation], tiles.data_ptr(),
                 size // runtime.TILE_FIELDS, block, int(transpose_out),
                 runtime.stream()), 'emph_conv1d')
+        return False
 
     def features(self, audio, plan, meta, tracks=None):
         """Feature matrix [num_features, ld_frames] of every segment
@@ -515,12 +533,15 @@ class Engine:
         return out
 
     def _transformer(self, layers, x, ld, plan, meta, axis, block, tag,
-                     key_counts=None):
-        """`Transformer.forward` (transformer.py:25-30) in place on x.
+                     key_counts=None, positioned=False):
+        """`Transformer.forward` (transformer.py:25-30) in place on x
+        (`positioned`: the producer of x has added the encoding already).
         `key_counts`: int32 device tensor, real (unpadded) positions per
         segment, for the key-padding mask over zero-padded word pieces."""
         config = self.config
         channels = config.channels
+        if block > 32 and ('tiles', axis, 32) in meta:
+            block = 32
         att_tiles, att_size = meta[('tiles', axis, ATTENTION_BLOCK)]
         att_count = att_size // runtime.TILE_FIELDS
         counts = plan.frames if axis == runtime.AXIS_FRAMES else plan.words
@@ -530,11 +551,12 @@ class Engine:
                 f'a chunk of {int(counts.max())} positions exceeds the '
                 f'{cfg.MAX_POSITIONS}-entry positional encoding; pass a '
                 'smaller batch_size')
-        with self._timed('add_position'):
-            runtime.check(self.lib.emph_add_position(
-                x.data_ptr(), ld, self.position.data_ptr(), channels,
-                cfg.MAX_POSITIONS, att_tiles.data_ptr(), att_count,
-                ATTENTION_BLOCK, runtime.stream()), 'emph_add_position')
+        if not positioned:
+            with self._timed('add_position'):
+                runtime.check(self.lib.emph_add_position(
+                    x.data_ptr(), ld, self.position.data_ptr(), channels,
+                    cfg.MAX_POSITIONS, att_tiles.data_ptr(), att_count,
+                    ATTENTION_BLOCK, runtime.stream()), 'emph_add_position')
         qk = self._buffer(tag + '_qk', 2 * channels, ld)
         v = self._buffer(tag + '_v', ld, channels)
         attended = self._buffer(tag + '_attended', channels, ld)
@@ -607,7 +629,7 @@ class Engine:
         return x
 
     def _stack_forward(self, layers, x, other, ld, plan, meta, axis, block,
-                       tag, key_counts=None):
+                       tag, key_counts=None, positioned=False):
         """Frame encoder / word decoder; returns the tensor holding the
         result (x or other)."""
         config = self.config
@@ -631,7 +653,7 @@ class Engine:
                     'emph_word_transformer')
             return x
         return self._transformer(
-            layers, x, ld, plan, meta, axis, block, tag, key_counts)
+            layers, x, ld, plan, meta, axis, block, tag, key_counts, positioned)
 
     ###########################################################################
     # Forward
@@ -723,14 +745,17 @@ class Engine:
         else:
             a = self._buffer('frames_a', channels, ld_f)
             b = self._buffer('frames_b', channels, ld_f)
-            self._conv(self.input_layer, features, ld_f, a, ld_f, meta,
-                       frames, block, None)
+            # (the stage dump wants the input layer's own output)
+            positioned = self._conv(
+                self.input_layer, features, ld_f, a, ld_f, meta, frames, block,
+                None, position=config.architecture == 'transformer' and
+                stages is None)
             if stages is not None:
                 stages['features'] = features.clone()
                 stages['input_layer'] = a.clone()
             encoded = self._stack_forward(
                 self.frame_encoder, a, b, ld_f, plan, meta, frames, block,
-                'frames')
+                'frames', positioned=positioned)
             if stages is not None:
                 stages['encoder'] = encoded.clone()
 

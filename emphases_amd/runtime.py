@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -67,6 +67,9 @@ SIGNATURES = {
     'emph_conv1d_winograd4': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _ptr, _i32,
         _ptr]),
+    'emph_conv1d_winograd4_position': (_c.c_int, [
+        _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _ptr, _i32,
+        _ptr, _i32, _ptr]),
     'emph_segment_reduce': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _i64, _i32, _ptr]),
     'emph_output_layer': (_c.c_int, [

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 19
+#define EMPH_ABI_VERSION 20
 
 /* Segment-table fields */
 enum {
@@ -274,6 +274,18 @@ int emph_conv1d_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
                           const float* pack, const float* bias, int32_t c_in,
                           int32_t c_out, int32_t activation,
                           const int32_t* tiles, int32_t n_tiles, void* stream);
+/* ... followed by PositionalEncoding (emphases/model/layers/transformer.py:45-52:
+ * `x + pe[:T]`, dropout the identity in eval) in the same launch, for the input
+ * layer in front of a Transformer encoder (model/core.py:88-99).  `position`:
+ * the sin / cos table CHANNEL-major, float32 [c_out][max_positions]; column t
+ * is added to position t of every segment after the activation. */
+int emph_conv1d_winograd4_position(const float* x, int64_t ldx, float* y,
+                                   int64_t ldy, const float* pack,
+                                   const float* bias, int32_t c_in,
+                                   int32_t c_out, int32_t activation,
+                                   const int32_t* tiles, int32_t n_tiles,
+                                   const float* position,
+                                   int32_t max_positions, void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Frame -> word resampling                                                  */

@@ -205,6 +205,61 @@ def test_conv1d_winograd4(c_in, c_out, activation):
         None) == -2                         # c_in must be a multiple of 4
 
 
+@pytest.mark.parametrize('c_in,c_out,activation,max_positions', [
+    (80, 80, None, 5000), (80, 80, 'relu', 150), (64, 64, None, 131),
+    (48, 33, None, 5000)])
+def test_conv1d_winograd4_position(c_in, c_out, activation, max_positions):
+    """Conv1d(k=3, 'same') followed by PositionalEncoding (`x + pe[:T]`,
+    transformer.py:45-52) in one launch: the table is channel-major, column
+    t goes to position t of EVERY segment, and positions beyond the table
+    (the engine raises before it gets there) are left without encoding."""
+    lib = runtime.library()
+    plan = ragged_plan([200, 1, 2, 3, 4, 5, 17, 64, 65, 130, 63, 66, 127])
+    axis, tile = runtime.AXIS_FRAMES, 64
+    meta = Meta(plan, [(axis, tile)])
+    x = random_packed(c_in, plan, axis, 21)
+    x[:, :batch.LEAD] = float('nan')
+    weight = synth.weights(7, (c_out, c_in, 3), 0.2)
+    bias = synth.weights(8, (c_out,), 0.5)
+    table = torch.from_numpy(synth.weights(9, (c_out, max_positions), 1.0))
+    y = torch.full((c_out, plan.ld_frames), 7.0, device=DEVICE)
+    pack = torch.from_numpy(runtime.conv_winograd4_pack(weight)).to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    x_dev, bias_dev = x.to(DEVICE), torch.from_numpy(bias).to(DEVICE)
+    table_dev = table.to(DEVICE)
+    runtime.check(lib.emph_conv1d_winograd4_position(
+        x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
+        pack.data_ptr(), bias_dev.data_ptr(), c_in, c_out,
+        runtime.ACTIVATIONS[activation], tiles.data_ptr(), size // 4,
+        table_dev.data_ptr(), max_positions, None),
+        'emph_conv1d_winograd4_position')
+    plain = torch.full((c_out, plan.ld_frames), 7.0, device=DEVICE)
+    runtime.check(lib.emph_conv1d_winograd4(
+        x_dev.data_ptr(), plan.ld_frames, plain.data_ptr(), plan.ld_frames,
+        pack.data_ptr(), bias_dev.data_ptr(), c_in, c_out,
+        runtime.ACTIVATIONS[activation], tiles.data_ptr(), size // 4, None),
+        'emph_conv1d_winograd4')
+    y, plain = y.cpu(), plain.cpu()
+    for off, count in spans(plan, axis):
+        want = ACTIVATIONS[activation](torch.nn.functional.conv1d(
+            x[None, :, off:off + count], torch.from_numpy(weight),
+            torch.from_numpy(bias), padding=1))[0]
+        covered = min(count, max_positions)
+        want[:, :covered] += table[:, :covered]
+        got = y[:, off:off + count]
+        assert torch.isfinite(got).all()
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got - want).abs().max()) < 5e-5 * scale
+        # exactly the plain kernel's output plus the table (one fp32 add)
+        assert torch.equal(
+            got[:, :covered], plain[:, off:off + covered] + table[:, :covered])
+    assert float(y[:, :batch.LEAD].min()) == 7.0
+    assert lib.emph_conv1d_winograd4_position(
+        x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
+        pack.data_ptr(), None, c_in, c_out, 0, tiles.data_ptr(), size // 4,
+        None, max_positions, None) == -1
+
+
 def test_conv1d_winograd_rejects_bad_arguments():
     lib = runtime.library()
     buffer = torch.zeros(4096, device=DEVICE)
