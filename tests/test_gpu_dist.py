@@ -87,3 +87,38 @@ def test_more_ranks_than_utterances(tmp_path):
     for result in results[1:]:
         for a, b in zip(result['scores'], results[0]['scores']):
             assert torch.equal(a, b)
+
+
+@pytest.mark.timeout(900)
+def test_bench_with_two_ranks(tmp_path):
+    """`bench.py --gpus 2` the way the driver launches it (one process per
+    rank, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) with
+    the gloo backend, both ranks on the one GPU of the box: rank 0 prints ONE
+    JSON line whose value is the whole job's rate (128 utterances per step),
+    the closing all_gather returns every rank's own rows intact (asserted
+    inside bench.py), and the other rank prints nothing."""
+    import json
+    port = _free_port()
+    children = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        children.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+             '--steps', '6', '--warmup', '2', '--backend', 'gloo',
+             '--no-cpu-baseline', '--no-api'],
+            env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True))
+    outputs = [child.communicate(timeout=600)[0] for child in children]
+    assert all(child.returncode == 0 for child in children)
+    lines = [l for l in outputs[0].splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    assert not [l for l in outputs[1].splitlines() if l.startswith('{')]
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['steps'] == 6
+    assert line['scaling'] == 'weak' and line['unit'] == 'utterances/s'
+    assert line['config']['utterances_per_gpu'] == 64
+    assert 'all_gather' in line['config']['exchange']
+    assert abs(line['value'] - 128 / (line['ms_per_step'] * 1e-3)) \
+        < 1e-6 * line['value']
+    assert line['roofline']['frac'] > 0 and 'cpu_baseline' not in line
