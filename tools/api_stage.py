@@ -1,0 +1,40 @@
+"""Public-API call latency percentiles on the bench workload and the share of the host gather:
+python tools/api_stage.py   (EMPHASES_COPY_STREAM=0 / EMPHASES_COPY_SPREAD=0 switch the gather measures off)"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench, emphases_amd
+from emphases_amd import runtime, session
+audios, alignments, _ = bench.workload(0)
+floats = [torch.from_numpy(a) for a in audios]
+lib = runtime.library()
+orig = lib.emph_host_gather
+spent = {'gather': 0.0, 'n': 0}
+class Wrap:
+    def __getattr__(self, name):
+        f = getattr(lib, name)
+        if name != 'emph_host_gather':
+            return f
+        def g(*a):
+            t = time.perf_counter(); r = f(*a); spent['gather'] += time.perf_counter() - t; spent['n'] += 1; return r
+        return g
+runtime_library = runtime.library
+runtime.library = lambda: Wrap()
+for _ in range(8):
+    emphases_amd.from_alignments_and_audios(alignments, floats, 16000)
+stage0 = session._Lane.stage
+st = {'stage': 0.0}
+def stage(self, *a, **k):
+    t = time.perf_counter(); r = stage0(self, *a, **k); st['stage'] += time.perf_counter() - t; return r
+session._Lane.stage = stage
+spent['gather'] = 0; spent['n'] = 0
+laps = []
+for _ in range(40):
+    time.sleep(0.002)
+    t = time.perf_counter()
+    emphases_amd.from_alignments_and_audios(alignments, floats, 16000)
+    laps.append(time.perf_counter() - t)
+laps = np.sort(laps) * 1e3
+print('call p10 %.3f p50 %.3f p90 %.3f max %.3f mean %.3f ms; mean stage %.3f gather %.3f' % (
+    laps[4], laps[20], laps[36], laps[-1], laps.mean(), st['stage'] / 40 * 1e3, spent['gather'] / 40 * 1e3))
+print('cpu affinity', len(os.sched_getaffinity(0)), 'threads', os.cpu_count())
