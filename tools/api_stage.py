@@ -1,5 +1,5 @@
 """Public-API call latency percentiles on the bench workload and the share of the host gather:
-python tools/api_stage.py   (EMPHASES_COPY_STREAM=0 / EMPHASES_COPY_SPREAD=0 switch the gather measures off)"""
+python tools/api_stage.py   (EMPHASES_COPY_STREAM=0: plain memcpy in the gather; CALLS=n)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -29,12 +29,15 @@ def stage(self, *a, **k):
 session._Lane.stage = stage
 spent['gather'] = 0; spent['n'] = 0
 laps = []
-for _ in range(40):
+CALLS = int(os.environ.get('CALLS', 40))
+for _ in range(CALLS):
     time.sleep(0.002)
     t = time.perf_counter()
     emphases_amd.from_alignments_and_audios(alignments, floats, 16000)
     laps.append(time.perf_counter() - t)
 laps = np.sort(laps) * 1e3
-print('call p10 %.3f p50 %.3f p90 %.3f max %.3f mean %.3f ms; mean stage %.3f gather %.3f' % (
-    laps[4], laps[20], laps[36], laps[-1], laps.mean(), st['stage'] / 40 * 1e3, spent['gather'] / 40 * 1e3))
+n = len(laps)
+print('call p10 %.3f p50 %.3f p90 %.3f p99 %.3f max %.3f mean %.3f ms; mean stage %.3f gather %.3f' % (
+    laps[n // 10], laps[n // 2], laps[n * 9 // 10], laps[n * 99 // 100], laps[-1], laps.mean(),
+    st['stage'] / n * 1e3, spent['gather'] / n * 1e3))
 print('cpu affinity', len(os.sched_getaffinity(0)), 'threads', os.cpu_count())
