@@ -34,29 +34,40 @@ __device__ __forceinline__ float rows_sum4(float x) {
 }
 
 // grid = workgroups of 8 waves over the tile table; MB = channels / 16.
-// LDS: three weight packs [4 MB steps][MB][64] + 8 vectors of `channels`.
-template <int MB, int NB>
+// LDS: three weight packs [4 MB steps][MB][64] + 7 vectors of `channels`.
+//
+// QKV: the NEXT layer's Q, K, V projections (in_proj of nn.MultiheadAttention) in
+// the same launch - the layer's output is in the accumulator layout, i.e. already
+// the B fragments of a GEMM whose weights are packed in chain order, so the
+// three projections read it from the registers it was normalised in instead of
+// from memory in a launch of their own.  LDS then holds six packs and ten vectors
+// (156.8 KB for 80 channels).
+template <int MB, int NB, bool QKV>
 __global__ __launch_bounds__(512) void transformer_block_kernel(
     const float* __restrict__ attended, float* __restrict__ x, int64_t ld,
-    const float* __restrict__ packs /* out | linear1 | linear2 */,
-    const float* __restrict__ vectors /* b_o g1 be1 b_1 b_2 g2 be2 */, float eps, int act,
-    const int32_t* __restrict__ tiles, int n_tiles) {
+    const float* __restrict__ packs /* out | linear1 | linear2 [| q | k | v] */,
+    const float* __restrict__ vectors /* b_o g1 be1 b_1 b_2 g2 be2 [b_q b_k b_v] */, float eps,
+    int act, const int32_t* __restrict__ tiles, int n_tiles, float* __restrict__ qk,
+    float* __restrict__ v_out) {
     constexpr int C = 16 * MB;
     constexpr int STEPS = 4 * MB;                 // k-steps of one GEMM
     constexpr int PACK = STEPS * MB * 64;         // floats per pack
+    constexpr int PACKS = QKV ? 6 : 3;
+    constexpr int VECTORS = QKV ? 10 : 7;
     extern __shared__ __align__(16) float lds[];
-    float* vec = lds + 3 * PACK;                  // [7][C]
+    float* vec = lds + PACKS * PACK;              // [VECTORS][C]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kk = lane >> 4;
     const int col = lane & 15;
 
-    // stage the three packs by LDS-DMA and the vectors by plain loads
-    for (int base = wave * 64; base < 3 * PACK / 4; base += 512)
+    // stage the packs by LDS-DMA and the vectors by plain loads
+    for (int base = wave * 64; base < PACKS * PACK / 4; base += 512)
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(packs + 4 * (base + lane)),
             (__attribute__((address_space(3))) void*)(lds + 4 * base), 16, 0, 0);
-    for (int index = threadIdx.x; index < 7 * C; index += 512) vec[index] = vectors[index];
+    for (int index = threadIdx.x; index < VECTORS * C; index += 512)
+        vec[index] = vectors[index];
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
@@ -74,12 +85,14 @@ __global__ __launch_bounds__(512) void transformer_block_kernel(
         // row pointers are wave-uniform (scalar registers); a lane adds one
         // 32-bit offset: its k row (4 kk rows down) and its position
         bool live[NB];
+        int64_t column_of[NB];
         uint32_t lane_offset[NB];      // accumulator layout: row 4 kk (+ 16 m + r)
         uint32_t operand_offset[NB];   // B-fragment layout: row kk (+ 4 g)
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
             live[n] = t0 + 16 * n + col < span.count;
             const int64_t column = span.offset + min(t0 + 16 * n + col, span.count - 1);
+            column_of[n] = column;
             lane_offset[n] = static_cast<uint32_t>(4 * kk * ld + column);
             operand_offset[n] = static_cast<uint32_t>(kk * ld + column);
         }
@@ -200,6 +213,37 @@ __global__ __launch_bounds__(512) void transformer_block_kernel(
                 for (int r = 0; r < 4; ++r)
                     if (live[n])
                         (x + static_cast<int64_t>(16 * m + r) * ld)[lane_offset[n]] = z[m][n][r];
+        if constexpr (QKV) {
+            // the next layer's Q | K (channel-major) and V (position-major)
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                f32x4 acc[MB][NB];
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const f32x4 add = *reinterpret_cast<const f32x4*>(
+                        vec + (7 + part) * C + 16 * m + 4 * kk);
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) acc[m][n] = add;
+                }
+                gemm(lds + (3 + part) * PACK, acc,
+                     [&](int s, int n) { return z[s >> 2][n][s & 3]; });
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) {
+                        if (!live[n]) continue;
+                        if (part < 2) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                (qk + static_cast<int64_t>(part * C + 16 * m + r) *
+                                          ld)[lane_offset[n]] = acc[m][n][r];
+                        } else {
+                            *reinterpret_cast<f32x4*>(v_out + column_of[n] * C + 16 * m +
+                                                      4 * kk) = acc[m][n];
+                        }
+                    }
+            }
+        }
     }
 }
 
@@ -333,11 +377,12 @@ int emph_linear_chain_pack(const float* host_weight, int32_t channels, int32_t n
     return EMPH_OK;
 }
 
-int emph_transformer_block(const float* attended, float* x, int64_t ld, int32_t channels,
-                           const float* packs, const float* vectors, float eps,
-                           int32_t activation, const int32_t* tiles, int32_t n_tiles,
-                           int32_t tile_n, void* stream) {
+static int launch_block(const float* attended, float* x, int64_t ld, int32_t channels,
+                        const float* packs, const float* vectors, float eps,
+                        int32_t activation, const int32_t* tiles, int32_t n_tiles,
+                        int32_t tile_n, float* qk, float* v, void* stream) {
     if (n_tiles == 0) return EMPH_OK;
+    const bool qkv = qk != nullptr;
     EMPH_REQUIRE(attended && x && packs && vectors && tiles, EMPH_EINVAL,
                  "emph_transformer_block: null pointer");
     EMPH_REQUIRE(channels == 64 || channels == 80, EMPH_ERANGE,
@@ -350,20 +395,26 @@ int emph_transformer_block(const float* attended, float* x, int64_t ld, int32_t 
                  static_cast<long long>(ld));
     EMPH_REQUIRE(activation == EMPH_ACT_RELU || activation == EMPH_ACT_NONE, EMPH_ERANGE,
                  "emph_transformer_block: activation %d (ReLU or none)", activation);
-    const size_t lds = (3 * static_cast<size_t>(channels) * channels + 7 * channels) *
-                       sizeof(float);
+    const size_t lds = ((qkv ? 6 : 3) * static_cast<size_t>(channels) * channels +
+                        (qkv ? 10 : 7) * channels) * sizeof(float);
+    EMPH_REQUIRE(lds <= 160 * 1024, EMPH_ERANGE, "emph_transformer_block: %zu bytes of LDS", lds);
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int groups = (n_tiles + 7) / 8;
     dim3 grid(groups < 256 ? groups : 256);
-#define EMPH_BLOCK(MB, NB)                                                              \
-    do {                                                                                \
-        auto kernel = transformer_block_kernel<MB, NB>;                                 \
+#define EMPH_BLOCK_LAUNCH(MB, NB, QKV)                                                         \
+    do {                                                                                       \
+        auto kernel = transformer_block_kernel<MB, NB, QKV>;                                   \
         static LdsReservation reserved;                                                        \
         if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,     \
                                      "emph_transformer_block"))                                \
             return status;                                                                     \
-        EMPH_LAUNCH(kernel, grid, dim3(512), lds, s, attended, x, ld, packs,     \
-                           vectors, eps, activation, tiles, n_tiles);                   \
+        EMPH_LAUNCH(kernel, grid, dim3(512), lds, s, attended, x, ld, packs, vectors, eps,     \
+                    activation, tiles, n_tiles, qk, v);                                        \
+    } while (0)
+#define EMPH_BLOCK(MB, NB)                                                                     \
+    do {                                                                                       \
+        if (qkv) EMPH_BLOCK_LAUNCH(MB, NB, true);                                              \
+        else EMPH_BLOCK_LAUNCH(MB, NB, false);                                                 \
     } while (0)
     if (channels == 80) {
         if (tile_n == 32) EMPH_BLOCK(5, 2); else EMPH_BLOCK(5, 1);
@@ -371,7 +422,27 @@ int emph_transformer_block(const float* attended, float* x, int64_t ld, int32_t 
         if (tile_n == 32) EMPH_BLOCK(4, 2); else EMPH_BLOCK(4, 1);
     }
 #undef EMPH_BLOCK
+#undef EMPH_BLOCK_LAUNCH
     return check_launch("emph_transformer_block");
+}
+
+int emph_transformer_block(const float* attended, float* x, int64_t ld, int32_t channels,
+                           const float* packs, const float* vectors, float eps,
+                           int32_t activation, const int32_t* tiles, int32_t n_tiles,
+                           int32_t tile_n, void* stream) {
+    return launch_block(attended, x, ld, channels, packs, vectors, eps, activation, tiles,
+                        n_tiles, tile_n, nullptr, nullptr, stream);
+}
+
+int emph_transformer_block_qkv(const float* attended, float* x, int64_t ld, int32_t channels,
+                               const float* packs, const float* vectors, float eps,
+                               int32_t activation, const int32_t* tiles, int32_t n_tiles,
+                               int32_t tile_n, float* qk, float* v, void* stream) {
+    EMPH_REQUIRE(qk && v, EMPH_EINVAL, "emph_transformer_block_qkv: null output");
+    EMPH_REQUIRE((reinterpret_cast<uintptr_t>(v) & 15) == 0, EMPH_EINVAL,
+                 "emph_transformer_block_qkv: v must be 16-byte aligned");
+    return launch_block(attended, x, ld, channels, packs, vectors, eps, activation, tiles,
+                        n_tiles, tile_n, qk, v, stream);
 }
 
 int emph_qkv_projection(const float* x, int64_t ld, float* qk, float* v, int32_t channels,

@@ -15,6 +15,7 @@ keeps its model on function attributes of `infer` (`core.py:298-315`); here the
 cache is an explicit object.
 """
 import contextlib
+import os
 import ctypes
 import threading
 
@@ -162,6 +163,8 @@ class Engine:
         # is one its register epilogue handles
         frame_layers = [self.input_layer] + (
             self.frame_encoder if config.architecture == 'convolution' else [])
+        # EMPHASES_FUSE_QKV=0: the block and the next layer's projections as two launches
+        self.fuse_qkv = os.environ.get('EMPHASES_FUSE_QKV', '1') != '0'
         self.quad = winograd and config.activation in (None, 'relu') and \
             all(layer.winograd4 is not None for layer in frame_layers)
         self.model = self._conv_model()
@@ -275,6 +278,24 @@ class Engine:
                        to(state[p + 'norm1.bias'])),
                 norm2=(to(state[p + 'norm2.weight']),
                        to(state[p + 'norm2.bias']))))
+        # layer i's block with layer i + 1's Q / K / V projections behind it in
+        # one launch (six packs and ten vectors must fit in LDS: 80 channels do)
+        for i in range(config.layers - 1):
+            p = f'{prefix}.model.layers.{i + 1}.'
+            block = layers[i]['block']
+            layers[i]['block_qkv'] = None
+            if block is None or layers[i + 1]['qkv'] is None or \
+                    (6 * channels * channels + 10 * channels) * 4 > 160 * 1024:
+                continue
+            in_w = state[p + 'self_attn.in_proj_weight']
+            in_b = state[p + 'self_attn.in_proj_bias']
+            layers[i]['block_qkv'] = (
+                torch.cat([block[0]] + [to(runtime.linear_chain_pack(
+                    in_w[part * channels:(part + 1) * channels], False))
+                    for part in range(3)]),
+                torch.cat([block[1], to(in_b.astype(np.float32))]))
+        if layers:
+            layers[-1]['block_qkv'] = None
         return layers
 
     ###########################################################################
@@ -581,8 +602,11 @@ class Engine:
                     config.layer_norm_eps, 0, ld, runtime.stream()),
                     'emph_add_layernorm')
 
+        projected_ahead = False     # this layer's Q, K, V came out of the last block
         for layer in layers:
-            if layer['qkv'] is not None and block <= 32:
+            if projected_ahead:
+                pass
+            elif layer['qkv'] is not None and block <= 32:
                 packs, bias = layer['qkv']
                 tiles, size = meta[('tiles', axis, block)]
                 with self._timed(f'qkv_projection_{tag}', 6. * channels * channels *
@@ -597,6 +621,7 @@ class Engine:
                            None)
                 self._conv(layer['v'], x, ld, v, channels, meta, axis, block,
                            None, transpose_out=True)
+            projected_ahead = False
             with self._timed(f'attention_{tag}', attention_flops):
                 runtime.check(self.lib.emph_attention(
                     qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld,
@@ -606,6 +631,21 @@ class Engine:
                     ATTENTION_GROUP if grouped else ATTENTION_BLOCK,
                     None if key_counts is None else key_counts.data_ptr(),
                     runtime.stream()), 'emph_attention')
+            if layer['block_qkv'] is not None and block <= 32 and self.fuse_qkv:
+                # (attention has consumed qk / v: the next layer's go there)
+                packs, vectors = layer['block_qkv']
+                tiles, size = meta[('tiles', axis, block)]
+                with self._timed(f'transformer_block_qkv_{tag}', 12. * channels *
+                                 channels * meta['positions'][axis]):
+                    runtime.check(self.lib.emph_transformer_block_qkv(
+                        attended.data_ptr(), x.data_ptr(), ld, channels,
+                        packs.data_ptr(), vectors.data_ptr(),
+                        config.layer_norm_eps, runtime.ACTIVATIONS['relu'],
+                        tiles.data_ptr(), size // runtime.TILE_FIELDS, block,
+                        qk.data_ptr(), v.data_ptr(), runtime.stream()),
+                        'emph_transformer_block_qkv')
+                projected_ahead = True
+                continue
             if layer['block'] is not None and block <= 32:
                 packs, vectors = layer['block']
                 tiles, size = meta[('tiles', axis, block)]

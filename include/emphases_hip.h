@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 20
+#define EMPH_ABI_VERSION 21
 
 /* Segment-table fields */
 enum {
@@ -453,6 +453,19 @@ int emph_transformer_block(const float* attended, float* x, int64_t ld,
                            const float* vectors, float eps, int32_t activation,
                            const int32_t* tiles, int32_t n_tiles,
                            int32_t tile_n, void* stream);
+
+/* ... and the NEXT layer's Q, K, V projections in the same launch (the layer's
+ * output is still in registers, already in the operand layout of a chain-packed
+ * GEMM: no second pass over x, one launch less per layer).  `packs` = out |
+ * linear1 | linear2 | W_q | W_k | W_v, the last three emph_linear_chain_pack(
+ * natural = 0) images of the next layer's in_proj; `vectors` float32 [10][channels]:
+ * the seven above, then b_q, b_k, b_v; qk / v as emph_qkv_projection writes them. */
+int emph_transformer_block_qkv(const float* attended, float* x, int64_t ld,
+                               int32_t channels, const float* packs,
+                               const float* vectors, float eps,
+                               int32_t activation, const int32_t* tiles,
+                               int32_t n_tiles, int32_t tile_n, float* qk,
+                               float* v, void* stream);
 
 /* Q, K, V projections of self-attention in one launch (in_proj of
  * nn.MultiheadAttention, transformer.py:18-23) in the layouts emph_attention

@@ -586,6 +586,71 @@ def test_transformer_block(channels, tile):
     assert torch.isnan(got[:, :batch.LEAD]).all()   # padding untouched
 
 
+@pytest.mark.parametrize('channels,tile', [(80, 32), (80, 16), (64, 32)])
+def test_transformer_block_qkv(channels, tile):
+    """The position-wise half of an encoder layer AND the next layer's Q, K, V
+    projections in one launch: x as emph_transformer_block leaves it (bit for
+    bit - the same instructions), Q | K | V of that x as torch computes them."""
+    lib = runtime.library()
+    plan = ragged_plan([200, 1, 17, 33, 64, 31])
+    axis = runtime.AXIS_FRAMES
+    meta = Meta(plan, [(axis, tile)])
+    x = random_packed(channels, plan, axis, 23)
+    attended = random_packed(channels, plan, axis, 24)
+    names = ['out', 'l1', 'l2']
+    weight = {n: torch.from_numpy(synth.weights(50 + i, (channels, channels), 0.3))
+              for i, n in enumerate(names)}
+    vector = {n: torch.from_numpy(synth.weights(60 + i, (channels,), 0.5))
+              for i, n in enumerate(
+                  ['b_o', 'g1', 'be1', 'b_1', 'b_2', 'g2', 'be2'])}
+    vector['g1'] += 1.
+    vector['g2'] += 1.
+    in_w = torch.from_numpy(synth.weights(70, (3 * channels, channels), 0.3))
+    in_b = torch.from_numpy(synth.weights(71, (3 * channels,), 0.5))
+    block_packs = np.concatenate([
+        runtime.linear_chain_pack(weight['out'].numpy(), True),
+        runtime.linear_chain_pack(weight['l1'].numpy(), False),
+        runtime.linear_chain_pack(weight['l2'].numpy(), False)])
+    packs = torch.from_numpy(np.concatenate([block_packs] + [
+        runtime.linear_chain_pack(
+            in_w[part * channels:(part + 1) * channels].numpy(), False)
+        for part in range(3)])).to(DEVICE)
+    seven = torch.cat([vector[n] for n in (
+        'b_o', 'g1', 'be1', 'b_1', 'b_2', 'g2', 'be2')])
+    vectors = torch.cat([seven, in_b]).to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    attended_dev = attended.to(DEVICE)
+    x_dev = x.to(DEVICE)
+    qk = torch.full((2 * channels, plan.ld_frames), 7.0, device=DEVICE)
+    v = torch.full((plan.ld_frames, channels), 7.0, device=DEVICE)
+    runtime.check(lib.emph_transformer_block_qkv(
+        attended_dev.data_ptr(), x_dev.data_ptr(), plan.ld_frames, channels,
+        packs.data_ptr(), vectors.data_ptr(), 1e-5, 1, tiles.data_ptr(),
+        size // 4, tile, qk.data_ptr(), v.data_ptr(), None),
+        'emph_transformer_block_qkv')
+    plain = x.to(DEVICE)
+    plain_packs = torch.from_numpy(block_packs).to(DEVICE)
+    plain_vectors = seven.to(DEVICE)
+    runtime.check(lib.emph_transformer_block(
+        attended_dev.data_ptr(), plain.data_ptr(), plan.ld_frames, channels,
+        plain_packs.data_ptr(), plain_vectors.data_ptr(), 1e-5, 1,
+        tiles.data_ptr(), size // 4, tile, None), 'emph_transformer_block')
+    got, plain, qk, v = x_dev.cpu(), plain.cpu(), qk.cpu(), v.cpu()
+    for off, count in spans(plan, axis):
+        assert torch.equal(got[:, off:off + count], plain[:, off:off + count])
+        want = in_w @ got[:, off:off + count] + in_b[:, None]
+        assert float((qk[:, off:off + count] -
+                      want[:2 * channels]).abs().max()) < 2e-5
+        assert float((v[off:off + count].T -
+                      want[2 * channels:]).abs().max()) < 2e-5
+    assert float(qk[:, :batch.LEAD].min()) == 7.0
+    assert float(v[:batch.LEAD].min()) == 7.0
+    assert lib.emph_transformer_block_qkv(
+        attended_dev.data_ptr(), x_dev.data_ptr(), plan.ld_frames, channels,
+        packs.data_ptr(), vectors.data_ptr(), 1e-5, 1, tiles.data_ptr(),
+        size // 4, tile, None, None, None) == -1
+
+
 @pytest.mark.parametrize('channels,tile', [(80, 32), (64, 16)])
 def test_qkv_projection(channels, tile):
     lib = runtime.library()
