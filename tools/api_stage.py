@@ -29,12 +29,21 @@ def stage(self, *a, **k):
 session._Lane.stage = stage
 spent['gather'] = 0; spent['n'] = 0
 laps = []
+records = []
 CALLS = int(os.environ.get('CALLS', 40))
-for _ in range(CALLS):
-    time.sleep(0.002)
+PAUSE = float(os.environ.get('PAUSE', 0.002))
+for index in range(CALLS):
+    if PAUSE:
+        time.sleep(PAUSE)
+    before = (st['stage'], spent['gather'])
     t = time.perf_counter()
     emphases_amd.from_alignments_and_audios(alignments, floats, 16000)
     laps.append(time.perf_counter() - t)
+    records.append((index, laps[-1], st['stage'] - before[0], spent['gather'] - before[1]))
+for index, lap, stage_time, gather_time in records:
+    if lap > 4e-3:
+        print('  slow call %d: %.2f ms (stage %.2f, gather %.2f)' % (
+            index, lap * 1e3, stage_time * 1e3, gather_time * 1e3))
 laps = np.sort(laps) * 1e3
 n = len(laps)
 print('call p10 %.3f p50 %.3f p90 %.3f p99 %.3f max %.3f mean %.3f ms; mean stage %.3f gather %.3f' % (
