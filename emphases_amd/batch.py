@@ -304,6 +304,10 @@ class Plan:
         if key not in self._tiles:
             if axis == runtime.AXIS_FRAMES:
                 self._tiles[key] = _tiles(self.frames, self.frame_off, block)
+            elif axis == runtime.AXIS_DECODER:
+                # `block` = (layers, kernel_size, out_kernel_size) of the decoder
+                self._tiles[key] = runtime.word_decoder_tiles(
+                    self.words, self.word_off, *block)
             else:
                 self._tiles[key] = _tiles(self.words, self.word_off, block)
         return self._tiles[key]

@@ -91,14 +91,27 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
     const int col = lane & 15;
 
     const Tile span = load_tile(tiles, blockIdx.x);
-    const bool single = span.count <= kWindow;        // whole segment, no halo
+    // A segment of 33 .. 2 (32 - halo) words is TWO tiles in the table
+    // (emph_word_decoder_tiles: first = 0 and ceil(count / 2)), each a 32-position
+    // window at one end of the segment that computes its half of the words with
+    // the other half's nearest `halo` words as halo: two workgroups of two
+    // 16-column tiles instead of one workgroup of four (a 10 s utterance has
+    // 24-36 words: the ones past 32 used to set the kernel's time, 41 vs 32 us).
+    const int reach = 32 - halo;                       // outputs next to ONE halo
+    const bool halves = span.count > 32 && span.count <= 2 * reach;
+    const bool second = halves && span.first != 0;
+    const bool single = span.count <= kWindow && !halves;   // whole segment, no halo
     if (single && span.first != 0) return;            // covered by the first tile
-    const int first_out = span.first;
-    const int last_out = single ? span.count : min(span.first + block, span.count);
-    const int start = single ? 0 : span.first - halo; // word index of window col 0
-    // a segment of at most 32 words needs only two of the four 16-column tiles:
+    const int half = (span.count + 1) >> 1;
+    const int first_out = halves ? (second ? half : 0) : span.first;
+    const int last_out = halves   ? (second ? span.count : half)
+                         : single ? span.count
+                                  : min(span.first + block, span.count);
+    // word index of window column 0
+    const int start = halves ? (second ? span.count - 32 : 0) : single ? 0 : span.first - halo;
+    // a window of at most 32 positions needs only two of the four 16-column tiles:
     // every wave then owns ONE of them and the per-layer MFMA work halves
-    const bool narrow = single && span.count <= 32;
+    const bool narrow = halves || (single && span.count <= 32);
 
     // Weight stream: the decoder's packs (emph_word_decoder_pack), layer after
     // layer, cut into chunks of chunk_trips trips (a trip = four 4-row groups of
@@ -392,6 +405,43 @@ int32_t emph_word_decoder_block(int32_t layers, int32_t kernel_size,
                                 int32_t out_kernel_size) {
     const int halo = layers * ((kernel_size - 1) / 2) + (out_kernel_size - 1) / 2;
     return kWindow - 2 * halo;
+}
+
+// The decoder's tile table (host): int32 [n][4] = (segment, first word, segment's
+// first column, segment's words).  A segment of at most 32 words, or of 2 (32 -
+// halo) + 1 .. 64, is one tile; 33 .. 2 (32 - halo) words are two (first = 0 and
+// ceil(count / 2)); longer segments one tile per `block` words.  Returns the number
+// of tiles (host_tiles may be NULL to count them).
+int32_t emph_word_decoder_tiles(const int64_t* host_counts, const int64_t* host_offsets,
+                                int32_t segments, int32_t layers, int32_t kernel_size,
+                                int32_t out_kernel_size, int32_t* host_tiles) {
+    const int block = emph_word_decoder_block(layers, kernel_size, out_kernel_size);
+    if (host_counts == nullptr || host_offsets == nullptr || block < 16) return -1;
+    const int halo = (kWindow - block) / 2;
+    int32_t total = 0;
+    auto emit = [&](int segment, int64_t first) {
+        if (host_tiles != nullptr) {
+            int32_t* row = host_tiles + 4 * static_cast<int64_t>(total);
+            row[0] = segment;
+            row[1] = static_cast<int32_t>(first);
+            row[2] = static_cast<int32_t>(host_offsets[segment]);
+            row[3] = static_cast<int32_t>(host_counts[segment]);
+        }
+        ++total;
+    };
+    for (int segment = 0; segment < segments; ++segment) {
+        const int64_t count = host_counts[segment];
+        if (count <= 0) continue;
+        if (count > 32 && count <= 2 * (32 - halo)) {
+            emit(segment, 0);
+            emit(segment, (count + 1) / 2);
+        } else if (count <= kWindow) {
+            emit(segment, 0);
+        } else {
+            for (int64_t first = 0; first < count; first += block) emit(segment, first);
+        }
+    }
+    return total;
 }
 
 int emph_word_decoder(const float* x, int64_t ldx, const int32_t* tiles,

@@ -140,6 +140,10 @@ class Engine:
             self.word_block = int(self.lib.emph_word_decoder_block(
                 self.decoder_layers, config.decoder_kernel_size,
                 config.decoder_kernel_size))
+            # the tile request of the fused word stage (emph_word_decoder_tiles)
+            self.decoder_tiles = (runtime.AXIS_DECODER, (
+                self.decoder_layers, config.decoder_kernel_size,
+                config.decoder_kernel_size))
         if config.architecture == 'transformer':
             self.position = to(weights_module.positional_encoding(
                 cfg.MAX_POSITIONS, config.channels))
@@ -358,7 +362,8 @@ class Engine:
         requests = [
             (runtime.AXIS_FRAMES, FRONTEND_BLOCK),
             (runtime.AXIS_FRAMES, tile),
-            (runtime.AXIS_WORDS, self.word_block)]
+            self.decoder_tiles if self.fused_words
+            else (runtime.AXIS_WORDS, self.word_block)]
         if self.config.architecture == 'transformer':
             # (the fused projection / block kernels own 32 positions per wave,
             # whatever tile the input layer's conv kernel takes)
@@ -729,7 +734,7 @@ class Engine:
             frontend_tiles, frontend_size = meta[
                 ('tiles', frames, FRONTEND_BLOCK)]
             frame_tiles, frame_size = meta[('tiles', frames, block)]
-            word_tiles, word_size = meta[('tiles', words, self.word_block)]
+            word_tiles, word_size = meta[('tiles',) + self.decoder_tiles]
             runtime.check(self.lib.emph_prominence_forward(
                 ctypes.byref(self.model), audio.data_ptr(),
                 audio_format(audio), meta['table'][0].data_ptr(),
@@ -810,7 +815,7 @@ class Engine:
         if stages is not None:
             stages['downsampled'] = wa.clone()
         if self.fused_words:
-            tiles, size = meta[('tiles', words, self.word_block)]
+            tiles, size = meta[('tiles',) + self.decoder_tiles]
             with self._timed('word_decoder', 2. * channels * (
                     channels * config.decoder_kernel_size * self.decoder_layers
                     + config.decoder_kernel_size) * plan.total_words):

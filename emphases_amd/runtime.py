@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -21,6 +21,10 @@ TILE_FIELDS = 4
 (SEG_AUDIO_OFF, SEG_AUDIO_LEN, SEG_START, SEG_LENGTH, SEG_FRAME_OFF,
  SEG_FRAMES, SEG_WORD_OFF, SEG_WORDS) = range(8)
 AXIS_FRAMES, AXIS_WORDS = 0, 1
+# pseudo-axis of tile requests: the word axis cut the way emph_word_decoder wants
+# it (emph_word_decoder_tiles); the 'block' of such a request is (layers,
+# kernel_size, out_kernel_size)
+AXIS_DECODER = 2
 ACTIVATIONS = {None: 0, 'none': 0, 'relu': 1, 'gelu': 2, 'silu': 3,
                'leaky_relu': 4}
 REDUCTIONS = {'sum': 0, 'average': 1, 'max': 2, 'center': 3}
@@ -92,6 +96,7 @@ SIGNATURES = {
     'emph_gather_columns': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _i32, _ptr, _i32, _ptr]),
     'emph_word_decoder_block': (_i32, [_i32, _i32, _i32]),
+    'emph_word_decoder_tiles': (_i32, [_ptr, _ptr, _i32, _i32, _i32, _i32, _ptr]),
     'emph_word_decoder_pack_size': (_i64, [_i32, _i32]),
     'emph_word_decoder_pack': (_c.c_int, [_ptr, _i32, _i32, _ptr]),
     'emph_word_decoder': (_c.c_int, [
@@ -205,6 +210,23 @@ def linear_chain_pack(weight, natural):
         weight.ctypes.data, channels, int(natural), pack.ctypes.data),
         'emph_linear_chain_pack')
     return pack
+
+
+def word_decoder_tiles(counts, offsets, layers, kernel_size, out_kernel_size):
+    """Tile table int32 [n, 4] of emph_word_decoder for segments of `counts`
+    words whose first columns are `offsets`."""
+    lib = library()
+    counts = np.ascontiguousarray(counts, dtype=np.int64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    arguments = (counts.ctypes.data, offsets.ctypes.data, len(counts),
+                 int(layers), int(kernel_size), int(out_kernel_size))
+    total = lib.emph_word_decoder_tiles(*arguments, None)
+    if total < 0:
+        raise ValueError('emph_word_decoder_tiles: bad decoder shape')
+    tiles = np.zeros((total, TILE_FIELDS), dtype=np.int32)
+    if total:
+        lib.emph_word_decoder_tiles(*arguments, tiles.ctypes.data)
+    return tiles
 
 
 def word_transformer_pack(state, prefix, channels, heads):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 21
+#define EMPH_ABI_VERSION 22
 
 /* Segment-table fields */
 enum {
@@ -344,10 +344,25 @@ int emph_gather_columns(const float* x, int64_t ldx, float* y, int64_t ldy,
 
 /* Output words per workgroup of emph_word_decoder for a decoder of `layers`
  * convolutions of `kernel_size` followed by an output convolution of
- * `out_kernel_size`: 64 minus the receptive-field halo on both sides.  The
- * word-axis tile table handed to emph_word_decoder must use this block. */
+ * `out_kernel_size`: 64 minus the receptive-field halo on both sides (what a
+ * workgroup computes of a segment longer than 64 words). */
 int32_t emph_word_decoder_block(int32_t layers, int32_t kernel_size,
                                 int32_t out_kernel_size);
+
+/* The word-axis tile table emph_word_decoder takes (HOST arrays in, host table
+ * out): rows (segment, first word, segment's first column, segment's words).
+ * A segment of at most 32 words is one tile (a workgroup then computes two
+ * 16-word MFMA tiles per layer instead of four); 33 .. 2 (32 - halo) words are
+ * TWO tiles, first = 0 and ceil(words / 2), each a 32-position window at one end
+ * of the segment with the other half's nearest words as halo; up to 64 words one
+ * tile; longer segments one tile per emph_word_decoder_block words.
+ *   host_counts, host_offsets  int64 [segments]  words and first column per segment
+ *   host_tiles                 int32 [n][4] or NULL (count only)
+ * Returns the number of tiles, or -1 for bad arguments. */
+int32_t emph_word_decoder_tiles(const int64_t* host_counts,
+                                const int64_t* host_offsets, int32_t segments,
+                                int32_t layers, int32_t kernel_size,
+                                int32_t out_kernel_size, int32_t* host_tiles);
 
 /* Host-side repack of one decoder layer's Conv1d weight [channels][channels]
  * [kernel_size] for emph_word_decoder: channels^2 * kernel_size floats, ordered
@@ -368,8 +383,8 @@ int emph_word_decoder_pack(const float* host_weight, int32_t channels,
  *
  *   x           float32 [channels, ldx]  word embeddings (word axis), e.g. the
  *                                        output of emph_segment_reduce
- *   tiles       int32 [n_tiles][4]       word-axis tile table, block =
- *                                        emph_word_decoder_block(...)
+ *   tiles       int32 [n_tiles][4]       the table of emph_word_decoder_tiles
+ *                                        (device copy)
  *   packs       float32                  emph_word_decoder_pack of every
  *                                        decoder layer, back to back
  *   biases      float32 [layers][channels]
@@ -590,8 +605,8 @@ int64_t emph_prominence_workspace_floats(int32_t features, int32_t channels,
  * core.py:89-138) of the convolutional configurations with encoder
  * kernel_size 3 and mel features.  The tables are those of the individual
  * entry points: `frontend_tiles` with blocks of emph_frontend_block() frames, `frame_tiles` with
- * block `tile_n` (32 or 64; 64 for conv_variant 1), `word_tiles` with block
- * emph_word_decoder_block(...).  Enqueues on `stream`; allocates nothing. */
+ * block `tile_n` (32 or 64; 64 for conv_variant 1), `word_tiles` from
+ * emph_word_decoder_tiles(...).  Enqueues on `stream`; allocates nothing. */
 int emph_prominence_forward(const emph_conv_model* model, const void* audio,
                             int32_t audio_format, const int64_t* seg,
                             const int32_t* frontend_tiles,

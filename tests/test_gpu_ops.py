@@ -771,12 +771,22 @@ def test_word_decoder(kernel_size, layers, activation, post):
     lib = runtime.library()
     channels = 80
     block = int(lib.emph_word_decoder_block(layers, kernel_size, kernel_size))
-    counts = [block, 1, 2, block + 1, 3 * block + 5, 7, 2 * block]
+    # ... and every length from 31 to 52: at most 32 words are one narrow
+    # window, 33 .. 2 (32 - halo) two of them, longer ones a full 64-word window
+    counts = [block, 1, 2, block + 1, 3 * block + 5, 7, 2 * block, 64, 65] + \
+        list(range(31, 53))
     bounds = [np.stack([np.arange(n), np.arange(n) + 1]).astype(np.int64)
               for n in counts]
     plan = ragged_plan(counts, bounds)
     axis = runtime.AXIS_WORDS
-    meta = Meta(plan, [(axis, block)])
+    request = (runtime.AXIS_DECODER, (layers, kernel_size, kernel_size))
+    meta = Meta(plan, [request])
+    table = plan.tiles(*request)
+    halo = (64 - block) // 2
+    expected = sum(
+        2 if 32 < n <= 2 * (32 - halo) else 1 if n <= 64 else -(-n // block)
+        for n in counts)
+    assert len(table) == expected
     x = random_packed(channels, plan, axis, 81) * 2.0
     valid = np.zeros(plan.ld_words, dtype=bool)
     for off, count in spans(plan, axis):
@@ -795,7 +805,7 @@ def test_word_decoder(kernel_size, layers, activation, post):
         if layers else None
     logits = torch.full((plan.ld_words,), 9.0, device=DEVICE)
     scores = torch.full((plan.ld_words,), 9.0, device=DEVICE)
-    tiles, size = meta.view(('tiles', axis, block))
+    tiles, size = meta.view(('tiles',) + request)
     x_dev = x.to(DEVICE)
     out_w_dev = torch.from_numpy(out_w).to(DEVICE)
     out_b_dev = torch.from_numpy(out_b).to(DEVICE)
