@@ -165,14 +165,29 @@ def test_mel_basis_matches_oracle_bitwise():
     ours = melbasis.filterbank()
     theirs = librosa_mel.mel(sr=16000, n_fft=1024, n_mels=80)
     assert np.array_equal(ours, theirs)
+    plain = melbasis.SparseBasis(ours, aligned=False)
+    assert plain.nnz == plain.values.size == 1001 and plain.read_cycles is None
+    # the packing the front-end takes: every run starts at a 16-byte aligned bin
+    # at or before the row's first non-zero one, zero weights in between, chosen
+    # so that the kernel's LDS reads have no bank conflicts (4 cycles for each of
+    # the 6 + 3 sixteen-byte reads of a frame; 69 with `first & ~3`)
     sparse = melbasis.default()
-    assert sparse.nnz == sparse.values.size == 1001
-    dense = np.zeros_like(ours)
-    for row in range(80):
-        lo, n, off = (sparse.row_start[row], sparse.row_count[row],
-                      sparse.row_offset[row])
-        dense[row, lo:lo + n] = sparse.values[off:off + n]
-    assert np.array_equal(dense, ours)
+    assert sparse.nnz == 1001 and sparse.read_cycles == 36
+    assert (sparse.row_start % 4 == 0).all()
+    assert (sparse.row_start <= plain.row_start).all()
+    assert sparse.row_count[:64].max() <= 24 and sparse.row_count[64:].max() <= 48
+    assert np.array_equal(sparse.row_start + sparse.row_count,
+                          plain.row_start + plain.row_count)
+    starts, cycles = melbasis.conflict_free_starts(
+        plain.row_start, plain.row_count)
+    assert cycles == 36 and np.array_equal(starts, sparse.row_start)
+    for packing in (plain, sparse):
+        dense = np.zeros_like(ours)
+        for row in range(80):
+            lo, n, off = (packing.row_start[row], packing.row_count[row],
+                          packing.row_offset[row])
+            dense[row, lo:lo + n] = packing.values[off:off + n]
+        assert np.array_equal(dense, ours)
 
 
 def test_bundled_checkpoint_is_the_reference_weights():
