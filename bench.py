@@ -10,16 +10,29 @@ scores — over one ragged batch of BASELINE.json's configs[1]: 64 synthetic
 10 s / 16 kHz utterances with random alignments, conv config, bundled
 checkpoint, per GPU (weak scaling: every rank owns its own 64 utterances and
 the only exchange is ONE RCCL all_gather of all steps' per-word scores at the
-end of the timed region).
+end of a timed region).
+
+Protocol.  The chip's clocks ramp for tens of milliseconds, so a pre-roll
+replays the step until three consecutive 50-step blocks agree to 2 % (at least
+0.3 s, at most 3 s); then `--warmup` untimed steps; then `--steps` steps are
+timed `--regions` (9) times, each region bracketed by a barrier +
+`torch.cuda.synchronize()` on both sides (max over ranks), and the MEDIAN
+region is the one reported (`ms_per_step`, `value`), with the fastest and the
+slowest beside it.
 
 Prints ONE JSON line on rank 0 with BASELINE.json's metric (utterances/s,
 whole job), the roofline of the dominant kernel (fp32-MFMA conv1d, measured
-live with HIP events on the launch stream) and the CPU oracle timed on the
-host cores beside it.
+live with HIP events on the launch stream, the committed rocprofv3 average
+beside it), the CPU oracle timed on the host cores (threads AND one process
+per core), and — on one GPU — side records for BASELINE configs[2]
+(Transformer), configs[3] (10 k-utterance corpus) and configs[4] (5-minute
+utterances chunked at batch_size 3000) and the public API end to end.
 """
 import argparse
+import csv
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,7 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import emphases_amd  # noqa: E402
-from emphases_amd import batch, config as cfg, runtime, synth  # noqa: E402
+from emphases_amd import batch, config as cfg, synth  # noqa: E402
 
 UTTERANCES = 64
 FRAMES = 1000                 # 10 s at 100 frames/s
@@ -39,6 +52,14 @@ PEAK_HBM = 8.0e12             # B/s, same guide
 # compulsory traffic and algorithmic flops of the conv path
 BYTES_PER_FRAME = 641.
 FLOPS_PER_FRAME, FLOPS_PER_WORD = 0.2968e6, 0.2309e6
+PROFILE_TAGS = ('r3', 'r2', 'r1')
+# kernel name in `Engine.timers` -> substring of the rocprofv3 kernel name
+ROCPROF_NAMES = {
+    'conv1d_winograd4_frames_80x80_k3': 'conv1d_winograd4_kernel',
+    'attention_frames': 'attention_group_kernel',
+    'frontend_logmel': 'frontend_kernel',
+    'segment_reduce': 'segment_reduce_kernel',
+    'word_decoder': 'word_decoder_kernel'}
 
 
 def parse_args():
@@ -46,12 +67,17 @@ def parse_args():
     parser.add_argument('--gpus', type=int, default=1)
     parser.add_argument('--steps', type=int, default=200)
     parser.add_argument('--warmup', type=int, default=20)
+    parser.add_argument('--regions', type=int, default=9,
+                        help='how often the --steps steps are timed; the '
+                             'median region is reported')
     parser.add_argument('--config', default='conv',
                         choices=['conv', 'transformer'])
     parser.add_argument('--tile', type=int, default=None)
     parser.add_argument('--no-cpu-baseline', action='store_true')
     parser.add_argument('--no-api', action='store_true',
                         help='skip the end-to-end public-API measurement')
+    parser.add_argument('--no-side', action='store_true',
+                        help='skip the side records (configs[2], [3], [4])')
     parser.add_argument('--streams', type=int, default=2,
                         help='batches in flight: consecutive steps alternate '
                              'between this many HIP streams (each with its '
@@ -60,7 +86,7 @@ def parse_args():
                              'the previous one')
     parser.add_argument('--no-winograd', action='store_true',
                         help='direct (3-tap) form of the frame-rate convs '
-                             'instead of Winograd F(2,3)')
+                             'instead of Winograd')
     parser.add_argument('--backend', default='nccl',
                         help="torch.distributed backend ('nccl' = RCCL; "
                              "'gloo' only to rehearse the N > 1 path on a box "
@@ -68,6 +94,9 @@ def parse_args():
     parser.add_argument('--no-graph', action='store_true',
                         help='launch kernel by kernel instead of replaying '
                              'the captured HIP graph')
+    parser.add_argument('--no-preroll', action='store_true')
+    parser.add_argument('--cpu-worker', type=float, default=None,
+                        help=argparse.SUPPRESS)
     return parser.parse_args()
 
 
@@ -91,6 +120,11 @@ def build_plan(audios, alignments):
     return batch.Plan(segments, offsets, lengths)
 
 
+###############################################################################
+# CPU baseline (runs BEFORE this process touches the GPU)
+###############################################################################
+
+
 def cpu_model():
     try:
         with open('/proc/cpuinfo') as file:
@@ -103,65 +137,156 @@ def cpu_model():
 
 
 def physical_cores():
-    """Physical cores of this box (/proc/cpuinfo: distinct (physical id,
-    core id) pairs), falling back to the logical count."""
+    """Physical cores this process may run on: distinct (physical id, core id)
+    pairs of /proc/cpuinfo among the CPUs of the affinity mask."""
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = None
     cores = set()
     try:
-        physical = core = None
+        processor = physical = core = None
         with open('/proc/cpuinfo') as file:
             for line in file:
-                if line.startswith('physical id'):
+                if line.startswith('processor'):
+                    processor = int(line.split(':')[1])
+                elif line.startswith('physical id'):
                     physical = line.split(':')[1].strip()
                 elif line.startswith('core id'):
                     core = line.split(':')[1].strip()
                 elif not line.strip():
-                    if physical is not None and core is not None:
+                    if physical is not None and core is not None and (
+                            allowed is None or processor in allowed):
                         cores.add((physical, core))
-                    physical = core = None
+                    processor = physical = core = None
     except OSError:
         pass
-    return len(cores) or (os.cpu_count() or 1)
+    fallback = len(allowed) if allowed else (os.cpu_count() or 1)
+    return len(cores) or fallback
 
 
-def cpu_baseline(audios, bounds, seconds=5.0):
-    """The CPU oracle (port of the reference's op sequence, B=1 loop exactly
-    like `emphases/core.py:169-179`) on this box's host cores, at 1 thread, at
-    8 threads (what the survey measured the reference itself with) and at all
-    physical cores."""
-    from oracle import prominence as oracle
+def oracle_inputs(count=8):
     from emphases_amd import weights
     state = {k: torch.from_numpy(v) for k, v in weights.load().items()}
-    words = [[(int(s) / 100., int(e) / 100.) for s, e in b.T] for b in bounds]
-    tensors = [torch.from_numpy(a) for a in audios]
+    audios = [torch.from_numpy(synth.audio(i, FRAMES)) for i in range(count)]
+    words = [[(int(s) / 100., int(e) / 100.) for s, e in
+              synth.word_frames(i, FRAMES).T] for i in range(count)]
+    return state, audios, words
+
+
+def cpu_worker(seconds):
+    """One child of the process-parallel baseline: one torch thread, the
+    oracle on its own utterances, B=1, one after the other
+    (`emphases/core.py:169-179`).  Never touches the GPU.  Protocol on
+    stdin/stdout: 'ready' when warm, waits for 'go', prints its count."""
+    torch.set_num_threads(1)
+    from oracle import prominence as oracle
+    state, audios, words = oracle_inputs(4)
+    oracle.from_alignment_and_audio(words[0], audios[0], state)
+    print('ready', flush=True)
+    sys.stdin.readline()
+    done = 0
+    start = time.perf_counter()
+    while time.perf_counter() - start < seconds:
+        index = done % len(audios)
+        oracle.from_alignment_and_audio(words[index], audios[index], state)
+        done += 1
+    print(json.dumps({'done': done, 'seconds': time.perf_counter() - start}),
+          flush=True)
+
+
+def cpu_processes(count, seconds):
+    """`count` fresh single-thread processes running the oracle side by side
+    for `seconds`; utterances/s summed over them."""
+    env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1',
+               HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='',
+               ROCR_VISIBLE_DEVICES='')
+    children = [subprocess.Popen(
+        [sys.executable, os.path.abspath(__file__), '--cpu-worker',
+         str(seconds)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
+        stderr=subprocess.DEVNULL, env=env, text=True, cwd=ROOT)
+        for _ in range(count)]
+    try:
+        for child in children:
+            line = child.stdout.readline()
+            if line.strip() != 'ready':
+                raise RuntimeError(f'cpu worker said {line!r}')
+        start = time.perf_counter()
+        for child in children:
+            child.stdin.write('go\n')
+            child.stdin.flush()
+        results = [json.loads(child.stdout.readline()) for child in children]
+        wall = time.perf_counter() - start
+    finally:
+        for child in children:
+            try:
+                child.stdin.close()
+                child.wait(timeout=30)
+            except Exception:       # noqa: BLE001
+                child.kill()
+    return {
+        'processes': count, 'threads_per_process': 1,
+        'value': sum(r['done'] / r['seconds'] for r in results),
+        'utterances': sum(r['done'] for r in results),
+        'seconds': wall}
+
+
+def cpu_baseline(seconds=4.0):
+    """The CPU oracle (port of the reference's op sequence, B=1 loop exactly
+    like `emphases/core.py:169-179`) on this box's host cores:
+    in this process at 1 and at 8 torch threads (what the survey timed the
+    reference itself with), and as P single-thread PROCESSES for P = 8 and P =
+    all physical cores — the reference's loop is sequential, so a corpus is
+    spread over a host by running it once per core, and that is the number the
+    GPU rate stands next to."""
+    from oracle import prominence as oracle
+    state, audios, words = oracle_inputs()
     physical = physical_cores()
     runs = []
-    for threads in sorted({1, min(8, physical), physical}):
+    for threads in sorted({1, min(8, physical)}):
         torch.set_num_threads(threads)
-        oracle.from_alignment_and_audio(words[0], tensors[0], state)  # warm up
+        oracle.from_alignment_and_audio(words[0], audios[0], state)  # warm up
         done = 0
         start = time.perf_counter()
         while time.perf_counter() - start < seconds:
-            index = done % len(tensors)
+            index = done % len(audios)
             oracle.from_alignment_and_audio(
-                words[index], tensors[index], state)
+                words[index], audios[index], state)
             done += 1
         elapsed = time.perf_counter() - start
-        runs.append({
-            'threads': threads, 'value': done / elapsed,
-            'utterances': done, 'seconds': elapsed})
-    best = max(runs, key=lambda run: run['value'])
+        runs.append({'threads': threads, 'value': done / elapsed,
+                     'utterances': done, 'seconds': elapsed})
+    torch.set_num_threads(min(8, physical))
+    pools = []
+    for count in sorted({min(8, physical), physical}):
+        try:
+            pools.append(cpu_processes(count, seconds))
+        except Exception as error:      # noqa: BLE001
+            pools.append({'processes': count, 'error': repr(error)})
+    best_pool = max((p for p in pools if 'value' in p),
+                    key=lambda p: p['value'], default=None)
+    best_run = max(runs, key=lambda run: run['value'])
+    if best_pool is not None and best_pool['value'] >= best_run['value']:
+        value, cores = best_pool['value'], best_pool['processes']
+        sample = (
+            f"{best_pool['utterances']} x 10 s utterances in "
+            f"{best_pool['seconds']:.1f} s by {cores} single-thread processes "
+            '(one per physical core), each looping oracle/prominence.py one '
+            'utterance at a time (B=1), torch CPU fp32')
+    else:
+        value, cores = best_run['value'], best_run['threads']
+        sample = (
+            f"{best_run['utterances']} x 10 s utterances in "
+            f"{best_run['seconds']:.1f} s at {cores} torch threads, one at a "
+            'time (B=1) through oracle/prominence.py, torch CPU fp32')
     return {
-        'value': best['value'], 'unit': 'utterances/s',
-        'cores': best['threads'], 'kind': 'port',
+        'value': value, 'unit': 'utterances/s', 'cores': cores,
+        'kind': 'port', 'sample': sample,
         'threads': {str(run['threads']): run['value'] for run in runs},
+        'processes': {str(p['processes']): p.get('value', p.get('error'))
+                      for p in pools},
         'physical_cores': physical, 'logical_cores': os.cpu_count(),
         'cpu': cpu_model(),
-        'sample': (
-            f"{best['utterances']} x 10 s utterances in "
-            f"{best['seconds']:.1f} s at {best['threads']} torch threads "
-            f"(the fastest of {[run['threads'] for run in runs]} threads, "
-            f"{seconds:.0f} s each), one at a time (B=1) through "
-            'oracle/prominence.py, torch CPU fp32'),
         # BASELINE.md / SURVEY.md §6: the reference itself (bf16 autocast as
         # shipped), measured in the survey container (8 vCPU Xeon @2.1 GHz)
         'reference_survey': {
@@ -173,14 +298,233 @@ def cpu_baseline(audios, bounds, seconds=5.0):
                      'from_alignment_and_audio as shipped'}}
 
 
-def end_to_end_api(audios, alignments, rounds=40):
+###############################################################################
+# The timed protocol
+###############################################################################
+
+
+class Runner:
+    """`streams` lanes (HIP stream + engine workspace + captured graph) over
+    one resident batch; `step()` enqueues one pass on the next lane."""
+
+    def __init__(self, config, state, device, audios, alignments, streams=2,
+                 tile=None, winograd=True, graph=True):
+        self.device = device
+        self.engine = emphases_amd.engine.Engine(
+            config, state, device, conv_tile=tile, winograd=winograd)
+        self.plan = build_plan(audios, alignments)
+        self.packed = torch.cat(
+            [torch.from_numpy(a).reshape(-1) for a in audios]).to(device)
+        self.meta = self.engine.upload(self.plan)
+        self.columns = torch.from_numpy(self.plan.word_columns()).to(device)
+        self.lanes = []
+        for index in range(max(1, streams)):
+            engine = self.engine if index == 0 else \
+                emphases_amd.engine.Engine(
+                    config, state, device, conv_tile=tile, winograd=winograd)
+            stream = torch.cuda.Stream(device=device) if streams > 1 \
+                else torch.cuda.current_stream()
+            with torch.cuda.stream(stream):
+                if graph:
+                    replay, scores, _ = engine.capture(
+                        self.packed, self.plan, self.meta)
+                else:
+                    replay, scores = None, None
+            self.lanes.append((stream, engine, replay, scores))
+        torch.cuda.synchronize()
+        self.counter = 0
+        self.after = None           # hook(stream, scores, step index)
+
+    def step(self):
+        stream, engine, replay, scores = self.lanes[
+            self.counter % len(self.lanes)]
+        index = self.counter
+        self.counter += 1
+        with torch.cuda.stream(stream):
+            if replay is None:
+                scores = engine.forward(self.packed, self.plan, self.meta)[0]
+            else:
+                replay()
+            if self.after is not None:
+                self.after(scores, index)
+        return scores
+
+    def kernel_times(self, passes=20):
+        """Per-kernel HIP-event durations on the launch stream (eager)."""
+        engine = self.engine
+        engine.timers = []
+        for _ in range(passes):
+            engine.forward(self.packed, self.plan, self.meta)
+        torch.cuda.synchronize()
+        kernels = {}
+        for name, flops, begin, end in engine.timers:
+            entry = kernels.setdefault(name, [0, 0., 0.])
+            entry[0] += 1
+            entry[1] += begin.elapsed_time(end) * 1e-3
+            entry[2] += flops
+        engine.timers = None
+        return kernels, passes
+
+
+def preroll(step, block=50, least=0.3, most=3.0, tolerance=0.02):
+    """Replay until the step time is steady: three consecutive `block`-step
+    means within `tolerance` of each other."""
+    history = []
+    begin = time.perf_counter()
+    while True:
+        start = time.perf_counter()
+        for _ in range(block):
+            step()
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        history.append((now - start) / block)
+        last = history[-3:]
+        steady = len(last) == 3 and max(last) <= min(last) * (1 + tolerance)
+        if (steady and now - begin >= least) or now - begin >= most:
+            return {'seconds': now - begin, 'blocks': len(history),
+                    'steady': bool(steady),
+                    'ms_per_step_first_block': history[0] * 1e3,
+                    'ms_per_step_last_block': history[-1] * 1e3}
+
+
+def timed_regions(runner, steps, warmup, regions, world, exchange=None,
+                  skip_preroll=False):
+    """[seconds] of `regions` timed regions of exactly `steps` steps."""
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    ramp = None if skip_preroll else preroll(runner.step)
+    for _ in range(warmup):
+        runner.step()
+    if exchange is not None:
+        exchange()
+    laps = []
+    for _ in range(max(1, regions)):
+        runner.counter = 0
+        barrier()
+        start = time.perf_counter()
+        for _ in range(steps):
+            scores = runner.step()
+        if exchange is not None:
+            exchange()
+        barrier()
+        elapsed = time.perf_counter() - start
+        if world > 1:
+            slowest = torch.tensor(
+                [elapsed], dtype=torch.float64, device=runner.device)
+            torch.distributed.all_reduce(
+                slowest, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(slowest.item())
+        laps.append(elapsed)
+    return laps, ramp, scores
+
+
+def profile_file(name):
+    for tag in PROFILE_TAGS:
+        path = os.path.join(ROOT, 'profiles', f'{tag}_{name}')
+        if os.path.exists(path):
+            return path
+    return None
+
+
+def from_profiles(config, dominant):
+    """What the committed rocprofv3 runs of this same command say about the
+    dominant kernel (NOT measured in this run; `profiles/README.md`)."""
+    result = {}
+    stats = profile_file('bench_kernel_stats_1stream.csv' if config == 'conv'
+                         else 'transformer_kernel_stats_1stream.csv')
+    pattern = ROCPROF_NAMES.get(dominant)
+    if stats and pattern:
+        with open(stats) as file:
+            for row in csv.DictReader(file):
+                if pattern in row['Name']:
+                    result['rocprof_avg_launch_us'] = \
+                        float(row['AverageNs']) * 1e-3
+                    result['rocprof_calls'] = int(row['Calls'])
+                    result['kernel_stats_file'] = os.path.relpath(stats, ROOT)
+                    break
+    summary = profile_file('pmc_summary.json' if config == 'conv'
+                           else 'transformer_pmc_summary.json')
+    if summary:
+        with open(summary) as file:
+            entry = json.load(file).get(dominant, {})
+        result['traffic'] = entry.get('traffic_bytes')
+        result['traffic_raw'] = entry.get('traffic_bytes_raw')
+        result['algorithmic_bytes'] = entry.get('algorithmic_bytes')
+        result['mfma_pipe_busy'] = entry.get('mfma_pipe_busy')
+        result['pmc_file'] = os.path.relpath(summary, ROOT)
+    return result
+
+
+def roofline(kernels, passes, ms_per_step, config):
+    dominant = max(kernels, key=lambda name: kernels[name][1])
+    launches, seconds, flops = kernels[dominant]
+    achieved = flops / seconds / 1e12
+    committed = from_profiles(config, dominant)
+    executed = .5 if 'winograd4' in dominant else \
+        2. / 3. if 'winograd' in dominant else 1.
+    result = {
+        'bound': 'mfma', 'kernel': dominant,
+        'achieved': achieved, 'peak': PEAK_FP32_MFMA,
+        'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA,
+        'avg_launch_us': seconds / launches * 1e6,
+        'avg_launch_us_is': 'HIP events around each launch on the launch '
+                            'stream, this run (includes the dispatch gap)',
+        'launches_per_step': launches / passes,
+        'share_of_step': seconds / passes / (ms_per_step * 1e-3),
+        'algorithmic_flops_per_launch': flops / launches,
+        # Winograd F(2,3) executes 2/3, F(4,3) 1/2 of the direct form's MFMAs
+        'executed_mfma_flops_per_launch': flops / launches * executed,
+        # HBM bytes per launch by PMC: from the committed profile of this
+        # command (see `from_profiles`), not collected in this run
+        'traffic': committed.get('traffic'),
+        'traffic_source': committed.get('pmc_file')}
+    if committed.get('rocprof_avg_launch_us'):
+        average = committed['rocprof_avg_launch_us']
+        result['rocprof_avg_launch_us'] = average
+        result['frac_at_rocprof_avg'] = \
+            flops / launches / (average * 1e-6) / 1e12 / PEAK_FP32_MFMA
+    return result, committed
+
+
+def summary(laps, steps):
+    laps = sorted(laps)
+    median = laps[len(laps) // 2] if len(laps) % 2 else \
+        0.5 * (laps[len(laps) // 2 - 1] + laps[len(laps) // 2])
+    return {
+        'ms_per_step': median / steps * 1e3,
+        'ms_per_step_min': laps[0] / steps * 1e3,
+        'ms_per_step_max': laps[-1] / steps * 1e3,
+        'timed_region_s': median, 'regions': len(laps)}
+
+
+###############################################################################
+# Side records
+###############################################################################
+
+
+def percentiles(laps):
+    laps = np.asarray(laps) * 1e3
+    return {
+        'ms_per_call': float(np.median(laps)),
+        'ms_per_call_p90': float(np.percentile(laps, 90)),
+        'ms_per_call_p99': float(np.percentile(laps, 99)),
+        'ms_per_call_worst': float(laps.max()),
+        'worst_lap_index': int(laps.argmax()),
+        'ms_per_call_mean': float(laps.mean()), 'laps': int(laps.size)}
+
+
+def end_to_end_api(audios, alignments, rounds=200):
     """SURVEY.md §8(d) protocol (ii): the public batch API on the same 64
     utterances, host tensors in, scores out - chunk planning, staging, H2D,
     kernels, D2H and the split into per-utterance tensors all inside the
     clock.  `call` = one synchronous `from_alignments_and_audios` after the
-    other; `pipelined` = `Session.submit` with two batches in flight (what
-    `from_files_to_files` does).  float32 = the reference's input type
-    (pageable CPU tensors); pcm16 = the same audio as 16-bit PCM tensors."""
+    other (median / p90 / p99 / worst of the laps); `pipelined` =
+    `Session.submit` with two batches in flight (what `from_files_to_files`
+    does).  float32 = the reference's input type (pageable CPU tensors); pcm16
+    = the same audio as 16-bit PCM tensors."""
     floats = [torch.from_numpy(a) for a in audios]
     pcm = [torch.from_numpy(np.rint(a * 32768.).astype(np.int16))
            for a in audios]
@@ -188,7 +532,7 @@ def end_to_end_api(audios, alignments, rounds=40):
     result = {}
     reference = None
     for name, tensors in (('float32', floats), ('pcm16', pcm)):
-        for _ in range(8):          # both lanes: buffers, layout cache, graph
+        for _ in range(16):         # both lanes: buffers, layout cache, graph
             scores = emphases_amd.from_alignments_and_audios(
                 alignments, tensors, 16000)
         torch.cuda.synchronize()
@@ -198,31 +542,30 @@ def end_to_end_api(audios, alignments, rounds=40):
             scores = emphases_amd.from_alignments_and_audios(
                 alignments, tensors, 16000)
             laps.append(time.perf_counter() - start)
-        call = float(np.median(laps))
-        # pipelined: three runs of `rounds` submissions, the median run counts
+        # pipelined: five runs of 40 submissions, the median run counts
         runs = []
-        for _ in range(3):
+        for _ in range(5):
             start = time.perf_counter()
             previous = None
-            for _ in range(rounds):
+            for _ in range(40):
                 pending = session.submit(alignments, tensors, 16000)
                 if previous is not None:
                     previous.result()
                 previous = pending
             scores = previous.result()
-            runs.append((time.perf_counter() - start) / rounds)
+            runs.append((time.perf_counter() - start) / 40)
         piped = float(np.median(runs))
         flat = torch.cat([s.reshape(-1) for s in scores])
         if reference is None:
             reference = flat
-        result[name] = {
-            'ms_per_call': call * 1e3,
-            'ms_per_call_mean': float(np.mean(laps)) * 1e3,
-            'ms_per_call_worst': float(np.max(laps)) * 1e3,
-            'utterances_per_s': len(audios) / call,
+        entry = percentiles(laps)
+        entry.update({
+            'utterances_per_s': len(audios) / entry['ms_per_call'] * 1e3,
             'ms_per_call_pipelined': piped * 1e3,
+            'ms_per_call_pipelined_runs': [run * 1e3 for run in runs],
             'utterances_per_s_pipelined': len(audios) / piped,
-            'bit_identical_to_float32': bool(torch.equal(flat, reference))}
+            'bit_identical_to_float32': bool(torch.equal(flat, reference))})
+        result[name] = entry
     # every call a layout never seen before (what a stream of real utterances
     # looks like: the layout cache and its captured graph never hit)
     fresh = [[emphases_amd.Alignment.from_frames(
@@ -245,22 +588,230 @@ def end_to_end_api(audios, alignments, rounds=40):
         previous = pending
     previous.result()
     piped = (time.perf_counter() - start) / len(fresh[4:])
-    result['float32_new_layout_every_call'] = {
-        'ms_per_call': float(np.median(laps)) * 1e3,
-        'ms_per_call_pipelined': piped * 1e3,
-        'utterances_per_s_pipelined': len(audios) / piped}
-    result['what'] = (
-        'emphases_amd.from_alignments_and_audios on 64 x 10 s host tensors: '
-        'planning + staging + H2D + kernels + D2H; pipelined = 2 batches in '
-        'flight (session.Session); ms_per_call = median of the laps')
+    entry = percentiles(laps)
+    entry.update({'ms_per_call_pipelined': piped * 1e3,
+                  'utterances_per_s_pipelined': len(audios) / piped})
+    result['float32_new_layout_every_call'] = entry
+    result['workload'] = (
+        'emphases_amd.from_alignments_and_audios on 64 x 10 s host tensors '
+        '(BASELINE configs[1] through the public API): planning + staging + '
+        'H2D + kernels + D2H; pipelined = 2 batches in flight '
+        '(session.Session); ms_per_call = median of the laps')
     return result
+
+
+def side_transformer(device, audios, alignments, args):
+    """BASELINE configs[2]: the same 64 x 10 s batch, Transformer config
+    (seeded weights), same protocol as the headline."""
+    config = cfg.Config(architecture='transformer')
+    state = emphases_amd.weights.random_state(config, seed=0)
+    runner = Runner(config, state, device, audios, alignments, streams=2)
+    steps = max(10, min(args.steps, 40))
+    laps, ramp, _ = timed_regions(runner, steps, 5, 5, 1)
+    line = summary(laps, steps)
+    kernels, passes = runner.kernel_times(5)
+    roof, committed = roofline(
+        kernels, passes, line['ms_per_step'], 'transformer')
+    line.update({
+        'workload': '64 synthetic 10 s 16 kHz utterances, Transformer config '
+                    '(6 post-LN layers, 2 heads, 80 channels; seeded '
+                    'weights), two batches in flight, hipGraph replay '
+                    '(BASELINE.json configs[2])',
+        'steps': steps, 'utterances_per_s':
+            UTTERANCES / line['ms_per_step'] * 1e3,
+        'roofline': roof, 'from_profiles': committed,
+        'kernels_us_per_step': {
+            name: value[1] / passes * 1e6 for name, value in kernels.items()},
+        'preroll': ramp})
+    del runner
+    torch.cuda.empty_cache()
+    return line
+
+
+def replay_time(engine, packed, alignments, lengths, batch_size, least=0.25):
+    """(seconds per pass, words, frames, checksum) of one ragged batch with
+    its audio resident, replayed as a graph."""
+    plan = batch.plan_batch(alignments, lengths, batch_size)
+    meta = engine.upload(plan)
+    replay, scores, _ = engine.capture(packed, plan, meta)
+    for _ in range(3):
+        replay()
+    torch.cuda.synchronize()
+    laps = []
+    begin = time.perf_counter()
+    while len(laps) < 5 or time.perf_counter() - begin < least:
+        start = time.perf_counter()
+        replay()
+        torch.cuda.synchronize()
+        laps.append(time.perf_counter() - start)
+        if len(laps) >= 200:
+            break
+    columns = torch.as_tensor(plan.word_columns(), device=scores.device)
+    values = scores[columns]
+    assert bool(torch.isfinite(values).all())
+    return (float(np.median(laps)), plan.total_words, plan.total_frames,
+            float(values.double().sum()), len(laps))
+
+
+def api_time(alignments, audios, batch_size, rounds=5):
+    for _ in range(4):      # both lanes see the layout twice: graphs captured
+        emphases_amd.from_alignments_and_audios(
+            alignments, audios, 16000, batch_size=batch_size, gpu=0)
+    laps = []
+    for _ in range(rounds):
+        start = time.perf_counter()
+        scores = emphases_amd.from_alignments_and_audios(
+            alignments, audios, 16000, batch_size=batch_size, gpu=0)
+        laps.append(time.perf_counter() - start)
+    return float(np.median(laps)), float(
+        sum(float(s.double().sum()) for s in scores))
+
+
+def rates(count, frames, words, seconds):
+    frames = int(frames)
+    return {
+        'ms': seconds * 1e3, 'utterances_per_s': count / seconds,
+        'frames_per_s': frames / seconds,
+        'realtime_factor': frames / 100. / seconds,
+        'mfma_frac': (frames * FLOPS_PER_FRAME + words * FLOPS_PER_WORD)
+        / seconds / (PEAK_FP32_MFMA * 1e12),
+        'hbm_frac_compulsory': frames * BYTES_PER_FRAME / seconds / PEAK_HBM}
+
+
+def side_corpus(device):
+    """BASELINE configs[3]: 10 000 utterances of 2-30 s (SURVEY.md §8d:
+    F_i ~ U{200..3000}; 16 M frames, 0.48 M words).  One GPU here: rank 0's
+    share under the 8-rank LPT assignment of `dist.assign` (what one GPU of
+    the node does) device-only and through the public API, and the WHOLE
+    corpus as one ragged batch device-only.  Utterance i's audio is a prefix
+    of one of 40 distinct 30 s signals (generating 2.6 G distinct samples
+    would take minutes); all alignments are distinct."""
+    from emphases_amd import dist
+    pool = 40
+    engine = emphases_amd.engine.Engine(cfg.DEFAULT, None, device)
+    host = [torch.from_numpy(synth.audio(7000 + i, 3000)) for i in range(pool)]
+    on_device = [a.reshape(-1).to(device) for a in host]
+    frames = synth.corpus_frames(10000, 200, 3000)
+    alignments = [emphases_amd.Alignment.from_frames(
+        synth.word_frames(5000 + i, int(n))) for i, n in enumerate(frames)]
+    picks = np.arange(len(frames)) % pool
+    shards = dist.assign(dist.cost(frames), 8)
+    loads = [int(frames[s].sum()) for s in shards]
+    own = shards[0]
+    result = {'workload': (
+        '10 000 synthetic utterances of 2-30 s (16.0 M frames), conv config '
+        '(BASELINE.json configs[3]) on ONE GPU: rank 0 of 8 = its LPT share '
+        'of the corpus; whole = all 10 000 as one ragged batch'),
+        'shard_frames_min_max': [min(loads), max(loads)]}
+
+    def packed_of(indices):
+        lengths = [int(frames[i]) * cfg.HOPSIZE for i in indices]
+        return torch.cat([on_device[picks[i]][:n]
+                          for i, n in zip(indices, lengths)]), lengths
+
+    packed, lengths = packed_of(own)
+    seconds, words, total, checksum, laps = replay_time(
+        engine, packed, [alignments[i] for i in own], lengths, None)
+    entry = rates(len(own), total, words, seconds)
+    entry.update({'utterances': len(own), 'frames': total, 'words': words,
+                  'checksum': checksum, 'laps': laps,
+                  'what': 'device-only graph replay, audio resident'})
+    result['rank0_of_8_device_only'] = entry
+    audios = [host[picks[i]][:, :int(frames[i]) * cfg.HOPSIZE] for i in own]
+    seconds, api_sum = api_time([alignments[i] for i in own], audios, None)
+    entry = rates(len(own), total, words, seconds)
+    entry.update({'checksum': api_sum, 'what': (
+        'public API: pageable float32 host tensors in, scores out'),
+        'pcie_floor_ms_at_55GBps': total * 640 / 55e9 * 1e3})
+    result['rank0_of_8_api_float32'] = entry
+    del packed
+    packed, lengths = packed_of(range(len(frames)))
+    seconds, words, total, checksum, laps = replay_time(
+        engine, packed, alignments, lengths, None, least=0.4)
+    entry = rates(len(frames), total, words, seconds)
+    entry.update({'utterances': len(frames), 'frames': total, 'words': words,
+                  'checksum': checksum, 'laps': laps,
+                  'memory_allocated_GB':
+                      torch.cuda.max_memory_allocated() / 1e9,
+                  'what': 'whole corpus as ONE ragged batch, device-only'})
+    result['whole_corpus_device_only'] = entry
+    del packed, engine, on_device
+    torch.cuda.empty_cache()
+    return result
+
+
+def side_longform(device):
+    """BASELINE configs[4]: 5-minute utterances (30 000 frames) chunked at
+    batch_size = 3000 frames, 8 per GPU (64 per node)."""
+    engine = emphases_amd.engine.Engine(cfg.DEFAULT, None, device)
+    count = 8
+    host = [torch.from_numpy(synth.audio(7100 + i, 30000))
+            for i in range(count)]
+    alignments = [emphases_amd.Alignment.from_frames(
+        synth.word_frames(9000 + i, 30000)) for i in range(count)]
+    lengths = [int(a.shape[1]) for a in host]
+    packed = torch.cat([a.reshape(-1) for a in host]).to(device)
+    seconds, words, total, checksum, laps = replay_time(
+        engine, packed, alignments, lengths, 3000)
+    result = {'workload': (
+        '8 synthetic 5-minute utterances (one GPU\'s share of 64 per node), '
+        'conv config, chunked at batch_size = 3000 frames '
+        '(BASELINE.json configs[4])')}
+    entry = rates(count, total, words, seconds)
+    entry.update({'frames': total, 'words': words, 'checksum': checksum,
+                  'laps': laps, 'chunks': len(batch.plan_batch(
+                      alignments, lengths, 3000)),
+                  'what': 'device-only graph replay, audio resident'})
+    result['device_only'] = entry
+    seconds, api_sum = api_time(alignments, host, 3000)
+    entry = rates(count, total, words, seconds)
+    entry.update({'checksum': api_sum, 'what': (
+        'public API: pageable float32 host tensors in, scores out'),
+        'pcie_floor_ms_at_55GBps': total * 640 / 55e9 * 1e3})
+    result['api_float32'] = entry
+    pcm = [torch.from_numpy(np.rint(a.numpy() * 32768.).astype(np.int16))
+           for a in host]
+    seconds, api_sum = api_time(alignments, pcm, 3000)
+    entry = rates(count, total, words, seconds)
+    entry.update({'checksum': api_sum,
+                  'what': 'public API, 16-bit PCM tensors in'})
+    result['api_pcm16'] = entry
+    del packed, engine
+    torch.cuda.empty_cache()
+    return result
+
+
+def guarded(function, *args):
+    """(the side measurements must never cost the line its headline)"""
+    try:
+        start = time.perf_counter()
+        result = function(*args)
+        result['seconds_spent'] = time.perf_counter() - start
+        return result
+    except Exception as error:       # noqa: BLE001
+        return {'error': repr(error)}
+
+
+###############################################################################
+# Main
+###############################################################################
 
 
 def main():
     args = parse_args()
+    if args.cpu_worker is not None:
+        cpu_worker(args.cpu_worker)
+        return
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+
+    # The host baseline first: its child processes are started before this
+    # process has touched the GPU, and nothing else competes for the cores.
+    host = None
+    if world == 1 and not args.no_cpu_baseline:
+        host = guarded(cpu_baseline)
+
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     local_rank %= max(torch.cuda.device_count(), 1)
@@ -275,136 +826,72 @@ def main():
         cfg.Config(architecture='transformer')
     state = None if args.config == 'conv' else \
         emphases_amd.weights.random_state(config, seed=0)
-    engine = emphases_amd.engine.Engine(
-        config, state, device, conv_tile=args.tile,
-        winograd=not args.no_winograd)
-
     audios, alignments, bounds = workload(rank)
-    plan = build_plan(audios, alignments)
-    packed = torch.cat(
-        [torch.from_numpy(a).reshape(-1) for a in audios]).to(device)
-    meta = engine.upload(plan)
-    columns = torch.from_numpy(plan.word_columns()).to(device)
-    most_words = plan.total_words
-    if world > 1:
-        # ranks hold different numbers of words: pad to the largest shard
-        most = torch.tensor([plan.total_words], device=device)
-        torch.distributed.all_reduce(most, op=torch.distributed.ReduceOp.MAX)
-        most_words = int(most.item())
+    runner = Runner(config, state, device, audios, alignments,
+                    streams=args.streams, tile=args.tile,
+                    winograd=not args.no_winograd, graph=not args.no_graph)
+    plan, columns = runner.plan, runner.columns
 
     # The one exchange of the path (north_star: "RCCL gather of per-word scores
     # only at the end"): every step leaves its dense per-word
     # scores in a row of `send_all`, and ONE all_gather of all rows closes the
     # timed region.  No collective sits between the steps.
-    rows = max(args.steps, 1)
+    exchange = None
     if world > 1:
-        send_all = torch.zeros(rows, most_words, dtype=torch.float32, device=device)
+        # ranks hold different numbers of words: pad to the largest shard
+        most = torch.tensor([plan.total_words], device=device)
+        torch.distributed.all_reduce(most, op=torch.distributed.ReduceOp.MAX)
+        most_words = int(most.item())
+        rows = max(args.steps, 1)
+        send_all = torch.zeros(
+            rows, most_words, dtype=torch.float32, device=device)
         gathered_all = torch.empty(
             world * rows * most_words, dtype=torch.float32, device=device)
 
-    # One lane per stream: its own engine workspace (weights are shared
-    # read-only through the same state), its own captured graph.
-    lanes = []
-    for index in range(max(1, args.streams)):
-        lane_engine = engine if index == 0 else emphases_amd.engine.Engine(
-            config, state, device, conv_tile=args.tile,
-            winograd=not args.no_winograd)
-        stream = torch.cuda.Stream(device=device) if args.streams > 1 \
-            else torch.cuda.current_stream()
-        with torch.cuda.stream(stream):
-            if args.no_graph:
-                lanes.append((stream, lane_engine, None, None))
-            else:
-                replay, buffer, _ = lane_engine.capture(packed, plan, meta)
-                lanes.append((stream, lane_engine, replay, buffer))
-    torch.cuda.synchronize()
-    counter = [0]
+        def keep(scores, index):
+            send_all[index % rows, :plan.total_words] = scores[columns]
+        runner.after = keep
 
-    def step():
-        stream, lane_engine, replay, buffer = lanes[counter[0] % len(lanes)]
-        row = counter[0] % rows
-        counter[0] += 1
-        with torch.cuda.stream(stream):
-            if replay is None:
-                scores = lane_engine.forward(packed, plan, meta)[0]
-            else:
-                replay()
-                scores = buffer
-            if world > 1:
-                send_all[row, :plan.total_words] = scores[columns]
-        return scores
+        def exchange():
+            """All ranks' scores of all steps on every rank: one all_gather."""
+            for stream, *_ in runner.lanes:
+                torch.cuda.current_stream().wait_stream(stream)
+            torch.distributed.all_gather_into_tensor(
+                gathered_all, send_all.view(-1))
 
-    def exchange():
-        """All ranks' scores of all steps on every rank: one RCCL all_gather."""
-        if world == 1:
-            return
-        for stream, *_ in lanes:
-            torch.cuda.current_stream().wait_stream(stream)
-        torch.distributed.all_gather_into_tensor(
-            gathered_all, send_all.view(-1))
-
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    exchange()
-    counter[0] = 0
-    barrier()
-    start = time.perf_counter()
-    for _ in range(args.steps):
-        scores = step()
-    exchange()
-    barrier()
-    elapsed = time.perf_counter() - start
+    laps, ramp, scores = timed_regions(
+        runner, args.steps, args.warmup, args.regions, world, exchange,
+        skip_preroll=args.no_preroll)
     if world > 1:
         # every rank now holds every rank's scores: its own rows came back intact
         mine = gathered_all.view(world, rows, most_words)[rank]
         assert torch.equal(mine, send_all), 'all_gather returned other scores'
-        slowest = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(
-            slowest, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(slowest.item())
+    line = summary(laps, args.steps)
+    elapsed = line['timed_region_s']
 
     # Dominant kernel, timed live with HIP events on the launch stream
-    engine.timers = []
-    for _ in range(min(args.steps, 10)):
-        engine.forward(packed, plan, meta)
-    torch.cuda.synchronize()
-    kernels = {}
-    for name, flops, begin, end in engine.timers:
-        entry = kernels.setdefault(name, [0, 0., 0.])
-        entry[0] += 1
-        entry[1] += begin.elapsed_time(end) * 1e-3
-        entry[2] += flops
-    engine.timers = None
-    dominant = max(kernels, key=lambda name: kernels[name][1])
-    launches, seconds, flops = kernels[dominant]
-    achieved = flops / seconds / 1e12
-    # HBM bytes per launch of that kernel from the committed PMC passes
-    # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
-    traffic = None
-    for tag in ('r2', 'r1'):
-        name = f'{tag}_pmc_summary.json' if args.config == 'conv' else \
-            f'{tag}_transformer_pmc_summary.json'
-        summary = os.path.join(ROOT, 'profiles', name)
-        if os.path.exists(summary):
-            with open(summary) as file:
-                traffic = json.load(file).get(dominant, {}).get(
-                    'traffic_bytes')
-            break
+    runner.after = None
+    kernels, passes = runner.kernel_times(20)
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
+        roof, committed = roofline(
+            kernels, passes, line['ms_per_step'], args.config)
         total_utterances = UTTERANCES * world
         result = {
             'metric': 'utterances/s (10 s @16 kHz) whole-node',
             'value': total_utterances * args.steps / elapsed,
             'unit': 'utterances/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step,
+            'ms_per_step': line['ms_per_step'],
+            'ms_per_step_min': line['ms_per_step_min'],
+            'ms_per_step_max': line['ms_per_step_max'],
+            'timed_region_s': elapsed, 'regions': line['regions'],
+            'timing': (
+                f'{args.steps} steps timed {line["regions"]} times after a '
+                'steady-state pre-roll and the warm-up; the median region is '
+                'reported (barrier + synchronize on both sides, max over '
+                'ranks)'),
+            'preroll': ramp,
             'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {
@@ -415,32 +902,16 @@ def main():
                     '(BASELINE.json configs[1])'),
                 'utterances_per_gpu': UTTERANCES, 'frames_per_gpu':
                     plan.total_frames, 'words_per_gpu': plan.total_words,
-                'conv_tile': meta['tile'],
+                'conv_tile': runner.meta['tile'],
                 'launch': 'eager' if args.no_graph else 'hipGraph replay',
-                'batches_in_flight': len(lanes),
+                'batches_in_flight': len(runner.lanes),
                 'parallelism': f'utterance-sharded x{world}',
                 'exchange': 'none (one rank)' if world == 1 else
                 f'one {args.backend} all_gather of the {args.steps} steps\' '
-                'per-word scores at the end of the timed region'},
+                'per-word scores at the end of each timed region'},
             'frames_per_s_per_gpu': plan.total_frames * args.steps / elapsed,
-            'roofline': {
-                'bound': 'mfma', 'kernel': dominant,
-                'achieved': achieved, 'peak': PEAK_FP32_MFMA,
-                'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA,
-                'avg_launch_us': seconds / launches * 1e6,
-                'share_of_step': seconds / min(args.steps, 10) /
-                    (elapsed / args.steps),
-                'traffic': traffic,
-                'algorithmic_flops_per_launch': flops / launches,
-                # Winograd F(2,3) executes 2/3, F(4,3) 1/2 of the direct form's
-                # MFMA work
-                # SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of this
-                # kernel, profiles/r2_pmc_utilisation.md
-                'mfma_pipe_busy_pmc': 0.49 if 'winograd4' in dominant else (
-                    0.74 if dominant == 'attention_frames' else None),
-                'executed_mfma_flops_per_launch': flops / launches * (
-                    .5 if 'winograd4' in dominant else
-                    2. / 3. if 'winograd' in dominant else 1.)},
+            'roofline': roof,
+            'from_profiles': committed,
             # the whole path against both ceilings (per GPU).
             # The conv path is MFMA-bound: its compulsory HBM traffic is only
             # 641 B per frame.
@@ -452,22 +923,23 @@ def main():
                                        args.steps / elapsed / PEAK_HBM,
                 'binds': 'mfma'} if args.config == 'conv' else None,
             'kernels_us_per_step': {
-                name: value[1] / min(args.steps, 10) * 1e6
+                name: value[1] / passes * 1e6
                 for name, value in kernels.items()},
         }
-        check = float(scores[columns].sum().item())
-        result['checksum'] = check
-        # (the side measurements must never cost the line its headline)
-        if world == 1 and args.config == 'conv' and not args.no_api:
-            try:
-                result['end_to_end_api'] = end_to_end_api(audios, alignments)
-            except Exception as error:       # noqa: BLE001
-                result['end_to_end_api'] = {'error': repr(error)}
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                result['cpu_baseline'] = cpu_baseline(audios, bounds)
-            except Exception as error:       # noqa: BLE001
-                result['cpu_baseline'] = {'error': repr(error)}
+        result['checksum'] = float(scores[columns].sum().item())
+        if host is not None:
+            result['cpu_baseline'] = host
+        del runner
+        torch.cuda.empty_cache()
+        if world == 1 and args.config == 'conv':
+            if not args.no_api:
+                result['end_to_end_api'] = guarded(
+                    end_to_end_api, audios, alignments)
+            if not args.no_side:
+                result['configs_2_transformer'] = guarded(
+                    side_transformer, device, audios, alignments, args)
+                result['configs_4_longform'] = guarded(side_longform, device)
+                result['configs_3_corpus'] = guarded(side_corpus, device)
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

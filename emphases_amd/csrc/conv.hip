@@ -30,10 +30,6 @@
 
 #include "common.h"
 
-#ifndef EMPH_STAMP
-#define EMPH_STAMP(slot)   // in-kernel timeline stamps: tools/micro only
-#endif
-
 namespace emph {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -252,7 +248,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_kernel(
     constexpr int GROUPS = KS == 1 ? U : 1;    // 4-row groups per iteration
     constexpr int kBatch = 10;                 // 16-byte loads in flight per lane
     extern __shared__ __align__(16) float weights[];   // [steps][MB][64]
-    EMPH_STAMP(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kk = lane >> 4;      // k index inside the k-step
@@ -390,7 +385,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_kernel(
             bias_lds[index] = (bias != nullptr && channel < c_out) ? bias[channel] : 0.f;
         }
     }
-    EMPH_STAMP(1);
 
     for (int group = blockIdx.x; group < groups_of_tiles; group += gridDim.x) {
         if (group != static_cast<int>(blockIdx.x)) {
@@ -453,7 +447,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_kernel(
             // is outstanding.  sched_barrier pins the three phases.
             float av[U][MB], bv[U][NB];
             load_a(a0, 0);
-            EMPH_STAMP(2);
 #pragma unroll 1
             for (int local = 0; local < count; ++local) {
                 select_b(bv, b0, first + local);
@@ -486,7 +479,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_kernel(
             }
         }
         if (!active) continue;
-        EMPH_STAMP(3);
 
         // ---- epilogue.  The MFMA result layout is D[row = 4*(lane>>4) + r]
         // [col = lane&15].  Identity / ReLU with channel-major output store it
@@ -532,7 +524,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_kernel(
                 wave_lds_fence();
             }
         }
-        EMPH_STAMP(4);
     }
 }
 
@@ -561,7 +552,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_winograd_kernel(
     const float* __restrict__ pack, const float* __restrict__ bias, int c_in,
     int c_out, int act, const int32_t* __restrict__ tiles, int n_tiles,
     int patch_offset) {
-    EMPH_STAMP(0);
     constexpr int THREADS = 64 * WAVES;
     constexpr int kPatchStride = patch_stride(2 * NB);
     extern __shared__ __align__(16) float weights[];   // [groups][4][MB][64]
@@ -631,7 +621,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_winograd_kernel(
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): LDS-DMA landed
         __syncthreads();
     }
-    EMPH_STAMP(1);
 
     for (int group = blockIdx.x; group < groups_of_tiles; group += gridDim.x) {
         if (group != static_cast<int>(blockIdx.x)) {
@@ -653,7 +642,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_winograd_kernel(
 
         float av[4][MB], v[4][NB];
         load_a(a0, 0);
-        EMPH_STAMP(2);
         // One K iteration (4 input channels): transform the B fragments that
         // have landed, request the ones TWO iterations ahead into the registers
         // just freed, then the 4 MB NB MFMAs with the next A fragments' LDS
@@ -722,7 +710,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_winograd_kernel(
                 step(b0, iteration, 1);
         }
 
-        EMPH_STAMP(3);
         // ---- output transform + epilogue.  Lane (kk, col) holds rows 4 kk + r
         // of pair `col` of pair-tile n, i.e. positions 32 n + 2 col (+1): for
         // identity / ReLU it stores them straight from registers as 8-byte
@@ -789,7 +776,6 @@ __global__ __launch_bounds__(64 * WAVES) void conv1d_winograd_kernel(
                 wave_lds_fence();
             }
         }
-        EMPH_STAMP(4);
     }
 }
 

@@ -25,10 +25,6 @@
 
 #include "common.h"
 
-#ifndef EMPH_STAMP
-#define EMPH_STAMP(slot)
-#endif
-
 namespace emph {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -56,7 +52,6 @@ __global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
     const float* __restrict__ pack, const float* __restrict__ bias, int c_in, int c_out,
     int act, const int32_t* __restrict__ tiles, int n_tiles, int bias_offset,
     const float* __restrict__ position, int max_positions) {
-    EMPH_STAMP(0);
     extern __shared__ __align__(16) float weights[];   // [groups][6][m_tiles][64]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -114,7 +109,6 @@ __global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): LDS-DMA landed
         __syncthreads();
     }
-    EMPH_STAMP(1);
 
     for (int group = blockIdx.x; group < groups_of_tiles; group += gridDim.x) {
         if (group != static_cast<int>(blockIdx.x)) {
@@ -185,7 +179,6 @@ __global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
         };
         load_a(0);
         load_b(b1, 1);
-        EMPH_STAMP(2);
         int iteration = 0;
 #pragma unroll 1
         for (; iteration + 1 < iterations; iteration += 2) {
@@ -193,7 +186,6 @@ __global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
             step(b1, iteration + 1);
         }
         if (iteration < iterations) step(b0, iteration);
-        EMPH_STAMP(3);
 
         // ---- output transform, bias, ReLU, one 16-byte store per row and quad
         const bool relu = act == EMPH_ACT_RELU;
@@ -247,7 +239,6 @@ __global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
         };
         if (m_count == MT) run(std::integral_constant<int, MT>{});
         else run(std::integral_constant<int, (MT > 1 ? MT - 1 : 1)>{});
-        EMPH_STAMP(4);
     }
 }
 

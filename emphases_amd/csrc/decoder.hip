@@ -32,10 +32,6 @@
 
 #include "common.h"
 
-#ifndef EMPH_STAMP
-#define EMPH_STAMP(slot)   // in-kernel timeline stamps: tools/micro only
-#endif
-
 namespace emph {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -71,7 +67,6 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
     const float* __restrict__ out_weight, const float* __restrict__ out_bias,
     int out_kernel, int post, float* __restrict__ logits, float* __restrict__ scores) {
     extern __shared__ __align__(16) float lds[];
-    EMPH_STAMP(0);
     const int m_tiles = channels >> 4;
     const int threads = blockDim.x;
     const int waves = threads >> 6;
@@ -168,7 +163,6 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
         bias_lds[index] = biases[index];
     for (int index = threadIdx.x; index <= channels * out_kernel; index += threads)
         out_lds[index] = index < channels * out_kernel ? out_weight[index] : out_bias[0];
-    EMPH_STAMP(1);
 
     if (loader) {
         // one barrier per chunk, in step with the MFMA waves below: chunk q has
@@ -268,10 +262,8 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (layer == 1 && trip < 5) EMPH_STAMP(11 + trip);
             };
             __syncthreads();                          // chunk (layer, 0) is in the ring
-            if (layer == 1) EMPH_STAMP(10);
             if (kTwoSets) {
                 issue(a_set[0], b_set[0], 0);
                 for (int trip = 0; trip < trips; trip += 2) {
@@ -317,7 +309,6 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
                     const int c = 16 * (m_begin + i) + 4 * kk + r;
                     target[c * kActStride + kLeadCols + p] = inside ? value[i][r] : 0.f;
                 }
-            EMPH_STAMP(3 + layer);
             buffer ^= 1;
         }
     };
@@ -359,7 +350,6 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
                 }
             }
         }
-        EMPH_STAMP(9);
     }
 }
 

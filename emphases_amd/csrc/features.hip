@@ -61,8 +61,10 @@ template <bool PCM>
 __global__ __launch_bounds__(256) void resample_kernel(
     const void* __restrict__ audio, const int64_t* __restrict__ table,
     const float* __restrict__ kernel, int orig, int fresh, int width, int taps,
-    float* __restrict__ out) {
-    const int64_t* row = table + static_cast<int64_t>(blockIdx.y) * 4;
+    int n_utterances, float* __restrict__ out) {
+  // (grid.y is capped at 65 535: a block row walks the utterances with that stride)
+  for (int utterance = blockIdx.y; utterance < n_utterances; utterance += gridDim.y) {
+    const int64_t* row = table + static_cast<int64_t>(utterance) * 4;
     const int64_t source = row[0], length = row[1], target = row[2], count = row[3];
     for (int64_t m = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; m < count;
          m += static_cast<int64_t>(gridDim.x) * 256) {
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(256) void resample_kernel(
         }
         out[target + m] = acc;
     }
+  }
 }
 
 }  // namespace emph
@@ -126,14 +129,14 @@ int emph_resample(const void* audio, int32_t audio_format, const int64_t* table,
     const int taps = 2 * width + orig;
     const int64_t blocks = (most_samples + 255) / 256;
     dim3 grid(static_cast<unsigned>(blocks < 4096 ? blocks : 4096),
-              static_cast<unsigned>(n_utterances));
+              static_cast<unsigned>(n_utterances < 65535 ? n_utterances : 65535));
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (audio_format == EMPH_AUDIO_PCM16)
         EMPH_LAUNCH(resample_kernel<true>, grid, dim3(256), 0, s, audio, table, kernel, orig,
-                    fresh, width, taps, out);
+                    fresh, width, taps, n_utterances, out);
     else
         EMPH_LAUNCH(resample_kernel<false>, grid, dim3(256), 0, s, audio, table, kernel, orig,
-                    fresh, width, taps, out);
+                    fresh, width, taps, n_utterances, out);
     return check_launch("emph_resample");
 }
 

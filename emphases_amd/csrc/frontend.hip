@@ -28,10 +28,6 @@
 
 #include "common.h"
 
-#ifndef EMPH_STAMP
-#define EMPH_STAMP(slot)   // in-kernel timeline stamps: tools/micro only
-#endif
-
 namespace emph {
 
 namespace {
@@ -50,11 +46,7 @@ void set_error(const char* format, ...) {
 // sees it: only the COMPILER has to be kept from reordering them; the wait for
 // the data is the s_waitcnt hipcc places before the first use of what was read.
 __device__ __forceinline__ void frontend_fence() {
-#ifdef EMPH_FE_FENCE_WAIT
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
     asm volatile("" ::: "memory");
-#endif
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -329,7 +321,6 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
     constexpr bool kPeak = MODE == 1;
 
     extern __shared__ __align__(16) float lds[];
-    EMPH_STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -439,7 +430,6 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
         peak = 0.f;
         peak_segment = segment;
     }
-    EMPH_STAMP(1);
 
     float floor_db = 0.f;
     if (kLoud) {
@@ -470,7 +460,6 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
         }
         cf v[kPair][8];
         cf* ex[kPair];
-        if (local == 8) EMPH_STAMP(2);
 #pragma unroll
         for (int f = 0; f < kPair; ++f) {
             ex[f] = reinterpret_cast<cf*>(exchange + f * kExFloats);
@@ -478,13 +467,11 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
             for (int q = 0; q < 8; ++q)
                 v[f][q] = raw[f][q] * cf{window[2 * q], window[2 * q + 1]};
         }
-        if (local == 8) EMPH_STAMP(3);
         if (kPrefetch && local + kPair < valid) {          // wave-uniform
 #pragma unroll
             for (int f = 0; f < kPair; ++f)
                 load_frame<PCM>(chunk, frame0 + min(local + kPair + f, valid - 1), p, raw[f]);
         }
-        if (local == 8) EMPH_STAMP(4);
         // Every exchange below is written frame by frame as
         //     compute(f); write(f); fence; read(f)
         // so that a frame's LDS round trip runs under the OTHER frame's
@@ -505,7 +492,6 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
             lds_read8<64>(v[f], ex[f] + r1 * kExRow + p0);        // p1 = 0 .. 7
             frontend_fence();
             frontend_section();
-            if (local == 8) EMPH_STAMP(5 + f);
         }
         // pass 3: lane (r, t) takes C[r][p0][t], radix-8 over p0
 #pragma unroll
@@ -520,7 +506,6 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
             lds_read8<8>(v[f], ex[f] + r1 * kExRowB + p0 * kExStepB);     // q = 0 .. 7
             frontend_fence();
             frontend_section();
-            if (local == 8) EMPH_STAMP(7 + f);
         }
         // Z[r + 8 t + 64 u] = v[u].  Real-FFT split, two bins per pair: with
         // E = Z[k] + conj(Z[512-k]) and O' = (-i W^k)(Z[k] - conj(Z[512-k])),
@@ -616,7 +601,6 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
                 if (lane < kMagFloats - kBins) mag[kBins + lane] = 0.f;
             }
             frontend_fence();
-            if (local == 8) EMPH_STAMP(12);
 #pragma unroll
             for (int f = 0; f < kPair; ++f) {
                 const float* mag = exchange + f * kExFloats;
@@ -652,12 +636,10 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
                     if (normalize) value = fmaf(value, 0.1f, 1.f);
                     tile[(64 + (lane >> 2)) * kTileStride + column] = value;
                 }
-                if (local == 8) EMPH_STAMP(13 + f);
             }
             frontend_fence();
         }
     }
-    EMPH_STAMP(15);
 
     if (!kPeak) {
         if (kMel) {
@@ -691,9 +673,6 @@ inline int frontend_grid(int n_tiles) {
     const int groups = (n_tiles + 3) / 4;
     constexpr int resident = 256 * EMPH_FE_WAVES;
     if (EMPH_FE_WAVES != 2) return groups < resident ? groups : resident;
-#ifdef EMPH_FE_GRID_ENV
-    if (const char* env = getenv("EMPH_FE_GRID")) return atoi(env);
-#endif
     return groups < 512 ? groups : 512;
 }
 

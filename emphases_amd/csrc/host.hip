@@ -34,12 +34,6 @@ struct Piece {
     size_t bytes;
 };
 
-// EMPHASES_COPY_STREAM=0 switches the streaming stores off.
-bool flag(const char* name) {
-    const char* value = getenv(name);
-    return value == nullptr || value[0] != '0';
-}
-
 // The staging buffer is written once and read by the DMA engine only: streaming
 // (non-temporal) stores skip the read-for-ownership of every destination line,
 // a third of the memory traffic of a plain memcpy.
@@ -188,8 +182,7 @@ int emph_host_gather(const void* const* host_sources, const int64_t* host_bytes,
     }
     job.count = static_cast<int>(job.pieces.size());
     job.workers = threads - 1;
-    static const bool streaming = flag("EMPHASES_COPY_STREAM");
-    job.streaming = streaming;
+    job.streaming = true;
     if (job.count == 0) return EMPH_OK;
     g_pool->run(&job);
     return EMPH_OK;

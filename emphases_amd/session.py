@@ -30,7 +30,8 @@ from . import batch
 from . import config as cfg
 from . import load
 
-COPY_THREADS = int(os.environ.get('EMPHASES_COPY_THREADS', 16))
+# (`emph_host_gather` takes 1 .. 64 copy threads)
+COPY_THREADS = min(64, max(1, int(os.environ.get('EMPHASES_COPY_THREADS', 16))))
 # A synchronous call with more audio than twice this is run as consecutive
 # sub-batches of about this size over the lanes, so that the kernels of one
 # run under the PCIe transfer of the next (a rank's 1.28 GB share of BASELINE
@@ -60,6 +61,9 @@ class _Lane:
         self.raw = None               # device uint8: audio before resampling
         self.result = None            # pinned float32
         self.pending = None
+        # `Pending.result()` of this lane's batch against a `submit` that takes
+        # the lane again from another thread
+        self.lock = threading.RLock()
         # recurring batch layouts: key -> _Layout (plan, device metadata and,
         # from the second sighting on, the captured HIP graph of the forward)
         self.layouts = collections.OrderedDict()
@@ -184,13 +188,20 @@ class Pending:
                 empty.to(lane.device) if self._on_device else empty.clone()
                 for _ in range(self._count)]
             return self._value
-        lane.done.synchronize()
-        if self._on_device:
-            packed = self._scores
-        else:
-            packed = lane.result[:self._ld_words].clone()
-        if lane.pending is self:
-            lane.pending = None
+        with lane.lock:
+            if self._value is not None:
+                return self._value
+            lane.done.synchronize()
+            if self._on_device:
+                packed = self._scores
+                # allocated on the lane's stream, consumed on the caller's: the
+                # caching allocator must not hand the block to the lane's next
+                # clone while the caller's kernels still read it
+                packed.record_stream(torch.cuda.current_stream(lane.device))
+            else:
+                packed = lane.result[:self._ld_words].clone()
+            if lane.pending is self:
+                lane.pending = None
         # one gather of the valid word columns, one split: per-utterance views
         # [1, W_u] of a dense row (an utterance's chunks are consecutive)
         columns = torch.from_numpy(plan.word_columns())
@@ -251,91 +262,117 @@ class Session:
         with self._lock:
             lane = self.lanes[self._cursor % len(self.lanes)]
             self._cursor += 1
-            if lane.pending is not None:
-                lane.pending.result()
-            alignments = list(alignments)
-            audios = [mono(audio) for audio in audios]
-            resampling = int(sample_rate) != cfg.SAMPLE_RATE
-            pcm = bool(audios) and all(
-                audio.dtype == torch.int16 for audio in audios)
-            dtype = torch.int16 if pcm else torch.float32
-            if not pcm:
-                audios = [audio.to(torch.float32) if audio.dtype != torch.float32
-                          else audio for audio in audios]
-            raw_lengths = [int(audio.shape[0]) for audio in audios]
-            lengths = raw_lengths
-            if resampling:
-                _, orig, new, _ = load.resample_kernel(sample_rate)
-                lengths = [load.resampled_length(n, orig, new)
-                           for n in raw_lengths]
-                dtype_in, dtype = dtype, torch.float32
-            layout = None
-            key = layout_key(alignments, lengths, batch_size, dtype) \
-                if audios else None
-            if key is not None:
-                layout = lane.layouts.get(key)
-                if layout is not None:
-                    lane.layouts.move_to_end(key)
-            fresh = layout is None and bool(audios)
-            if fresh:
-                layout = _Layout(
-                    batch.plan_batch(alignments, lengths, batch_size))
-            plan = layout.plan if layout is not None else None
-            pending = Pending(
-                lane, plan, len(audios), on_device,
-                plan.ld_words if plan is not None else 0)
-            if plan is None or not len(plan):
-                return pending
-            engine = lane.engine
-            # (growing the buffers drops the cached layouts, whose graphs point
-            # into the old ones: so before this layout joins the cache)
-            lane._reserve(
-                max(sum(lengths) * (2 if dtype == torch.int16 else 4),
-                    sum(raw_lengths) * 4 if resampling else 0),
-                plan.ld_words)
-            if fresh and key is not None:
-                lane.layouts[key] = layout
-                while len(lane.layouts) > _Layout.KEEP:
-                    lane.layouts.popitem(last=False)
-            with torch.cuda.device(lane.device), \
-                    torch.cuda.stream(lane.stream):
-                tracks = None
-                if engine.config.pitch_feature or \
-                        engine.config.periodicity_feature:
-                    from . import core
-                    # (the tracker runs on the host and wants 16 kHz audio)
-                    heard = audios if not resampling else [
-                        load.resample(
-                            (a.to(torch.float32) / 32768.
-                             if a.dtype == torch.int16 else a).cpu(),
-                            sample_rate) for a in audios]
-                    tracks = core._tracks(
-                        engine, plan, heard, pitch_tracker, lane.device.index)
-                if resampling:
-                    packed, _ = self._resample(
-                        lane, audios, raw_lengths, dtype_in, sample_rate)
-                else:
-                    packed = lane.stage(audios, lengths, dtype)
-                layout.seen += 1
-                if tracks is None and layout.replay is None and \
-                        layout.seen >= 2 and key in lane.layouts:
-                    # the layout came back: from now on one graph launch
-                    layout.meta = engine.upload(plan)
-                    layout.replay, layout.scores, _ = engine.capture(
-                        packed, plan, layout.meta)
-                if tracks is None and layout.replay is not None:
-                    layout.replay()
-                    scores = layout.scores
-                else:
-                    scores, _ = engine.forward(packed, plan, tracks=tracks)
-                if on_device:
-                    pending._scores = scores.clone()
-                else:
-                    lane.result[:plan.ld_words].copy_(
-                        scores, non_blocking=True)
-                lane.done.record(lane.stream)
-            lane.pending = pending
+            with lane.lock:
+                if lane.pending is not None:
+                    lane.pending.result()
+                try:
+                    return self._enqueue(
+                        lane, list(alignments), list(audios), sample_rate,
+                        batch_size, on_device, pitch_tracker)
+                except BaseException:
+                    # Copies and kernels may already be queued on the lane's
+                    # stream with no `done` event behind them: drain it before
+                    # the pinned staging buffer can be reused, and forget the
+                    # layouts (one of them may be half built / half captured).
+                    try:
+                        lane.stream.synchronize()
+                    except Exception:     # noqa: BLE001
+                        pass
+                    lane.layouts.clear()
+                    lane.pending = None
+                    raise
+
+    def _enqueue(self, lane, alignments, audios, sample_rate, batch_size,
+                 on_device, pitch_tracker):
+        audios = [mono(audio) for audio in audios]
+        resampling = int(sample_rate) != cfg.SAMPLE_RATE
+        pcm = bool(audios) and all(
+            audio.dtype == torch.int16 for audio in audios)
+        dtype = torch.int16 if pcm else torch.float32
+        if not pcm:
+            # int16 is 16-bit PCM wherever it appears (x / 32768, exact): a
+            # mixed batch gives every utterance the bits of its own call
+            audios = [audio.to(torch.float32) / 32768.
+                      if audio.dtype == torch.int16 else audio
+                      for audio in audios]
+        raw_lengths = [int(audio.shape[0]) for audio in audios]
+        lengths = raw_lengths
+        if resampling:
+            _, orig, new, _ = load.resample_kernel(sample_rate)
+            lengths = [load.resampled_length(n, orig, new)
+                       for n in raw_lengths]
+            dtype_in, dtype = dtype, torch.float32
+        layout = None
+        key = layout_key(alignments, lengths, batch_size, dtype) \
+            if audios else None
+        if key is not None:
+            layout = lane.layouts.get(key)
+            if layout is not None:
+                lane.layouts.move_to_end(key)
+        fresh = layout is None and bool(audios)
+        if fresh:
+            layout = _Layout(
+                batch.plan_batch(alignments, lengths, batch_size))
+        plan = layout.plan if layout is not None else None
+        pending = Pending(
+            lane, plan, len(audios), on_device,
+            plan.ld_words if plan is not None else 0)
+        if plan is None or not len(plan):
             return pending
+        engine = lane.engine
+        # (growing the buffers drops the cached layouts, whose graphs point
+        # into the old ones: so before this layout joins the cache)
+        lane._reserve(
+            max(sum(lengths) * (2 if dtype == torch.int16 else 4),
+                sum(raw_lengths) * 4 if resampling else 0),
+            plan.ld_words)
+        if fresh and key is not None:
+            lane.layouts[key] = layout
+            while len(lane.layouts) > _Layout.KEEP:
+                lane.layouts.popitem(last=False)
+        if any(audio.is_cuda for audio in audios):
+            # device-resident input may still be being written by kernels on
+            # the caller's stream
+            lane.stream.wait_stream(torch.cuda.current_stream(lane.device))
+        with torch.cuda.device(lane.device), \
+                torch.cuda.stream(lane.stream):
+            tracks = None
+            if engine.config.pitch_feature or \
+                    engine.config.periodicity_feature:
+                from . import core
+                # (the tracker runs on the host and wants 16 kHz audio)
+                heard = audios if not resampling else [
+                    load.resample(
+                        (a.to(torch.float32) / 32768.
+                         if a.dtype == torch.int16 else a).cpu(),
+                        sample_rate) for a in audios]
+                tracks = core._tracks(
+                    engine, plan, heard, pitch_tracker, lane.device.index)
+            if resampling:
+                packed, _ = self._resample(
+                    lane, audios, raw_lengths, dtype_in, sample_rate)
+            else:
+                packed = lane.stage(audios, lengths, dtype)
+            layout.seen += 1
+            if tracks is None and layout.replay is None and \
+                    layout.seen >= 2 and key in lane.layouts:
+                # the layout came back: from now on one graph launch
+                layout.meta = engine.upload(plan)
+                layout.replay, layout.scores, _ = engine.capture(
+                    packed, plan, layout.meta)
+            if tracks is None and layout.replay is not None:
+                layout.replay()
+                scores = layout.scores
+            else:
+                scores, _ = engine.forward(packed, plan, tracks=tracks)
+            if on_device:
+                pending._scores = scores.clone()
+            else:
+                lane.result[:plan.ld_words].copy_(
+                    scores, non_blocking=True)
+            lane.done.record(lane.stream)
+        lane.pending = pending
+        return pending
 
     def run(self, alignments, audios, sample_rate=cfg.SAMPLE_RATE,
             batch_size=None, on_device=False, pitch_tracker=None):

@@ -6,7 +6,10 @@ PearsonCorrelation}` (third-party, absent: PARITY UNPINNED there); their
 published definitions are restated below.  First-party arithmetic (the mask,
 `binary_cross_entropy_with_logits` vs the clamped log form, `mse_loss` of the
 postprocessed logits) follows the reference line by line with the same ATen
-ops."""
+ops and is PINNED: `tests/golden/generate.py` runs the reference's own
+`Statistics` / `Metrics.update` on seeded ragged batches (with stand-in
+running averages for the absent bases) and `tests/test_oracle.py` compares
+per-word values bitwise and the results to 2e-6 (`tests/golden/metrics.npz`)."""
 import math
 
 import torch
@@ -21,6 +24,23 @@ def mask_from_lengths(lengths):
 def postprocess(logits, loss='bce'):
     return torch.sigmoid(logits) if loss == 'bce' else \
         torch.clamp(logits, 0., 1.)
+
+
+def word_values(logits, targets, word_lengths, loss='bce'):
+    """(per-word BCE values, per-word squared errors) of the masked words:
+    what `BinaryCrossEntropy.update` / `MeanSquaredError.update`
+    (metrics.py:59-92) hand to their running averages."""
+    mask = mask_from_lengths(word_lengths)                     # metrics.py:36
+    logits, targets = logits[mask], targets[mask]
+    if loss == 'bce':                                          # metrics.py:62-67
+        values = torch.nn.functional.binary_cross_entropy_with_logits(
+            logits, targets, reduction='none')
+    else:                                                      # metrics.py:71-74
+        x, y = torch.clamp(logits, 0., 1.), targets
+        values = -(y * torch.log(x + 1e-6) +
+                   (1 - y) * torch.log(1 - x + 1e-6))
+    return values, torch.nn.functional.mse_loss(
+        postprocess(logits, loss), targets, reduction='none')
 
 
 class Metrics:

@@ -12,6 +12,8 @@ Outputs (committed; data only, no reference source):
   tests/golden/cases.npz       default conv model, bundled checkpoint
   tests/golden/chunks.npz      chunk plans of `emphases.preprocess`
   tests/golden/variants.npz    config-variant matrix with seeded weights
+  tests/golden/metrics.npz     the reference's own evaluate.metrics on seeded
+                               ragged batches (`generate.py metrics` = only this)
   emphases_amd/assets/checkpoint.npz   the reference's trained weights
 The GPU box never runs this script; it only reads the .npz files.
 """
@@ -378,11 +380,100 @@ def capture_variants(out):
 
 
 ###############################################################################
+# Evaluation metrics (emphases/evaluate/metrics.py:12-110)
+###############################################################################
+
+
+def metric_batches(loss, seed):
+    """Seeded ragged batches [B, 1, W]: logits, targets, word_lengths.  Padding
+    columns hold large finite garbage (the mask must drop them)."""
+    generator = np.random.default_rng(seed)
+    batches = []
+    for lengths in ([37, 1, 12, 30, 5], [1], [64, 64], [3, 17, 2, 9, 40, 8, 1]):
+        lengths = np.array(lengths, dtype=np.int64)
+        shape = (len(lengths), 1, int(lengths.max()))
+        if loss == 'bce':
+            logits = generator.normal(0., 3., shape)
+        else:   # raw scores around [0, 1], some outside (the clamp matters)
+            logits = generator.uniform(-0.4, 1.4, shape)
+            logits.flat[::7] = 0.            # log(0 + 1e-6) branch
+            logits.flat[3::11] = 1.
+        targets = generator.uniform(0., 1., shape)
+        targets.flat[::13] = 0.
+        targets.flat[5::17] = 1.
+        for row, length in enumerate(lengths):
+            logits[row, :, length:] = 1e4
+            targets[row, :, length:] = -1e4
+        batches.append((logits.astype(np.float32),
+                        targets.astype(np.float32), lengths))
+    return batches
+
+
+def capture_metrics(out):
+    """The reference's `Statistics` then `Metrics` exactly as
+    `evaluate/core.py:28-52` chains them, per `LOSS`; the per-word values its
+    first-party `update`s hand to the (stand-in) running averages are recorded
+    too, so the first-party arithmetic is pinned element by element."""
+    import torchutil
+    metrics = emphases.evaluate.metrics
+    for loss in ('bce', 'mse'):
+        emphases.LOSS = loss
+        batches = metric_batches(loss, 100 + len(loss))
+        predicted_stats, target_stats = metrics.Statistics(), metrics.Statistics()
+        for logits, targets, lengths in batches:
+            scores = emphases.postprocess(torch.from_numpy(logits))
+            target_stats.update(torch.from_numpy(targets), torch.from_numpy(lengths))
+            predicted_stats.update(scores, torch.from_numpy(lengths))
+        out[f'{loss}/predicted_stats'] = np.array(predicted_stats(), np.float64)
+        out[f'{loss}/target_stats'] = np.array(target_stats(), np.float64)
+        recorded = []
+        original = torchutil.metrics.Average.update
+
+        def update(self, values, count, original=original, recorded=recorded):
+            recorded.append(values.detach().numpy().copy())
+            original(self, values, count)
+        torchutil.metrics.Average.update = update
+        try:
+            total = metrics.Metrics(predicted_stats, target_stats)
+            for index, (logits, targets, lengths) in enumerate(batches):
+                single = metrics.Metrics(predicted_stats, target_stats)
+                for metric in (total, single):
+                    metric.update(
+                        torch.from_numpy(logits), torch.from_numpy(targets),
+                        torch.from_numpy(lengths))
+                out[f'{loss}/{index}/logits'] = logits
+                out[f'{loss}/{index}/targets'] = targets
+                out[f'{loss}/{index}/word_lengths'] = lengths
+                # (total's bce, mse, then single's bce, mse)
+                out[f'{loss}/{index}/bce_values'] = recorded[-4]
+                out[f'{loss}/{index}/squared_errors'] = recorded[-3]
+                result = single()
+                out[f'{loss}/{index}/result'] = np.array(
+                    [result['pearson_correlation'], result['bce'],
+                     result['mse']], np.float64)
+            result = total()
+            out[f'{loss}/result'] = np.array(
+                [result['pearson_correlation'], result['bce'], result['mse']],
+                np.float64)
+            out[f'{loss}/batches'] = np.int64(len(batches))
+            print(f'metrics {loss}: stats p={predicted_stats()} '
+                  f't={target_stats()} -> {result}')
+        finally:
+            torchutil.metrics.Average.update = original
+    emphases.LOSS = acfg.DEFAULT.loss
+
+
+###############################################################################
 # Entry point
 ###############################################################################
 
 
 def main():
+    measures = {}
+    capture_metrics(measures)
+    np.savez_compressed(os.path.join(HERE, 'metrics.npz'), **measures)
+    if sys.argv[1:] == ['metrics']:
+        return
     default, chunk_plans, variants = {}, {}, {}
     state = capture_default(default)
     capture_chunks(chunk_plans)

@@ -901,17 +901,24 @@ def test_word_metrics(loss):
 
 @pytest.mark.parametrize('rate', [8000, 22050, 44100, 48000])
 def test_resample(rate):
-    """emph_resample against the host restatement of torchaudio's Resample
-    (`load.resample`: strided conv1d with the same kernel table), float32 and
-    16-bit PCM input, a ragged batch of three utterances."""
+    """emph_resample against oracle/resample.py (the independent per-sample
+    float64 restatement of torchaudio's Resample, itself anchored on closed-form
+    answers in tests/test_oracle.py): float32 and 16-bit PCM input, a ragged
+    batch of utterances incl. one of 5 and one of 1 sample, and a 1 kHz tone
+    whose amplitude and phase must come back."""
     import emphases_amd
     from emphases_amd import load
+    from oracle import resample as oracle_resample
     lib = runtime.library()
     kernel, orig, new, width = load.resample_kernel(rate)
-    lengths = [rate // 3 + 17, 5, rate // 2]
+    assert (orig, new) == oracle_resample.reduced(rate, 16000)
+    lengths = [rate // 3 + 17, 5, rate // 2, 1]
     audios = [torch.from_numpy(synth.weights(200 + i, (n,), 0.9))
               for i, n in enumerate(lengths)]
-    targets = [load.resampled_length(n, orig, new) for n in lengths]
+    audios[2] = torch.from_numpy(np.sin(
+        2 * np.pi * 1000. * np.arange(lengths[2]) / rate).astype(np.float32))
+    targets = [oracle_resample.output_length(n, rate, 16000) for n in lengths]
+    assert targets == [load.resampled_length(n, orig, new) for n in lengths]
     table = np.stack([np.cumsum([0] + lengths)[:-1], lengths,
                       np.cumsum([0] + targets)[:-1], targets], axis=1)
     table_dev = torch.from_numpy(table.astype(np.int64)).to(DEVICE)
@@ -934,17 +941,88 @@ def test_resample(rate):
         assert float(out[sum(targets):].min()) == 7.0
         cursor = 0
         for audio, count in zip(reference, targets):
-            want = load.resample(audio[None], rate)[0]
+            want = oracle_resample.resample(audio.numpy(), rate)
             assert want.shape == (count,)
-            got = out[cursor:cursor + count]
-            assert float((got - want).abs().max()) < 2e-6
+            got = out[cursor:cursor + count].numpy().astype(np.float64)
+            assert np.abs(got - want).max() < 2e-6
             cursor += count
-    # through the public API: device resampling == host resampling first
+        # closed form: the tone keeps its phase and (to the filter's 4e-4
+        # passband ripple) its amplitude
+        first = sum(targets[:2])
+        tone = out[first:first + targets[2]].numpy()[2000:6000]
+        want = np.sin(2 * np.pi * 1000. * np.arange(2000, 6000) / 16000.)
+        assert np.abs(tone - want * (32767. / 32768. if pcm else 1.)).max() < 6e-4
+    # through the public API: resampled on the device == the oracle's
+    # resampling first, then the 16 kHz path
     frames = 240
     words = emphases_amd.Alignment.from_frames(synth.word_frames(9, frames))
     native = torch.from_numpy(synth.weights(77, (1, frames * rate // 100), 0.3))
     on_device = emphases_amd.from_alignment_and_audio(words, native, rate)
-    on_host = emphases_amd.from_alignment_and_audio(
-        words, load.resample(native, rate), 16000)
+    resampled = torch.from_numpy(oracle_resample.resample(
+        native[0].numpy(), rate).astype(np.float32))[None]
+    on_host = emphases_amd.from_alignment_and_audio(words, resampled, 16000)
     assert on_device.shape == on_host.shape == (1, len(words))
     assert float((on_device - on_host).abs().max()) < 1e-5
+
+
+def test_resample_many_utterances():
+    """More utterances than a grid's y dimension holds (65 535)."""
+    from emphases_amd import load
+    from oracle import resample as oracle_resample
+    lib = runtime.library()
+    rate, count, length = 8000, 70000, 6
+    kernel, orig, new, width = load.resample_kernel(rate)
+    audio = torch.from_numpy(synth.weights(31, (count * length,), 0.9))
+    starts = np.arange(count) * length
+    table = np.stack([starts, np.full(count, length), starts * 2,
+                      np.full(count, length * 2)], axis=1).astype(np.int64)
+    out = torch.zeros(count * length * 2, device=DEVICE)
+    runtime.check(lib.emph_resample(
+        audio.to(DEVICE).data_ptr(), 0, torch.from_numpy(table).to(DEVICE).data_ptr(),
+        count, length * 2, kernel.reshape(new, -1).contiguous().to(DEVICE).data_ptr(),
+        orig, new, width, out.data_ptr(), None), 'emph_resample')
+    out = out.cpu().numpy().reshape(count, length * 2)
+    for index in (0, 1, 65534, 65535, 65536, count - 1):
+        want = oracle_resample.resample(
+            audio[index * length:(index + 1) * length].numpy(), rate)
+        assert np.abs(out[index] - want).max() < 2e-6, index
+
+
+@pytest.mark.parametrize('loss', ['bce', 'mse'])
+def test_word_metrics_match_reference(loss):
+    """emphases_amd.metrics (emph_word_metrics) against what the reference's
+    own `Statistics` / `Metrics` produced (tests/golden/metrics.npz,
+    evaluate/metrics.py:12-110 run by tests/golden/generate.py)."""
+    import os
+    from emphases_amd import metrics as metrics_module
+    golden = np.load(os.path.join(
+        os.path.dirname(__file__), 'golden', 'metrics.npz'))
+    count = int(golden[f'{loss}/batches'])
+    batches = [tuple(torch.from_numpy(golden[f'{loss}/{i}/{key}'])
+                     for key in ('logits', 'targets', 'word_lengths'))
+               for i in range(count)]
+    predicted = metrics_module.Statistics(0)
+    target = metrics_module.Statistics(0)
+    for logits, targets, lengths in batches:
+        scores = torch.sigmoid(logits) if loss == 'bce' else logits.clamp(0., 1.)
+        predicted.update(scores, lengths)
+        target.update(targets, lengths)
+    np.testing.assert_allclose(
+        predicted(), golden[f'{loss}/predicted_stats'], rtol=1e-6)
+    np.testing.assert_allclose(
+        target(), golden[f'{loss}/target_stats'], rtol=1e-6)
+    # (the reference hands the Statistics objects over; so do we)
+    total = metrics_module.Metrics(predicted, target, gpu=0, loss=loss)
+    single = metrics_module.Metrics(predicted, target, gpu=0, loss=loss)
+    for index, (logits, targets, lengths) in enumerate(batches):
+        single.reset()
+        single.update(logits, targets, lengths)
+        total.update(logits, targets, lengths)
+        got = single()
+        np.testing.assert_allclose(
+            [got['pearson_correlation'], got['bce'], got['mse']],
+            golden[f'{loss}/{index}/result'], rtol=3e-6, atol=2e-7)
+    got = total()
+    np.testing.assert_allclose(
+        [got['pearson_correlation'], got['bce'], got['mse']],
+        golden[f'{loss}/result'], rtol=3e-6, atol=2e-7)

@@ -622,6 +622,40 @@ def test_session_pipeline_pcm_and_layout_cache(default_engine):
         torch.cat([s.reshape(-1) for s in on_device]).cpu(), want[0])
 
 
+def test_mixed_sample_formats_in_one_batch(default_engine):
+    """int16 is 16-bit PCM wherever it appears: a batch mixing int16, float32
+    and float64 tensors (host and device) gives every utterance the bits of
+    the all-float32 batch, also when the call is split into sub-batches."""
+    from emphases_amd import session as session_module
+    session = session_module.Session(default_engine, depth=2)
+    frames = [400, 1000, 57, 720, 250]
+    aligns = [emphases_amd.Alignment.from_frames(synth.word_frames(40 + i, n))
+              for i, n in enumerate(frames)]
+    pcm = [np.rint(synth.audio(50 + i, n) * 32768.).clip(-32768, 32767).astype(
+        np.int16) for i, n in enumerate(frames)]
+    floats = [torch.from_numpy(p.astype(np.float32) / 32768.) for p in pcm]
+    want = torch.cat([s.reshape(-1) for s in session.run(aligns, floats)])
+    all_pcm = torch.cat([s.reshape(-1) for s in session.run(
+        aligns, [torch.from_numpy(p) for p in pcm])])
+    assert torch.equal(all_pcm, want)
+    mixed = [torch.from_numpy(pcm[0]), floats[1], torch.from_numpy(pcm[2]).cuda(),
+             floats[3].to(torch.float64), floats[4].cuda()]
+    got = torch.cat([s.reshape(-1) for s in session.run(aligns, mixed)])
+    assert torch.equal(got, want)
+    got = torch.cat([s.reshape(-1) for s in
+                     emphases_amd.from_alignments_and_audios(aligns, mixed)])
+    assert torch.equal(got, want)
+    # a producer still running on the caller's stream when the batch is
+    # submitted: the lane must wait for it
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(20_000_000)
+        late = [f.cuda(non_blocking=True) * 1.0 for f in floats]
+        got = torch.cat([s.reshape(-1) for s in session.run(
+            aligns, late, on_device=True)])
+    assert torch.equal(got.cpu(), want)
+
+
 def test_large_call_runs_as_sub_batches(default_engine, monkeypatch):
     """A synchronous call with more audio than 2 x session.SPLIT_BYTES runs as
     consecutive sub-batches over the lanes (kernels of one under the transfer

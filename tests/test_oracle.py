@@ -1,5 +1,7 @@
 """CPU: the oracle against the golden vectors captured from the reference
 (tests/golden/generate.py), and the known answers of SURVEY.md App. E."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -155,3 +157,118 @@ def test_metrics_restatement_known_answers():
     clamped.update(torch.tensor([[[2., -3.]]]), torch.tensor([[[1., 0.]]]),
                    torch.tensor([2]))
     assert abs(clamped()['mse']) < 1e-12          # clamp(2)=1, clamp(-3)=0
+
+
+###############################################################################
+# resampling (torchaudio is third-party and absent: the
+# restatement is anchored on closed-form answers)
+###############################################################################
+
+
+def windowed_sinc_gain(nu):
+    """Continuous-time frequency response of sinc(u) hann(u), |u| < 6, at nu =
+    f / (cut-off): the integral of sin(pi u)/(pi u) (1 + cos(pi u / 6))/2
+    cos(pi nu u) du over [-6, 6], written with sine integrals."""
+    from scipy.special import sici
+    a = 6 * np.pi
+    si = lambda x: sici(x)[0]        # noqa: E731
+    return (si(a * (1 + nu)) + si(a * (1 - nu))) / (2 * np.pi) + (
+        si(a * (1 + nu + 1 / 6)) + si(a * (1 + nu - 1 / 6)) +
+        si(a * (1 - nu + 1 / 6)) + si(a * (1 - nu - 1 / 6))) / (4 * np.pi)
+
+
+RATES = [8000, 22050, 44100, 48000]
+
+
+@pytest.mark.parametrize('rate', RATES)
+def test_resample_known_answers(rate):
+    """oracle/resample.py: output lengths, DC gain and the amplitude / phase
+    of a 1 kHz sinusoid against the closed-form response of the Hann-windowed
+    sinc (zero phase: the filter is symmetric).  When upsampling, the image of
+    DC at the input rate sits in the transition band and leaves a 4e-4 ripple
+    (a property of the filter, not of the restatement)."""
+    from oracle import resample as oracle_resample
+    for length in (0, 1, 5, rate // 3 + 17, rate):
+        got = oracle_resample.resample(np.zeros(length), rate)
+        assert len(got) == -(-16000 * length // rate) == \
+            oracle_resample.output_length(length, rate, 16000)
+    count = rate // 2
+    interior = slice(2000, 6000)             # of the 8000 output samples
+    dc = oracle_resample.resample(np.ones(count), rate)[interior]
+    ripple = {8000: 5e-4, 22050: 1e-4}.get(rate, 5e-6)
+    assert np.abs(dc - windowed_sinc_gain(0.)).max() < ripple
+    tone = np.sin(2 * np.pi * 1000. * np.arange(count) / rate)
+    got = oracle_resample.resample(tone, rate)
+    cutoff = min(rate, 16000) * 0.99 / 2
+    want = windowed_sinc_gain(1000. / cutoff) * np.sin(
+        2 * np.pi * 1000. * np.arange(len(got)) / 16000.)
+    assert np.abs(got[interior] - want[interior]).max() < 1e-4
+    assert abs(windowed_sinc_gain(1000. / cutoff) - 1) < 5e-4
+    # an impulse comes back as the filter itself (peak base / orig at its time)
+    impulse = np.zeros(64 * rate // math.gcd(rate, 16000))
+    impulse[len(impulse) // 2] = 1.
+    response = oracle_resample.resample(impulse, rate)
+    orig, new = oracle_resample.reduced(rate, 16000)
+    assert abs(response.max() - np.float32(min(orig, new) * 0.99 / orig)) < 1e-7
+    assert response.argmax() == (len(impulse) // 2) * new // orig
+
+
+@pytest.mark.parametrize('rate', RATES)
+def test_host_resample_matches_oracle(rate):
+    """The product's host resampler (`emphases_amd.load.resample`, file
+    plumbing) against the independent restatement."""
+    from emphases_amd import load
+    from oracle import resample as oracle_resample
+    for index, length in enumerate((rate // 3 + 17, 5, 1)):
+        audio = synth.weights(200 + index, (length,), 0.9)
+        got = load.resample(torch.from_numpy(audio)[None], rate)[0].numpy()
+        want = oracle_resample.resample(audio, rate)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < 1e-6
+
+
+###############################################################################
+# evaluation metrics against the reference's own run (tests/golden/metrics.npz)
+###############################################################################
+
+
+@pytest.mark.parametrize('loss', ['bce', 'mse'])
+def test_metrics_restatement_matches_reference(loss):
+    """oracle/metrics.py against what the reference's own `Statistics` /
+    `Metrics.update` (evaluate/metrics.py:12-110) produced on seeded ragged
+    batches: per-word BCE and squared-error values, per-batch and running
+    results."""
+    import os
+    from oracle import metrics
+    golden = np.load(os.path.join(
+        os.path.dirname(__file__), 'golden', 'metrics.npz'))
+    count = int(golden[f'{loss}/batches'])
+    batches = [tuple(torch.from_numpy(golden[f'{loss}/{i}/{key}'])
+                     for key in ('logits', 'targets', 'word_lengths'))
+               for i in range(count)]
+    predicted, target = [], []
+    for logits, targets, lengths in batches:
+        mask = metrics.mask_from_lengths(lengths)
+        predicted += metrics.postprocess(logits, loss)[mask].tolist()
+        target += targets[mask].tolist()
+    stats_p, stats_t = metrics.mean_std(predicted), metrics.mean_std(target)
+    np.testing.assert_allclose(stats_p, golden[f'{loss}/predicted_stats'], rtol=1e-12)
+    np.testing.assert_allclose(stats_t, golden[f'{loss}/target_stats'], rtol=1e-12)
+    total = metrics.Metrics(stats_p, stats_t, loss)
+    for index, (logits, targets, lengths) in enumerate(batches):
+        single = metrics.Metrics(stats_p, stats_t, loss)
+        single.update(logits, targets, lengths)
+        total.update(logits, targets, lengths)
+        got = single()
+        want = golden[f'{loss}/{index}/result']
+        np.testing.assert_allclose(
+            [got['pearson_correlation'], got['bce'], got['mse']], want,
+            rtol=2e-6, atol=1e-7)
+        values = metrics.word_values(logits, targets, lengths, loss)
+        assert np.array_equal(values[0].numpy(), golden[f'{loss}/{index}/bce_values'])
+        assert np.array_equal(
+            values[1].numpy(), golden[f'{loss}/{index}/squared_errors'])
+    got = total()
+    np.testing.assert_allclose(
+        [got['pearson_correlation'], got['bce'], got['mse']],
+        golden[f'{loss}/result'], rtol=2e-6, atol=1e-7)

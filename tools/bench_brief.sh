@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/bench_brief.sh [bench args]  -> one short line
-python bench.py --steps 50 --warmup 10 --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "
+python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-side --no-api "$@" 2>&1 | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 r=d['roofline']
