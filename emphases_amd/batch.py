@@ -180,6 +180,19 @@ def plan_batch(alignments, lengths, batch_size=None):
         bounds[:, selected], offsets, lengths)
 
 
+def score_counts(alignments, lengths, batch_size=None):
+    """Scores each utterance will have: its words minus those of chunks the
+    reference drops (`core.py:414-415`) - known from the plan alone, before
+    anything is computed (what a sharded run sizes its one score exchange
+    from, `dist.exchange_counts`)."""
+    plan = plan_batch(alignments, lengths, batch_size)
+    if not len(plan):
+        return np.zeros(len(lengths), dtype=np.int64)
+    return np.bincount(
+        plan.utterance, weights=plan.words,
+        minlength=len(lengths)).astype(np.int64)
+
+
 def _round_up(value, multiple):
     return (value + multiple - 1) // multiple * multiple
 

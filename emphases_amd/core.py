@@ -47,18 +47,23 @@ def active_config():
 
 
 @functools.lru_cache(maxsize=8)
-def _engine(checkpoint, device_index, config):
-    return engine_module.Engine(config, checkpoint, device_index)
+def _engine(checkpoint, device_index, config, conv_tile=None):
+    return engine_module.Engine(
+        config, checkpoint, device_index, conv_tile=conv_tile)
 
 
-def get_engine(checkpoint=None, gpu=None, config=None):
-    """Cached `Engine` per (checkpoint, device, config) — the explicit form of
-    the reference's function-attribute cache (`core.py:298-315`)."""
+def get_engine(checkpoint=None, gpu=None, config=None, conv_tile=None):
+    """Cached `Engine` per (checkpoint, device, config, conv_tile) — the
+    explicit form of the reference's function-attribute cache
+    (`core.py:298-315`).  `conv_tile`: positions per frame-rate conv tile
+    (64 / 32 / 16); None lets `Engine.frame_tile` pick by batch size.  Scores
+    of different tiles agree to 1e-6, scores of the same tile are bitwise
+    reproducible whatever else is in the batch: sharded runs pin it."""
     device = runtime.require_gpu(gpu)
     index = device.index if device.index is not None else \
         torch.cuda.current_device()
     checkpoint = None if checkpoint is None else os.fspath(checkpoint)
-    return _engine(checkpoint, index, config or active_config())
+    return _engine(checkpoint, index, config or active_config(), conv_tile)
 
 
 ###############################################################################
@@ -100,24 +105,26 @@ def _tracks(engine, plan, audios, pitch_tracker, gpu):
 
 
 @functools.lru_cache(maxsize=8)
-def _session(checkpoint, device_index, config):
+def _session(checkpoint, device_index, config, conv_tile=None):
     from . import session
-    return session.Session(_engine(checkpoint, device_index, config), depth=2)
+    return session.Session(
+        _engine(checkpoint, device_index, config, conv_tile), depth=2)
 
 
-def get_session(checkpoint=None, gpu=None, config=None):
+def get_session(checkpoint=None, gpu=None, config=None, conv_tile=None):
     """Cached `session.Session` (batches in flight on their own streams) of
     the cached engine."""
     device = runtime.require_gpu(gpu)
     index = device.index if device.index is not None else \
         torch.cuda.current_device()
     checkpoint = None if checkpoint is None else os.fspath(checkpoint)
-    return _session(checkpoint, index, config or active_config())
+    return _session(checkpoint, index, config or active_config(), conv_tile)
 
 
 def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
                                checkpoint=None, batch_size=None, gpu=None,
-                               config=None, pitch_tracker=None):
+                               config=None, pitch_tracker=None,
+                               conv_tile=None):
     """Scores for many utterances in one ragged batch.
 
     audios: float tensors [1, S] (or [S]); int16 tensors are taken as 16-bit
@@ -128,7 +135,7 @@ def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
         `(chunk audio [1, Sc]) -> (pitch [1, Fc] Hz, periodicity [1, Fc])`;
         default: `penn` itself, if installed.
     Returns a list of float32 tensors [1, W_i] (CPU if `gpu is None`)."""
-    session = get_session(checkpoint, gpu, config)
+    session = get_session(checkpoint, gpu, config, conv_tile)
     return session.run(
         alignments, audios, sample_rate, batch_size,
         on_device=gpu is not None, pitch_tracker=pitch_tracker)
@@ -193,38 +200,32 @@ def from_file_to_file(text_file, audio_file, output_prefix=None,
     _save(alignment_module.Alignment(text_file), scores, output_prefix)
 
 
-def from_files_to_files(text_files, audio_files, output_prefixes=None,
-                        checkpoint=None, batch_size=None, gpu=None,
-                        utterances_per_batch=64):
-    """`core.py:115-179`, but the files are processed in ragged batches of
-    `utterances_per_batch` instead of one at a time, two batches in flight:
-    the files of batch i+1 are read and staged while batch i computes, and
-    16-bit PCM files travel to the device as 16-bit PCM."""
-    from pathlib import Path
+def files_to_scores(text_files, audio_files, session, batch_size=None,
+                    utterances_per_batch=64, deliver=None):
+    """The loop of `core.py:169-179` over ragged batches of
+    `utterances_per_batch` files, two batches in flight: the files of batch
+    i+1 are read and staged while batch i computes, 16-bit PCM files travel to
+    the device as 16-bit PCM, files that are not at 16 kHz are resampled on
+    the device (one submission per sample rate).  `deliver(index, alignment,
+    scores)` is called for every file, in order within a batch."""
     text_files, audio_files = list(text_files), list(audio_files)
-    if output_prefixes is None:
-        output_prefixes = [Path(file).stem for file in text_files]
     for file in text_files:
         if not str(file).endswith(('.TextGrid', '.json')):
             from_text_and_audio(None, None, None)
-    session = get_session(checkpoint, gpu)
     in_flight = []
 
     def finish(jobs):
-        for pending, alignments, prefixes in jobs:
-            for item, scores, prefix in zip(
-                    alignments, pending.result(), prefixes):
-                _save(item, scores, prefix)
+        for pending, alignments, indices in jobs:
+            for item, scores, index in zip(
+                    alignments, pending.result(), indices):
+                deliver(index, item, scores)
 
     for first in range(0, len(text_files), utterances_per_batch):
-        last = first + utterances_per_batch
+        last = min(first + utterances_per_batch, len(text_files))
         alignments = [
             alignment_module.Alignment(file)
             for file in text_files[first:last]]
         loaded = [load.wav(file, raw=True) for file in audio_files[first:last]]
-        prefixes = output_prefixes[first:last]
-        # one submission per sample rate (files that are not at 16 kHz are
-        # resampled on the device, a rate at a time)
         jobs = []
         for rate in sorted({rate for _, rate in loaded}):
             chosen = [i for i, (_, r) in enumerate(loaded) if r == rate]
@@ -232,10 +233,27 @@ def from_files_to_files(text_files, audio_files, output_prefixes=None,
             jobs.append((
                 session.submit(
                     picked, [loaded[i][0] for i in chosen], rate, batch_size),
-                picked, [prefixes[i] for i in chosen]))
+                picked, [first + i for i in chosen]))
         finish(in_flight)
         in_flight = jobs
     finish(in_flight)
+
+
+def from_files_to_files(text_files, audio_files, output_prefixes=None,
+                        checkpoint=None, batch_size=None, gpu=None,
+                        utterances_per_batch=64, conv_tile=None):
+    """`core.py:115-179`, but the files are processed in ragged batches of
+    `utterances_per_batch` instead of one at a time, two batches in flight
+    (`files_to_scores`).  On several GPUs: `dist.from_files_to_files`."""
+    from pathlib import Path
+    text_files, audio_files = list(text_files), list(audio_files)
+    if output_prefixes is None:
+        output_prefixes = [Path(file).stem for file in text_files]
+    session = get_session(checkpoint, gpu, None, conv_tile)
+    files_to_scores(
+        text_files, audio_files, session, batch_size, utterances_per_batch,
+        lambda index, item, scores: _save(
+            item, scores, output_prefixes[index]))
 
 
 ###############################################################################

@@ -71,6 +71,41 @@ def wav(file, raw=False):
         np.ascontiguousarray(values.reshape(-1, channels).T)), rate
 
 
+def wav_info(file):
+    """(sample rate, channels, samples per channel) from the headers of a
+    RIFF/WAVE file alone: the chunk list is walked with seeks, the samples are
+    not read (what a sharded run plans from, `dist.from_files_to_files`)."""
+    with open(file, 'rb') as handle:
+        head = handle.read(12)
+        if head[:4] != b'RIFF' or head[8:12] != b'WAVE':
+            raise ValueError(f'{file} is not a RIFF/WAVE file')
+        fmt = None
+        while True:
+            header = handle.read(8)
+            if len(header) < 8:
+                break
+            tag, size = header[:4], struct.unpack('<I', header[4:])[0]
+            if tag == b'fmt ':
+                body = handle.read(size)
+                _, channels, rate, _, _, bits = struct.unpack(
+                    '<HHIIHH', body[:16])
+                fmt = (rate, channels, bits)
+                handle.seek(size & 1, 1)
+            elif tag == b'data':
+                if fmt is None:
+                    break
+                rate, channels, bits = fmt
+                # (a data chunk that claims more than the file holds: `wav`
+                # reads what is there)
+                here = handle.tell()
+                handle.seek(0, 2)
+                size = min(size, handle.tell() - here)
+                return rate, channels, size // (bits // 8) // channels
+            else:
+                handle.seek(size + (size & 1), 1)
+    raise ValueError(f'{file} has no fmt/data chunk')
+
+
 def save_wav(file, audio, sample_rate=cfg.SAMPLE_RATE):
     """Write float audio [channels, samples] as 16-bit PCM."""
     audio = np.asarray(audio, dtype=np.float32)

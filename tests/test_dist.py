@@ -113,3 +113,139 @@ def test_more_ranks_than_utterances():
     for rank, _, worst, shapes, words in results:
         assert worst == 0.0
         assert shapes == [(1, w) for w in words]
+
+
+###############################################################################
+# Sharded file API (dist.from_files_to_files)
+###############################################################################
+
+
+FILE_FRAMES = (300, 120, 450, 80, 200, 260, 90)
+FILE_RATES = (16000, 16000, 8000, 16000, 16000, 22050, 16000)
+
+
+def _write_corpus(directory):
+    """Seeded WAV + TextGrid files; two of them not at 16 kHz."""
+    import emphases_amd
+    from emphases_amd import load, synth
+    texts, audios = [], []
+    for index, (frames, rate) in enumerate(zip(FILE_FRAMES, FILE_RATES)):
+        samples = frames * rate // 100
+        audio = synth.weights(900 + index, (1, samples), 0.4)
+        load.save_wav(directory / f'u{index}.wav', audio, rate)
+        emphases_amd.Alignment.from_frames(
+            synth.word_frames(index, frames, 3, 40)).save(
+                directory / f'u{index}.TextGrid')
+        texts.append(directory / f'u{index}.TextGrid')
+        audios.append(directory / f'u{index}.wav')
+    return texts, audios
+
+
+def _oracle_file(text_file, audio_file, state):
+    import emphases_amd
+    from emphases_amd import load
+    from oracle import prominence as oracle
+    from oracle import resample as oracle_resample
+    alignment = emphases_amd.Alignment(text_file)
+    audio, rate = load.wav(audio_file)
+    if rate != 16000:
+        audio = torch.from_numpy(oracle_resample.resample(
+            audio[0].numpy(), rate).astype(np.float32))[None]
+    return alignment, oracle.from_alignment_and_audio(
+        [(w.start(), w.end()) for w in alignment], audio, state)
+
+
+def _file_worker(rank, world, port, queue, directory):
+    from pathlib import Path
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from emphases_amd import load, weights
+        directory = Path(directory)
+        texts = [directory / f'u{i}.TextGrid' for i in range(len(FILE_FRAMES))]
+        audios = [directory / f'u{i}.wav' for i in range(len(FILE_FRAMES))]
+        prefixes = [directory / f'out_{world}_{i}'
+                    for i in range(len(FILE_FRAMES))]
+        state = {k: torch.from_numpy(v) for k, v in weights.load().items()}
+        read = []
+        original = load.wav
+
+        def tracking_wav(file, raw=False):
+            read.append(Path(file).name)
+            return original(file, raw)
+        load.wav = tracking_wav
+
+        def compute(own_text, own_audio, deliver):
+            for index, (text, audio) in enumerate(zip(own_text, own_audio)):
+                alignment, scores = _oracle_file(text, audio, state)
+                deliver(index, alignment, scores)
+
+        scores = edist.from_files_to_files(
+            texts, audios, prefixes, compute=compute)
+        queue.put((rank, sorted(read), [s.clone() for s in scores]))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_files_read_only_their_shard(tmp_path):
+    """dist.from_files_to_files under 2 gloo ranks (the oracle as compute):
+    planned from WAV headers alone, every rank reads the samples of its own
+    shard only, writes its own outputs, and both ranks get all scores - the
+    ones a single process computes."""
+    from emphases_amd import load, weights
+    texts, audios = _write_corpus(tmp_path)
+    for file, frames, rate in zip(audios, FILE_FRAMES, FILE_RATES):
+        assert load.wav_info(file) == (rate, 1, frames * rate // 100)
+    world = 2
+    context = mp.get_context('spawn')
+    queue = context.Queue()
+    port = _free_port()
+    workers = [context.Process(
+        target=_file_worker, args=(r, world, port, queue, str(tmp_path)))
+        for r in range(world)]
+    for worker in workers:
+        worker.start()
+    results = sorted([queue.get(timeout=240) for _ in workers],
+                     key=lambda item: item[0])
+    for worker in workers:
+        worker.join(timeout=60)
+        assert worker.exitcode == 0
+    # the shards: planned by frames at 16 kHz, disjoint, covering
+    frames = [edist.frames_at_16k(f * r // 100, r)
+              for f, r in zip(FILE_FRAMES, FILE_RATES)]
+    shards = edist.assign(edist.cost(frames), world)
+    for (rank, read, _), shard in zip(results, shards):
+        assert read == sorted(f'u{i}.wav' for i in shard)
+    state = {k: torch.from_numpy(v) for k, v in weights.load().items()}
+    torch.set_num_threads(1)       # the workers' setting: same summation order
+    for index, (text, audio) in enumerate(zip(texts, audios)):
+        alignment, want = _oracle_file(text, audio, state)
+        for _, _, scores in results:
+            assert scores[index].shape == (1, len(alignment))
+            assert torch.equal(scores[index], want)
+        saved = torch.load(tmp_path / f'out_{world}_{index}.pt')
+        assert torch.equal(saved, want)
+        assert (tmp_path / f'out_{world}_{index}.TextGrid').exists()
+
+
+def test_score_counts_follow_the_plan():
+    """batch.score_counts: words minus those of dropped chunks
+    (core.py:414-415), per utterance."""
+    import emphases_amd
+    from emphases_amd import batch
+    bounds = np.array([[0, 40, 42, 90], [40, 42, 90, 130]])
+    aligns = [emphases_amd.Alignment.from_frames(bounds),
+              emphases_amd.Alignment.from_frames(bounds)]
+    lengths = [130 * 160, 130 * 160]
+    assert batch.score_counts(aligns, lengths).tolist() == [4, 4]
+    # batch_size 10: the 2-frame word becomes a chunk shorter than the reflect
+    # pad and is dropped (tests/golden/chunks.npz short_chunk_b10)
+    counts = batch.score_counts(aligns, lengths, 10)
+    plan = batch.plan_batch(aligns, lengths, 10)
+    assert counts.tolist() == [int(plan.words[plan.utterance == u].sum())
+                               for u in range(2)]
+    assert counts.tolist() == [3, 3]
