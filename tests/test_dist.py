@@ -242,10 +242,10 @@ def test_score_counts_follow_the_plan():
               emphases_amd.Alignment.from_frames(bounds)]
     lengths = [130 * 160, 130 * 160]
     assert batch.score_counts(aligns, lengths).tolist() == [4, 4]
-    # batch_size 10: the 2-frame word becomes a chunk shorter than the reflect
-    # pad and is dropped (tests/golden/chunks.npz short_chunk_b10)
-    counts = batch.score_counts(aligns, lengths, 10)
-    plan = batch.plan_batch(aligns, lengths, 10)
+    # batch_size 0: every word its own chunk; the 2-frame word is shorter than
+    # the reflect pad and is dropped (tests/golden/chunks.npz dropped_chunk_b0)
+    counts = batch.score_counts(aligns, lengths, 0)
+    plan = batch.plan_batch(aligns, lengths, 0)
     assert counts.tolist() == [int(plan.words[plan.utterance == u].sum())
                                for u in range(2)]
     assert counts.tolist() == [3, 3]
