@@ -103,7 +103,7 @@ def exchange_scores(local_scores, all_counts, shards, group=None, device=None):
     if local_scores:
         flat = torch.cat(
             [score.reshape(-1).to(torch.float32) for score in local_scores])
-        payload[:flat.numel()] = flat.to(device, non_blocking=True)
+        payload[:flat.numel()] = flat.to(device)
     payloads = torch.empty(world * most, dtype=torch.float32, device=device)
     dist.all_gather_into_tensor(payloads, payload, group=group)
 

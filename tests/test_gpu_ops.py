@@ -977,10 +977,13 @@ def test_resample_many_utterances():
     table = np.stack([starts, np.full(count, length), starts * 2,
                       np.full(count, length * 2)], axis=1).astype(np.int64)
     out = torch.zeros(count * length * 2, device=DEVICE)
+    audio_dev = audio.to(DEVICE)
+    table_dev = torch.from_numpy(table).to(DEVICE)
+    kernel_dev = kernel.reshape(new, -1).contiguous().to(DEVICE)
     runtime.check(lib.emph_resample(
-        audio.to(DEVICE).data_ptr(), 0, torch.from_numpy(table).to(DEVICE).data_ptr(),
-        count, length * 2, kernel.reshape(new, -1).contiguous().to(DEVICE).data_ptr(),
-        orig, new, width, out.data_ptr(), None), 'emph_resample')
+        audio_dev.data_ptr(), 0, table_dev.data_ptr(), count, length * 2,
+        kernel_dev.data_ptr(), orig, new, width, out.data_ptr(), None),
+        'emph_resample')
     out = out.cpu().numpy().reshape(count, length * 2)
     for index in (0, 1, 65534, 65535, 65536, count - 1):
         want = oracle_resample.resample(
