@@ -165,6 +165,26 @@ def physical_cores():
     return len(cores) or fallback
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1
+    cfs quota), or None when unlimited: 128 visible cores under a quota of a
+    few CPUs behave like those few."""
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as file:
+            quota, period = file.read().split()
+        return None if quota == 'max' else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as file:
+            quota = float(file.read())
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as file:
+            period = float(file.read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 def oracle_inputs(count=8):
     from emphases_amd import weights
     state = {k: torch.from_numpy(v) for k, v in weights.load().items()}
@@ -235,7 +255,7 @@ def cpu_baseline(seconds=4.0):
     """The CPU oracle (port of the reference's op sequence, B=1 loop exactly
     like `emphases/core.py:169-179`) on this box's host cores:
     in this process at 1 and at 8 torch threads (what the survey timed the
-    reference itself with), and as P single-thread PROCESSES for P = 8 and P =
+    reference itself with), and as P single-thread PROCESSES for P = 8, 32 and
     all physical cores — the reference's loop is sequential, so a corpus is
     spread over a host by running it once per core, and that is the number the
     GPU rate stands next to."""
@@ -258,7 +278,7 @@ def cpu_baseline(seconds=4.0):
                      'utterances': done, 'seconds': elapsed})
     torch.set_num_threads(min(8, physical))
     pools = []
-    for count in sorted({min(8, physical), physical}):
+    for count in sorted({min(8, physical), min(32, physical), physical}):
         try:
             pools.append(cpu_processes(count, seconds))
         except Exception as error:      # noqa: BLE001
@@ -286,7 +306,7 @@ def cpu_baseline(seconds=4.0):
         'processes': {str(p['processes']): p.get('value', p.get('error'))
                       for p in pools},
         'physical_cores': physical, 'logical_cores': os.cpu_count(),
-        'cpu': cpu_model(),
+        'cgroup_cpu_quota': cpu_quota(), 'cpu': cpu_model(),
         # BASELINE.md / SURVEY.md §6: the reference itself (bf16 autocast as
         # shipped), measured in the survey container (8 vCPU Xeon @2.1 GHz)
         'reference_survey': {

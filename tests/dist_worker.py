@@ -2,6 +2,7 @@
 tests/test_gpu_dist.py as a fresh child process; never imported by pytest).
 
     python tests/dist_worker.py <backend> <count> <low> <high> <out.pt>
+    python tests/dist_worker.py <backend> files <directory> <count> <out.pt>
 
 Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT like a
 torchrun worker, runs `emphases_amd.dist.from_alignments_and_audios` with the
@@ -28,7 +29,60 @@ def corpus(count, low, high):
     return aligns, audios
 
 
+def write_files(directory, count, low=200, high=3000):
+    """The seeded corpus as <directory>/u<i>.wav (16-bit PCM; every 7th file
+    at 8 kHz, every 11th at 22.05 kHz) + u<i>.TextGrid."""
+    import emphases_amd
+    from emphases_amd import load, synth
+    frames = synth.corpus_frames(count, low, high)
+    for index, n in enumerate(frames):
+        rate = 8000 if index % 7 == 3 else 22050 if index % 11 == 5 else 16000
+        samples = int(n) * rate // 100
+        if rate == 16000:
+            audio = synth.audio(500 + index, int(n))
+        else:
+            audio = synth.weights(700 + index, (1, samples), 0.3)
+        load.save_wav(os.path.join(directory, f'u{index}.wav'), audio, rate)
+        emphases_amd.Alignment.from_frames(
+            synth.word_frames(500 + index, int(n))).save(
+                os.path.join(directory, f'u{index}.TextGrid'))
+
+
+def file_lists(directory, count, tag):
+    texts = [os.path.join(directory, f'u{i}.TextGrid') for i in range(count)]
+    audios = [os.path.join(directory, f'u{i}.wav') for i in range(count)]
+    prefixes = [os.path.join(directory, f'{tag}_{i}') for i in range(count)]
+    return texts, audios, prefixes
+
+
+def files_main(backend, directory, count, out):
+    """`dist.from_files_to_files` on this rank; records which audio files this
+    process read the samples of."""
+    rank = int(os.environ['RANK'])
+    world = int(os.environ['WORLD_SIZE'])
+    from emphases_amd import dist as edist, load
+    torch.distributed.init_process_group(backend, rank=rank, world_size=world)
+    try:
+        read = []
+        original = load.wav
+
+        def tracking_wav(file, raw=False):
+            read.append(os.path.basename(str(file)))
+            return original(file, raw)
+        load.wav = tracking_wav
+        texts, audios, prefixes = file_lists(directory, count, f'w{world}')
+        scores = edist.from_files_to_files(texts, audios, prefixes)
+        torch.save({'scores': [s.cpu() for s in scores], 'read': sorted(read)},
+                   out)
+    finally:
+        torch.distributed.destroy_process_group()
+
+
 def main():
+    if sys.argv[2] == 'files':
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        return files_main(sys.argv[1], sys.argv[3], int(sys.argv[4]),
+                          sys.argv[5])
     backend, count, low, high, out = sys.argv[1:6]
     rank = int(os.environ['RANK'])
     world = int(os.environ['WORLD_SIZE'])

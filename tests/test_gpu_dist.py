@@ -28,17 +28,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(backend, world, tmp_path, count=COUNT):
+def _launch(backend, world, tmp_path, count=COUNT, files=None):
     port = _free_port()
     children = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank),
                    WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        out = tmp_path / f'{backend}_{rank}.pt'
+        out = tmp_path / f'{backend}_{world}_{rank}.pt'
+        arguments = [backend, str(count), str(LOW), str(HIGH), str(out)] \
+            if files is None else \
+            [backend, 'files', str(files), str(count), str(out)]
         children.append((out, subprocess.Popen(
-            [sys.executable, WORKER, backend, str(count), str(LOW),
-             str(HIGH), str(out)], env=env, cwd=ROOT)))
+            [sys.executable, WORKER] + arguments, env=env, cwd=ROOT)))
     results = []
     for out, child in children:
         assert child.wait(timeout=600) == 0
@@ -122,3 +124,39 @@ def test_bench_with_two_ranks(tmp_path):
     assert abs(line['value'] - 128 / (line['ms_per_step'] * 1e-3)) \
         < 1e-6 * line['value']
     assert line['roofline']['frac'] > 0 and 'cpu_baseline' not in line
+
+
+@pytest.mark.timeout(900)
+def test_sharded_file_api(tmp_path):
+    """dist.from_files_to_files (core.py:115-179 over a process group): 200
+    WAV + TextGrid files (some at 8 and 22.05 kHz), two gloo ranks sharing the
+    GPU and three ranks: every rank reads the samples of its own shard only,
+    writes its own outputs, and both the files and the gathered scores are
+    BITWISE those of one process (`emphases_amd.from_files_to_files` with the
+    same pinned conv tile) - shards of 100 and of 67 files alike."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import dist_worker
+    from emphases_amd import dist as edist, load
+    directory = tmp_path / 'corpus'
+    directory.mkdir()
+    dist_worker.write_files(str(directory), COUNT)
+    texts, audios, prefixes = dist_worker.file_lists(
+        str(directory), COUNT, 'single')
+    emphases_amd.from_files_to_files(
+        texts, audios, prefixes, gpu=0, conv_tile=edist.CONV_TILE)
+    want = [torch.load(f'{prefix}.pt') for prefix in prefixes]
+    assert all(w.dtype == torch.float32 and not w.is_cuda for w in want)
+    headers = [load.wav_info(file) for file in audios]
+    frames = [edist.frames_at_16k(samples, rate) for rate, _, samples in headers]
+    for world in (2, 3):
+        results = _launch('gloo', world, tmp_path, files=directory)
+        shards = edist.assign(edist.cost(frames), world)
+        for result, shard in zip(results, shards):
+            assert result['read'] == sorted(f'u{i}.wav' for i in shard)
+            assert len(result['scores']) == COUNT
+            for got, expect in zip(result['scores'], want):
+                assert torch.equal(got, expect)
+        for index in range(COUNT):
+            saved = torch.load(directory / f'w{world}_{index}.pt')
+            assert torch.equal(saved, want[index])
+            assert (directory / f'w{world}_{index}.TextGrid').exists()
