@@ -256,7 +256,8 @@ def cpu_baseline(seconds=4.0):
     like `emphases/core.py:169-179`) on this box's host cores:
     in this process at 1 and at 8 torch threads (what the survey timed the
     reference itself with), and as P single-thread PROCESSES for P = 8, 32 and
-    all physical cores — the reference's loop is sequential, so a corpus is
+    all physical cores (P = 8, the cgroup CPU quota and twice the quota when
+    the container has one: 128 visible cores under a 16-CPU quota collapse) — the reference's loop is sequential, so a corpus is
     spread over a host by running it once per core, and that is the number the
     GPU rate stands next to."""
     from oracle import prominence as oracle
@@ -278,7 +279,13 @@ def cpu_baseline(seconds=4.0):
                      'utterances': done, 'seconds': elapsed})
     torch.set_num_threads(min(8, physical))
     pools = []
-    for count in sorted({min(8, physical), min(32, physical), physical}):
+    quota = cpu_quota()
+    if quota:       # a cgroup CPU quota, not the visible cores, is the capacity
+        counts = {min(8, physical), min(physical, max(1, round(quota))),
+                  min(physical, max(1, round(2 * quota)))}
+    else:
+        counts = {min(8, physical), min(32, physical), physical}
+    for count in sorted(counts):
         try:
             pools.append(cpu_processes(count, seconds))
         except Exception as error:      # noqa: BLE001
@@ -291,8 +298,9 @@ def cpu_baseline(seconds=4.0):
         sample = (
             f"{best_pool['utterances']} x 10 s utterances in "
             f"{best_pool['seconds']:.1f} s by {cores} single-thread processes "
-            '(one per physical core), each looping oracle/prominence.py one '
-            'utterance at a time (B=1), torch CPU fp32')
+            f'side by side ({physical} physical cores visible, cgroup CPU '
+            f'quota {quota}), each looping oracle/prominence.py one utterance '
+            'at a time (B=1), torch CPU fp32')
     else:
         value, cores = best_run['value'], best_run['threads']
         sample = (
@@ -306,7 +314,7 @@ def cpu_baseline(seconds=4.0):
         'processes': {str(p['processes']): p.get('value', p.get('error'))
                       for p in pools},
         'physical_cores': physical, 'logical_cores': os.cpu_count(),
-        'cgroup_cpu_quota': cpu_quota(), 'cpu': cpu_model(),
+        'cgroup_cpu_quota': quota, 'cpu': cpu_model(),
         # BASELINE.md / SURVEY.md §6: the reference itself (bf16 autocast as
         # shipped), measured in the survey container (8 vCPU Xeon @2.1 GHz)
         'reference_survey': {

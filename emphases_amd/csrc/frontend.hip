@@ -258,6 +258,11 @@ __device__ __forceinline__ Chunk open_chunk(const void* audio, int64_t audio_off
 template <bool PCM>
 __device__ __forceinline__ void load_frame(const Chunk& chunk, int frame, int p, cf (&s)[8]) {
     const int first = frame * kHop - kPad;              // chunk position of sample 0
+#ifdef FX_NOLOAD
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] = {(p + 64 * q) * 1e-3f, frame * 1e-3f + q};
+    return;
+#endif
     if (first >= chunk.r_lo && first + kFft <= chunk.r_hi) {      // wave-uniform
         if (PCM) {
             const int16_t* source = static_cast<const int16_t*>(chunk.origin) + first;
@@ -619,7 +624,11 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
                 // (x + 10) / 10 as one fma: both within 1e-7 of the exact forms
                 float value = kLn2 * __builtin_amdgcn_logf(fmaxf(acc, 1e-5f));
                 if (normalize) value = fmaf(value, 0.1f, 1.f);
+#ifdef FX_NOTILE
+                out[static_cast<int64_t>(mel_row + lane) * ld + frame_off + frame0 + column] = value;
+#else
                 tile[lane * kTileStride + column] = value;
+#endif
                 acc = 0.f;
 #pragma unroll
                 for (int piece = 0; piece < kRunB / 4; ++piece) {
@@ -634,7 +643,11 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
                 if ((lane & 3) == 0) {
                     value = kLn2 * __builtin_amdgcn_logf(fmaxf(acc, 1e-5f));
                     if (normalize) value = fmaf(value, 0.1f, 1.f);
+#ifdef FX_NOTILE
+                    out[static_cast<int64_t>(mel_row + 64 + (lane >> 2)) * ld + frame_off + frame0 + column] = value;
+#else
                     tile[(64 + (lane >> 2)) * kTileStride + column] = value;
+#endif
                 }
             }
             frontend_fence();
@@ -642,7 +655,13 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
     }
 
     if (!kPeak) {
+#ifdef FX_NOTILE
+        if (false) {
+#elif defined(FX_NOSTORE)
+        if (kMel && n_tiles < 0) {
+#else
         if (kMel) {
+#endif
             // 80 rows x kWaveFrames frames: 4 * kWaveFrames-byte row segments
             const int column = lane & (kWaveFrames - 1);
 #pragma unroll 4
