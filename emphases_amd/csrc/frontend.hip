@@ -57,17 +57,9 @@ __device__ __forceinline__ void frontend_fence() {
 __device__ __forceinline__ void frontend_section() { __builtin_amdgcn_sched_barrier(0); }
 
 constexpr float kLn2 = 0.69314718055994530942f;
-#ifndef EMPH_FE_TILE
-#define EMPH_FE_TILE 8
-#endif
-constexpr int kWaveFrames = EMPH_FE_TILE;   // consecutive frames per wave = tile-table block
-#ifndef EMPH_FE_PAIR
-#define EMPH_FE_PAIR 1
-#endif
-#ifndef EMPH_FE_WAVES
-#define EMPH_FE_WAVES 3
-#endif
-constexpr int kPair = EMPH_FE_PAIR;  // frames a wave transforms at a time
+constexpr int kWaveFrames = 8;     // consecutive frames per wave = tile-table block
+constexpr int kPair = 1;           // frames a wave transforms at a time
+constexpr int kWavesPerSimd = 3;   // 168 VGPRs
 constexpr int kTileStride = kWaveFrames + 1;
 constexpr int kExRow = 72;                                     // complex per exchange row
 // Second exchange, C[r][t][p0] at r * kExRowB + t * kExStepB + p0: written by
@@ -76,10 +68,7 @@ constexpr int kExRow = 72;                                     // complex per ex
 // odd step 9 spreads t (or p0) over those 16: both directions are conflict free
 // (with rows of 8 the reads were 4-way conflicts: SQ_LDS_BANK_CONFLICT was 42 %
 // of the LDS-active cycles of this kernel).
-#ifndef EMPH_FE_ROWB
-#define EMPH_FE_ROWB 88
-#endif
-constexpr int kExRowB = EMPH_FE_ROWB;
+constexpr int kExRowB = 88;
 constexpr int kExStepB = 9;
 constexpr int kExFloats = 2 * 8 * kExRowB;                     // floats per frame slot
 // natural-order spectrum: 4 complex of padding after every 32 so that the
@@ -177,18 +166,39 @@ __device__ __forceinline__ cf sub_conj(cf a, cf b) {
     return r;
 }
 
+// c + k (-i a) = (c.x + k a.y, c.y - k a.x) and c - k (-i a), k a real scalar
+// given as the pair kk = (k, -k): one packed fma each (the rotation rides on
+// the operand selects, the sign of the second form on the negate modifiers)
+__device__ __forceinline__ cf fma_mi(cf a, cf kk, cf c) {
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1]"
+        : "=v"(r)
+        : "v"(a), "v"(kk), "v"(c));
+    return r;
+}
+__device__ __forceinline__ cf fms_mi(cf a, cf kk, cf c) {
+    cf r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0] "
+        "neg_hi:[0,1,0]"
+        : "=v"(r)
+        : "v"(a), "v"(kk), "v"(c));
+    return r;
+}
+
 // In-place forward DFT of 8 points, natural order in and out:
-// v[r] <- sum_q v[q] exp(-2 pi i q r / 8).  28 packed instructions.
+// v[r] <- sum_q v[q] exp(-2 pi i q r / 8).  26 packed instructions: the two
+// multiplications by W8 = (1 - i) / sqrt(2) and W8^3 are deferred into the fmas
+// of the last stage.
 __device__ __forceinline__ void dft8(cf v[8]) {
     constexpr float kH = 0.70710678118654752440f;
     const cf a0 = v[0] + v[4], b0 = v[0] - v[4];
     const cf a1 = v[1] + v[5], d1 = v[1] - v[5];
     const cf a2 = v[2] + v[6], b2 = v[2] - v[6];    // (b2 is used as -i b2 below)
     const cf a3 = v[3] + v[7], d3 = v[3] - v[7];
-    // b1 = W8 d1 = kH (d1.x + d1.y, d1.y - d1.x); b3 = W8^3 d3 = -kH (d3.x - d3.y,
-    // d3.x + d3.y)
-    const cf b1 = add_mi(d1, d1) * kH;
-    const cf b3 = sub_mi(d3, d3) * -kH;
+    // b1 = W8 d1 = kH (d1.x + d1.y, d1.y - d1.x) = kH p1; b3 = W8^3 d3 =
+    // -kH (d3.x - d3.y, d3.x + d3.y) = -kH p3
+    const cf p1 = add_mi(d1, d1);
+    const cf p3 = sub_mi(d3, d3);
     // DFT-4 of a -> even outputs
     cf e0 = a0 + a2, e1 = a0 - a2;
     cf o0 = a1 + a3, t = a1 - a3;
@@ -196,15 +206,17 @@ __device__ __forceinline__ void dft8(cf v[8]) {
     v[4] = e0 - o0;
     v[2] = add_mi(e1, t);
     v[6] = sub_mi(e1, t);
-    // DFT-4 of (b0, b1, -i b2, b3) -> odd outputs
+    // DFT-4 of (b0, b1, -i b2, b3) -> odd outputs, with b1 + b3 = kH (p1 - p3)
+    // and b1 - b3 = kH (p1 + p3)
     e0 = add_mi(b0, b2);
     e1 = sub_mi(b0, b2);
-    o0 = b1 + b3;
-    t = b1 - b3;
-    v[1] = e0 + o0;
-    v[5] = e0 - o0;
-    v[3] = add_mi(e1, t);
-    v[7] = sub_mi(e1, t);
+    o0 = p1 - p3;
+    t = p1 + p3;
+    const cf scale = {kH, kH}, rotate = {kH, -kH};
+    v[1] = o0 * scale + e0;
+    v[5] = e0 - o0 * scale;
+    v[3] = fma_mi(t, rotate, e1);
+    v[7] = fms_mi(t, rotate, e1);
 }
 
 // Sum over the four lanes of a quad on the DPP path (quad_perm [1,0,3,2] and
@@ -255,33 +267,57 @@ __device__ __forceinline__ Chunk open_chunk(const void* audio, int64_t audio_off
     return chunk;
 }
 
+// Samples of an INTERIOR frame (its 1024 samples all lie inside the audio that
+// backs the chunk): eight coalesced 8-byte loads (4-byte for 16-bit PCM) from
+// `source` = address of the frame's first sample.
 template <bool PCM>
-__device__ __forceinline__ void load_frame(const Chunk& chunk, int frame, int p, cf (&s)[8]) {
-    const int first = frame * kHop - kPad;              // chunk position of sample 0
-#ifdef FX_NOLOAD
+__device__ __forceinline__ void load_interior(const void* source, int p, cf (&s)[8]) {
+    if (PCM) {
+        const int16_t* samples = static_cast<const int16_t*>(source);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) s[q] = {(p + 64 * q) * 1e-3f, frame * 1e-3f + q};
-    return;
-#endif
-    if (first >= chunk.r_lo && first + kFft <= chunk.r_hi) {      // wave-uniform
-        if (PCM) {
-            const int16_t* source = static_cast<const int16_t*>(chunk.origin) + first;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                typedef uint32_t u32_u __attribute__((aligned(2)));
-                const uint32_t two = *reinterpret_cast<const u32_u*>(source + 2 * (p + 64 * q));
-                s[q] = {static_cast<float>(static_cast<int16_t>(two & 0xffffu)),
-                        static_cast<float>(static_cast<int16_t>(two >> 16))};
-            }
-        } else {
-            const float* source = static_cast<const float*>(chunk.origin) + first;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                s[q] = *reinterpret_cast<const cf_u*>(source + 2 * (p + 64 * q));
+        for (int q = 0; q < 8; ++q) {
+            typedef uint32_t u32_u __attribute__((aligned(2)));
+            const uint32_t two = *reinterpret_cast<const u32_u*>(samples + 2 * (p + 64 * q));
+            s[q] = {static_cast<float>(static_cast<int16_t>(two & 0xffffu)),
+                    static_cast<float>(static_cast<int16_t>(two >> 16))};
         }
-        return;
+    } else {
+        const float* samples = static_cast<const float*>(source);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            s[q] = *reinterpret_cast<const cf_u*>(samples + 2 * (p + 64 * q));
     }
-    // a frame at a chunk's (or the utterance's) end: reflect / zero per sample
+}
+
+// Is frame `frame` of the chunk interior, and where does it start?
+__device__ __forceinline__ bool frame_is_interior(const Chunk& chunk, int frame) {
+    const int first = frame * kHop - kPad;              // chunk position of sample 0
+    return first >= chunk.r_lo && first + kFft <= chunk.r_hi;
+}
+
+// Address the NEXT frame is requested from, one frame ahead and without a
+// branch: an interior frame's own samples; for a frame at a chunk's end (whose
+// samples `load_edge` fetches when its turn comes) any 1024 readable samples -
+// the nearest interior frame's, or the constant table when the chunk has none
+// (the table holds more than 1024 floats).  The prefetch is a single
+// unconditional definition of the sample registers: with the interior / edge
+// choice inside it, hipcc merged the two paths through 32 v_mov per frame.
+template <bool PCM>
+__device__ __forceinline__ const void* frame_source(const Chunk& chunk, int frame,
+                                                    const float* table) {
+    int first = frame * kHop - kPad;
+    const int highest = chunk.r_hi - kFft;
+    if (highest < chunk.r_lo) return table;
+    first = min(max(first, chunk.r_lo), highest);
+    return PCM ? static_cast<const void*>(static_cast<const int16_t*>(chunk.origin) + first)
+               : static_cast<const void*>(static_cast<const float*>(chunk.origin) + first);
+}
+
+// A frame at a chunk's (or the utterance's) end: reflect / zero per sample
+// (emphases/core.py:357-401 and mels.py:31-36).
+template <bool PCM>
+__device__ __forceinline__ void load_edge(const Chunk& chunk, int frame, int p, cf (&s)[8]) {
+    const int first = frame * kHop - kPad;
     const int safe = chunk.r_hi > chunk.r_lo ? chunk.r_lo : 0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -313,7 +349,7 @@ __device__ __forceinline__ void load_frame(const Chunk& chunk, int frame, int p,
 // what ships: 66.5 vs 68.7 us).
 template <int MODE, bool PCM>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend_kernel(
+__attribute__((amdgpu_waves_per_eu(kWavesPerSimd, kWavesPerSimd))) void frontend_kernel(
     const void* __restrict__ audio, const int64_t* __restrict__ seg,
     const int32_t* __restrict__ tiles, const float* __restrict__ table,
     const int32_t* __restrict__ mel_start, const int32_t* __restrict__ mel_count,
@@ -324,6 +360,9 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
     constexpr bool kMel = MODE == 0 || MODE == 2;
     constexpr bool kLoud = MODE == 2 || MODE == 3;
     constexpr bool kPeak = MODE == 1;
+    // what `power` carries on top of |X|^2: the magnitude's 1e-6 when nothing
+    // but the mel rows reads it
+    constexpr float kPowerFloor = MODE == 0 ? 1e-6f : 0.f;
 
     extern __shared__ __align__(16) float lds[];
     const int tid = threadIdx.x;
@@ -443,40 +482,35 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
         floor_db = top - 80.f;
     }
 
-    // samples of the first pair; every later pair is requested one iteration
-    // ahead (a global load takes 1-2 us under load: far longer than a pair's
-    // arithmetic could hide behind the transform's own LDS round trips)
-#ifndef EMPH_FE_PREFETCH
-#define EMPH_FE_PREFETCH 1
-#endif
-    constexpr bool kPrefetch = EMPH_FE_PREFETCH != 0;
+    // The samples of a frame are requested one frame ahead (a global load takes
+    // 1-2 us under load: far longer than the transform's own LDS round trips
+    // could cover), the first frame of a tile in front of the loop.
+    // (`transform` is called with the same set as `cur` and `next`: the frame is
+    // windowed out of it before the next frame's samples are requested into it)
     cf raw[kPair][8];
-    if (kPrefetch) {
 #pragma unroll
-        for (int f = 0; f < kPair; ++f)
-            // an odd tail repeats the last frame (its result is written twice)
-            load_frame<PCM>(chunk, frame0 + min(f, valid - 1), p, raw[f]);
-    }
-    for (int local = 0; local < valid; local += kPair) {
-        if (!kPrefetch) {
-#pragma unroll
-            for (int f = 0; f < kPair; ++f)
-                load_frame<PCM>(chunk, frame0 + min(local + f, valid - 1), p, raw[f]);
-        }
+    for (int f = 0; f < kPair; ++f)
+        // an odd tail repeats the last frame (its result is written twice)
+        load_interior<PCM>(frame_source<PCM>(chunk, frame0 + min(f, valid - 1), table), p,
+                           raw[f]);
+    auto transform = [&](cf (&cur)[kPair][8], cf (&next)[kPair][8], int local) {
         cf v[kPair][8];
         cf* ex[kPair];
 #pragma unroll
         for (int f = 0; f < kPair; ++f) {
+            const int frame = frame0 + min(local + f, valid - 1);
+            if (!frame_is_interior(chunk, frame))          // wave-uniform, rare
+                load_edge<PCM>(chunk, frame, p, cur[f]);
             ex[f] = reinterpret_cast<cf*>(exchange + f * kExFloats);
 #pragma unroll
             for (int q = 0; q < 8; ++q)
-                v[f][q] = raw[f][q] * cf{window[2 * q], window[2 * q + 1]};
+                v[f][q] = cur[f][q] * cf{window[2 * q], window[2 * q + 1]};
         }
-        if (kPrefetch && local + kPair < valid) {          // wave-uniform
 #pragma unroll
-            for (int f = 0; f < kPair; ++f)
-                load_frame<PCM>(chunk, frame0 + min(local + kPair + f, valid - 1), p, raw[f]);
-        }
+        for (int f = 0; f < kPair; ++f)
+            load_interior<PCM>(
+                frame_source<PCM>(chunk, frame0 + min(local + kPair + f, valid - 1), table), p,
+                next[f]);
         // Every exchange below is written frame by frame as
         //     compute(f); write(f); fence; read(f)
         // so that a frame's LDS round trip runs under the OTHER frame's
@@ -546,13 +580,24 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
                 if (u == 0) z = lane == 0 ? v[f][0] : z;
                 const cf e = add_conj(v[f][u], z);
                 const cf o = cmul(tw3[u], sub_conj(v[f][u], z));
-                const cf low = e + o, high = e - o;
-                power[f][u] = low.x * low.x + low.y * low.y;            // |X[k]|^2
-                power[f][4 + u] = high.x * high.x + high.y * high.y;    // |X[512 - k]|^2
+                // (|X[k]|^2, |X[512 - k]|^2) with X[k] = e + o, conj(X[512 - k]) =
+                // e - o, as real parts squared plus imaginary parts squared of the
+                // two bins side by side: four packed instructions for two powers.
+                // Where only the mel rows are wanted, the 1e-6 of the magnitude
+                // (mels.py:51) is the addend of the first of them.
+                cf real, imag;
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,0] neg_hi:[0,1]"
+                    : "=v"(real) : "v"(e), "v"(o));
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,1] neg_hi:[0,1]"
+                    : "=v"(imag) : "v"(e), "v"(o));
+                const cf floor = {kPowerFloor, kPowerFloor};
+                const cf both = imag * imag + (real * real + floor);
+                power[f][u] = both.x;
+                power[f][4 + u] = both.y;
             }
             // k = 256 pairs with itself: X[256] = conj(Z[256]) (lane 0 holds it, u = 4);
             // the window's 1/2 has to be undone there
-            power[f][8] = 4.f * (v[f][4].x * v[f][4].x + v[f][4].y * v[f][4].y);
+            power[f][8] = 4.f * (v[f][4].x * v[f][4].x + v[f][4].y * v[f][4].y) + kPowerFloor;
         }
         if (kPeak) {
 #pragma unroll
@@ -561,7 +606,7 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
                 for (int j = 0; j < 8; ++j) peak = fmaxf(peak, power[f][j]);
                 if (lane == 0) peak = fmaxf(peak, power[f][8]);
             }
-            continue;
+            return;
         }
 
         if (kLoud) {
@@ -599,8 +644,9 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
                 // correctly rounded sqrtf is ten more instructions per bin
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    mag[bin_of(j)] = __builtin_amdgcn_sqrtf(power[f][j] + 1e-6f);
-                if (lane == 0) mag[256] = __builtin_amdgcn_sqrtf(power[f][8] + 1e-6f);
+                    mag[bin_of(j)] = __builtin_amdgcn_sqrtf(power[f][j] + (1e-6f - kPowerFloor));
+                if (lane == 0)
+                    mag[256] = __builtin_amdgcn_sqrtf(power[f][8] + (1e-6f - kPowerFloor));
                 // zero tail: the fixed-length runs read past bin 512 (weight 0, but
                 // the buffer holds spectrum bits there: 0 * NaN would poison the sum)
                 if (lane < kMagFloats - kBins) mag[kBins + lane] = 0.f;
@@ -624,11 +670,7 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
                 // (x + 10) / 10 as one fma: both within 1e-7 of the exact forms
                 float value = kLn2 * __builtin_amdgcn_logf(fmaxf(acc, 1e-5f));
                 if (normalize) value = fmaf(value, 0.1f, 1.f);
-#ifdef FX_NOTILE
-                out[static_cast<int64_t>(mel_row + lane) * ld + frame_off + frame0 + column] = value;
-#else
                 tile[lane * kTileStride + column] = value;
-#endif
                 acc = 0.f;
 #pragma unroll
                 for (int piece = 0; piece < kRunB / 4; ++piece) {
@@ -643,25 +685,16 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
                 if ((lane & 3) == 0) {
                     value = kLn2 * __builtin_amdgcn_logf(fmaxf(acc, 1e-5f));
                     if (normalize) value = fmaf(value, 0.1f, 1.f);
-#ifdef FX_NOTILE
-                    out[static_cast<int64_t>(mel_row + 64 + (lane >> 2)) * ld + frame_off + frame0 + column] = value;
-#else
                     tile[(64 + (lane >> 2)) * kTileStride + column] = value;
-#endif
                 }
             }
             frontend_fence();
         }
-    }
+        };
+    for (int local = 0; local < valid; local += kPair) transform(raw, raw, local);
 
     if (!kPeak) {
-#ifdef FX_NOTILE
-        if (false) {
-#elif defined(FX_NOSTORE)
-        if (kMel && n_tiles < 0) {
-#else
         if (kMel) {
-#endif
             // 80 rows x kWaveFrames frames: 4 * kWaveFrames-byte row segments
             const int column = lane & (kWaveFrames - 1);
 #pragma unroll 4
@@ -687,12 +720,11 @@ __attribute__((amdgpu_waves_per_eu(EMPH_FE_WAVES, EMPH_FE_WAVES))) void frontend
     }
 }
 
-// two workgroups per CU (registers), each wave looping over its share of the tiles
+// three workgroups per CU (registers), each wave looping over its share of the tiles
 inline int frontend_grid(int n_tiles) {
     const int groups = (n_tiles + 3) / 4;
-    constexpr int resident = 256 * EMPH_FE_WAVES;
-    if (EMPH_FE_WAVES != 2) return groups < resident ? groups : resident;
-    return groups < 512 ? groups : 512;
+    constexpr int resident = 256 * kWavesPerSimd;
+    return groups < resident ? groups : resident;
 }
 
 size_t frontend_lds_bytes(bool loud) {

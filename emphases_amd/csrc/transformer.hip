@@ -363,18 +363,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // 32 distinct banks):
 //     K[d][64 keys]   row stride 80 floats  (A fragment: K[4 s + kk][key0 + col])
 //     V[key][D]       row stride D + 4      (A fragment: V[key0 + 4 kk + r][16 m + col])
-#ifndef EMPH_ATT_QT
-#define EMPH_ATT_QT 2        // 16-query tiles per wave: 4 (four waves) or 2 (eight)
-#endif
-constexpr int kGroupThreads = 256 * 4 / EMPH_ATT_QT;
+constexpr int kQueryTiles = 2;     // 16-query tiles per wave: eight waves of 32 queries
+constexpr int kGroupThreads = 256 * 4 / kQueryTiles;
 template <int D>
 __global__ __launch_bounds__(kGroupThreads)
-__attribute__((amdgpu_waves_per_eu(8 / EMPH_ATT_QT, 8 / EMPH_ATT_QT)))
+__attribute__((amdgpu_waves_per_eu(8 / kQueryTiles, 8 / kQueryTiles)))
 void attention_group_kernel(
     const float* __restrict__ qk, const float* __restrict__ v, float* __restrict__ out,
     int64_t ld, int channels, const int32_t* __restrict__ tiles,
     const int32_t* __restrict__ key_counts) {
-    constexpr int QT = EMPH_ATT_QT;       // 16-query tiles per wave
+    constexpr int QT = kQueryTiles;       // 16-query tiles per wave
     constexpr int THREADS = kGroupThreads;
     constexpr int KSTEPS = D / 4;
     constexpr int MT = (D + 15) / 16;

@@ -83,6 +83,19 @@ int main() {
     launch(); CHECK(hipDeviceSynchronize());
     std::vector<unsigned long long> host(slots);
     CHECK(hipMemcpy(host.data(), stamps, slots * 8, hipMemcpyDeviceToHost));
+#ifdef FX_CLOCK
+    {
+        double best = 0, sum = 0; size_t n = 0; double longest = 0;
+        for (size_t i = 0; i < slots; i += 16) {
+            if (!host[i + 3] || host[i + 3] == host[i + 2]) continue;
+            const double mhz = double(host[i + 1] - host[i]) / double(host[i + 3] - host[i + 2]) * 100.;
+            sum += mhz; ++n; best = std::max(best, mhz);
+            longest = std::max(longest, double(host[i + 3] - host[i + 2]) * 0.01);
+        }
+        printf("   shader clock during the kernel: mean %.0f MHz, max %.0f MHz over %zu waves; longest wave %.2f us\n", sum / n, best, n, longest);
+        return 0;
+    }
+#endif
     const char* names[16] = {"start", "tile", "top", "windowed", "nextload", "A T1", "B T1", "A T2", "B T2", "A hi", "B hi", "power", "mag wr", "A mel", "B mel", ""};
     for (int slot = 1; slot < 15; ++slot) {
         std::vector<double> values2;
