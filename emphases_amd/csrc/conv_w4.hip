@@ -46,12 +46,22 @@ struct Run6 {
 // POSITION: the layer is followed by PositionalEncoding (transformer.py:45-52) -
 // `position[c][t]`, channel-major with `max_positions` columns, is added to the
 // output at position t of its segment (after the activation).
-template <int M_TILES, bool POSITION>
-__global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
+//
+// HALF: the workgroup is ONE of the two halves - four waves (one per tile) that
+// own the upper (`half` = 0: ceil(m_tiles / 2)) or lower m-tiles, around THEIR
+// rows of the pack only (`pack` = that half's slice of emph_conv_winograd4_
+// split_pack: 92 KB and 61 KB for 80 x 80).  The two halves of a layer are
+// separate launches on two streams: nothing couples them (they read the same
+// input and write different output rows), so a compute unit holds the two halves
+// of DIFFERENT layers - of the two batches in flight - side by side, or one half
+// beside front-end workgroups, and one's weight transfer and store burst run
+// under the other's MFMAs instead of idling the matrix pipe.
+template <int M_TILES, bool POSITION, bool HALF>
+__global__ __launch_bounds__(HALF ? 256 : 512) void conv1d_winograd4_kernel(
     const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
     const float* __restrict__ pack, const float* __restrict__ bias, int c_in, int c_out,
     int act, const int32_t* __restrict__ tiles, int n_tiles, int bias_offset,
-    const float* __restrict__ position, int max_positions) {
+    const float* __restrict__ position, int max_positions, int half) {
     extern __shared__ __align__(16) float weights[];   // [groups][6][m_tiles][64]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -61,7 +71,8 @@ __global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
     constexpr int m_tiles = M_TILES;
     constexpr int split = (m_tiles + 1) >> 1;
     constexpr int MT = split;
-    const int part = wave >> 2;
+    constexpr int kThreads = HALF ? 256 : 512;
+    const int part = HALF ? half : wave >> 2;
     const int m_begin = part ? split : 0;
     const int m_count = part ? m_tiles - split : split;     // wave-uniform, <= MT
     float* bias_lds = weights + bias_offset;
@@ -96,16 +107,21 @@ __global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
     Run6 b0, b1;
     open_tile(blockIdx.x);
     {
-        const int quads = iterations * 6 * m_tiles * 16;
+        const int quads = iterations * 6 * (HALF ? m_count : m_tiles) * 16;
         // (480 quads per iteration: an odd iteration count ends in half a wave)
-        for (int base = wave * 64; base < quads; base += 512)
+        for (int base = wave * 64; base < quads; base += kThreads)
             if (base + lane < quads)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void*)(pack + 4 * (base + lane)),
                     (__attribute__((address_space(3))) void*)(weights + 4 * base), 16, 0, 0);
         if (active) load_b(b0, 0);
-        for (int index = threadIdx.x; index < m_tiles * 16; index += 512)
-            bias_lds[index] = (bias != nullptr && index < c_out) ? bias[index] : 0.f;
+        // (HALF: the half's own channels, bias_lds[i] = bias of channel 16 m_begin + i)
+        const int bias_first = HALF ? 16 * m_begin : 0;
+        for (int index = threadIdx.x; index < (HALF ? m_count : m_tiles) * 16;
+             index += kThreads)
+            bias_lds[index] = (bias != nullptr && bias_first + index < c_out)
+                                  ? bias[bias_first + index]
+                                  : 0.f;
         __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): LDS-DMA landed
         __syncthreads();
     }
@@ -129,12 +145,14 @@ __global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
 
         float a0[6][COUNT], av[6][COUNT], v[6];
         auto load_a = [&](int iteration) {
+            // (HALF: the image holds this half's COUNT m-tiles only)
+            constexpr int row = HALF ? COUNT : m_tiles;
             const float* fragment =
-                weights + ((iteration * 6 * m_tiles + m_begin) << 6) + lane;
+                weights + ((iteration * 6 * row + (HALF ? 0 : m_begin)) << 6) + lane;
 #pragma unroll
             for (int j = 0; j < 6; ++j)
 #pragma unroll
-                for (int m = 0; m < COUNT; ++m) a0[j][m] = fragment[(j * m_tiles + m) << 6];
+                for (int m = 0; m < COUNT; ++m) a0[j][m] = fragment[(j * row + m) << 6];
         };
         auto step = [&](Run6& b, int iteration) {
             float d[6];
@@ -195,7 +213,8 @@ __global__ __launch_bounds__(512) void conv1d_winograd4_kernel(
 #pragma unroll
         for (int m = 0; m < COUNT; ++m) {
             const int channel0 = 16 * (m_begin + m) + 4 * kk;
-            const f32x4 add = *reinterpret_cast<const f32x4*>(bias_lds + channel0);
+            const f32x4 add = *reinterpret_cast<const f32x4*>(
+                bias_lds + channel0 - (HALF ? 16 * m_begin : 0));
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float m1 = acc[1][m][r], m2 = acc[2][m][r];
@@ -285,10 +304,39 @@ int emph_conv_winograd4_pack(const float* host_weight, int32_t c_out, int32_t c_
     return EMPH_OK;
 }
 
+// The same pack cut into the two halves a split layer launches: half 0 = m-tiles
+// 0 .. ceil(m_tiles / 2) - 1 as [group][j][m][lane], then half 1 the same way.
+int emph_conv_winograd4_split_pack(const float* host_weight, int32_t c_out, int32_t c_in,
+                                   float* host_pack) {
+    EMPH_REQUIRE(host_weight && host_pack, EMPH_EINVAL,
+                 "emph_conv_winograd4_split_pack: null pointer");
+    const int64_t size = emph_conv_winograd4_pack_size(c_out, c_in);
+    float* whole = static_cast<float*>(malloc(static_cast<size_t>(size) * sizeof(float)));
+    EMPH_REQUIRE(whole != nullptr, EMPH_EINVAL, "emph_conv_winograd4_split_pack: out of memory");
+    const int status = emph_conv_winograd4_pack(host_weight, c_out, c_in, whole);
+    if (status == EMPH_OK) {
+        const int groups = (c_in + 3) / 4, m_tiles = (c_out + 15) / 16;
+        const int split = (m_tiles + 1) / 2;
+        float* cursor = host_pack;
+        for (int half = 0; half < 2; ++half) {
+            const int first = half ? split : 0, count = half ? m_tiles - split : split;
+            for (int group = 0; group < groups; ++group)
+                for (int j = 0; j < 6; ++j)
+                    for (int m = 0; m < count; ++m)
+                        for (int lane = 0; lane < 64; ++lane)
+                            *cursor++ = whole[(((static_cast<int64_t>(group) * 6 + j) * m_tiles +
+                                                first + m) << 6) + lane];
+        }
+    }
+    free(whole);
+    return status;
+}
+
 static int launch_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
                             const float* pack, const float* bias, int32_t c_in, int32_t c_out,
                             int32_t activation, const int32_t* tiles, int32_t n_tiles,
-                            const float* position, int32_t max_positions, void* stream) {
+                            const float* position, int32_t max_positions, int32_t half,
+                            void* stream) {
     if (n_tiles == 0) return EMPH_OK;
     EMPH_REQUIRE(x && y && pack && tiles, EMPH_EINVAL, "emph_conv1d_winograd4: null pointer");
     EMPH_REQUIRE(activation == EMPH_ACT_NONE || activation == EMPH_ACT_RELU, EMPH_ERANGE,
@@ -298,28 +346,39 @@ static int launch_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
                  c_in, c_out);
     EMPH_REQUIRE(position == nullptr || max_positions > 0, EMPH_EINVAL,
                  "emph_conv1d_winograd4_position: %d positions in the table", max_positions);
-    const size_t lds = static_cast<size_t>(emph_conv_winograd4_lds_bytes(c_out, c_in));
+    const int m_tiles = (c_out + 15) / 16;
+    EMPH_REQUIRE(half >= -1 && half <= 1 && (half < 0 || m_tiles >= 2), EMPH_ERANGE,
+                 "emph_conv1d_winograd4: half %d of %d m-tiles", half, m_tiles);
+    // (half < 0: the whole layer in one launch)
+    const int split = (m_tiles + 1) / 2;
+    const int own_tiles = half < 0 ? m_tiles : half ? m_tiles - split : split;
+    const int64_t per_tile = static_cast<int64_t>((c_in + 3) / 4) * 6 * 64;   // floats
+    const int bias_offset = static_cast<int>(per_tile * own_tiles);
+    const size_t lds = static_cast<size_t>(bias_offset + own_tiles * 16) * sizeof(float);
     EMPH_REQUIRE(lds <= 160 * 1024, EMPH_ERANGE,
                  "emph_conv1d_winograd4: %zu bytes of LDS needed", lds);
-    const int m_tiles = (c_out + 15) / 16;
-    const int bias_offset = static_cast<int>(emph_conv_winograd4_pack_size(c_out, c_in));
+    if (half == 1) pack += per_tile * split;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int groups = (n_tiles + 3) / 4;
-    dim3 grid(groups < 256 ? groups : 256);
-#define EMPH_W4_LAUNCH(M_TILES, POSITION)                                                      \
+    dim3 grid(groups < 256 || half >= 0 ? groups : 256);
+#define EMPH_W4_LAUNCH(M_TILES, POSITION, HALF)                                                \
     do {                                                                                       \
-        auto kernel = conv1d_winograd4_kernel<M_TILES, POSITION>;                              \
+        auto kernel = conv1d_winograd4_kernel<M_TILES, POSITION, HALF>;                        \
         static LdsReservation reserved;                                                        \
         if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,     \
                                      "emph_conv1d_winograd4"))                                 \
             return status;                                                                     \
-        EMPH_LAUNCH(kernel, grid, dim3(512), lds, s, x, ldx, y, ldy, pack, bias, c_in, c_out,  \
-                    activation, tiles, n_tiles, bias_offset, position, max_positions);         \
+        EMPH_LAUNCH(kernel, grid, dim3(HALF ? 256 : 512), lds, s, x, ldx, y, ldy, pack, bias,  \
+                    c_in, c_out, activation, tiles, n_tiles, bias_offset, position,            \
+                    max_positions, half);                                                      \
     } while (0)
 #define EMPH_W4(M_TILES)                                                                       \
     do {                                                                                       \
-        if (position != nullptr) EMPH_W4_LAUNCH(M_TILES, true);                                \
-        else EMPH_W4_LAUNCH(M_TILES, false);                                                   \
+        if (half >= 0) {                                                                       \
+            if (position != nullptr) EMPH_W4_LAUNCH(M_TILES, true, true);                      \
+            else EMPH_W4_LAUNCH(M_TILES, false, true);                                         \
+        } else if (position != nullptr) EMPH_W4_LAUNCH(M_TILES, true, false);                  \
+        else EMPH_W4_LAUNCH(M_TILES, false, false);                                            \
     } while (0)
     switch (m_tiles) {
         case 1: EMPH_W4(1); break;
@@ -342,7 +401,18 @@ int emph_conv1d_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
                           int32_t activation, const int32_t* tiles, int32_t n_tiles,
                           void* stream) {
     return launch_winograd4(x, ldx, y, ldy, pack, bias, c_in, c_out, activation, tiles, n_tiles,
-                            nullptr, 0, stream);
+                            nullptr, 0, -1, stream);
+}
+
+int emph_conv1d_winograd4_half(const float* x, int64_t ldx, float* y, int64_t ldy,
+                               const float* split_pack, const float* bias, int32_t c_in,
+                               int32_t c_out, int32_t activation, const int32_t* tiles,
+                               int32_t n_tiles, const float* position, int32_t max_positions,
+                               int32_t half, void* stream) {
+    EMPH_REQUIRE(half == 0 || half == 1, EMPH_EINVAL, "emph_conv1d_winograd4_half: half %d",
+                 half);
+    return launch_winograd4(x, ldx, y, ldy, split_pack, bias, c_in, c_out, activation, tiles,
+                            n_tiles, position, max_positions, half, stream);
 }
 
 int emph_conv1d_winograd4_position(const float* x, int64_t ldx, float* y, int64_t ldy,
@@ -353,7 +423,7 @@ int emph_conv1d_winograd4_position(const float* x, int64_t ldx, float* y, int64_
     EMPH_REQUIRE(position != nullptr, EMPH_EINVAL,
                  "emph_conv1d_winograd4_position: null position table");
     return launch_winograd4(x, ldx, y, ldy, pack, bias, c_in, c_out, activation, tiles, n_tiles,
-                            position, max_positions, stream);
+                            position, max_positions, -1, stream);
 }
 
 }  // extern "C"

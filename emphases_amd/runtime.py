@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -74,6 +74,10 @@ SIGNATURES = {
     'emph_conv1d_winograd4_position': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _ptr, _i32,
         _ptr, _i32, _ptr]),
+    'emph_conv_winograd4_split_pack': (_c.c_int, [_ptr, _i32, _i32, _ptr]),
+    'emph_conv1d_winograd4_half': (_c.c_int, [
+        _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _ptr, _i32,
+        _ptr, _i32, _i32, _ptr]),
     'emph_segment_reduce': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i64, _i32, _ptr, _ptr, _i64, _i32, _ptr]),
     'emph_output_layer': (_c.c_int, [
@@ -273,17 +277,19 @@ def word_decoder_pack(weight):
     return pack
 
 
-def conv_winograd4_pack(weight):
-    """Winograd F(4,3) pack of a [c_out, c_in, 3] weight (host, numpy)."""
+def conv_winograd4_pack(weight, split=False):
+    """Winograd F(4,3) pack of a [c_out, c_in, 3] weight (host, numpy);
+    `split`: cut into the two halves of `emph_conv1d_winograd4_half`."""
     lib = library()
     weight = np.ascontiguousarray(weight, dtype=np.float32)
     c_out, c_in, kernel_size = weight.shape
     assert kernel_size == 3
     pack = np.zeros(
         lib.emph_conv_winograd4_pack_size(c_out, c_in), dtype=np.float32)
-    check(lib.emph_conv_winograd4_pack(
-        weight.ctypes.data, c_out, c_in, pack.ctypes.data),
-        'emph_conv_winograd4_pack')
+    function = lib.emph_conv_winograd4_split_pack if split else \
+        lib.emph_conv_winograd4_pack
+    check(function(weight.ctypes.data, c_out, c_in, pack.ctypes.data),
+          'emph_conv_winograd4_pack')
     return pack
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 22
+#define EMPH_ABI_VERSION 23
 
 /* Segment-table fields */
 enum {
@@ -286,6 +286,25 @@ int emph_conv1d_winograd4_position(const float* x, int64_t ldx, float* y,
                                    const int32_t* tiles, int32_t n_tiles,
                                    const float* position,
                                    int32_t max_positions, void* stream);
+
+/* The F(4,3) layer as TWO independent launches ("halves"): half 0 computes the
+ * output channels of the first ceil(m_tiles / 2) 16-channel tiles, half 1 the
+ * rest, each around its own rows of the pack only (92 KB + 61 KB of LDS for
+ * 80 x 80, four waves per workgroup).  Same values, bit for bit, as
+ * emph_conv1d_winograd4[_position]; issued on two streams, the halves of
+ * different layers / batches share a compute unit, so one's weight transfer and
+ * store burst run under the other's matrix work.  `split_pack`: the pack cut
+ * by emph_conv_winograd4_split_pack (same size as emph_conv_winograd4_pack's;
+ * half 0's rows first); `position` may be NULL. */
+int emph_conv_winograd4_split_pack(const float* host_weight, int32_t c_out,
+                                   int32_t c_in, float* host_pack);
+int emph_conv1d_winograd4_half(const float* x, int64_t ldx, float* y,
+                               int64_t ldy, const float* split_pack,
+                               const float* bias, int32_t c_in, int32_t c_out,
+                               int32_t activation, const int32_t* tiles,
+                               int32_t n_tiles, const float* position,
+                               int32_t max_positions, int32_t half,
+                               void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Frame -> word resampling                                                  */

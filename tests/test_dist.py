@@ -185,7 +185,9 @@ def _file_worker(rank, world, port, queue, directory):
 
         scores = edist.from_files_to_files(
             texts, audios, prefixes, compute=compute)
-        queue.put((rank, sorted(read), [s.clone() for s in scores]))
+        # (numpy: pickled by value; a torch tensor travels as a shared-memory
+        # handle that dies with this process)
+        queue.put((rank, sorted(read), [s.numpy().copy() for s in scores]))
     finally:
         torch.distributed.destroy_process_group()
 
@@ -226,7 +228,7 @@ def test_sharded_files_read_only_their_shard(tmp_path):
         alignment, want = _oracle_file(text, audio, state)
         for _, _, scores in results:
             assert scores[index].shape == (1, len(alignment))
-            assert torch.equal(scores[index], want)
+            assert np.array_equal(scores[index], want.numpy())
         saved = torch.load(tmp_path / f'out_{world}_{index}.pt')
         assert torch.equal(saved, want)
         assert (tmp_path / f'out_{world}_{index}.TextGrid').exists()

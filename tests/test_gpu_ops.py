@@ -183,6 +183,18 @@ def test_conv1d_winograd4(c_in, c_out, activation):
         pack.data_ptr(), bias_dev.data_ptr(), c_in, c_out,
         runtime.ACTIVATIONS[activation], tiles.data_ptr(), size // 4, None),
         'emph_conv1d_winograd4')
+    if c_out > 16:
+        # the layer as two independent half launches: the same bits
+        split = torch.from_numpy(runtime.conv_winograd4_pack(
+            weight, split=True)).to(DEVICE)
+        halves = torch.full((c_out, plan.ld_frames), 7.0, device=DEVICE)
+        for half in (1, 0):
+            runtime.check(lib.emph_conv1d_winograd4_half(
+                x_dev.data_ptr(), plan.ld_frames, halves.data_ptr(),
+                plan.ld_frames, split.data_ptr(), bias_dev.data_ptr(), c_in,
+                c_out, runtime.ACTIVATIONS[activation], tiles.data_ptr(),
+                size // 4, None, 0, half, None), 'emph_conv1d_winograd4_half')
+        assert torch.equal(halves, y)
     y = y.cpu()
     for off, count in spans(plan, axis):
         want = ACTIVATIONS[activation](torch.nn.functional.conv1d(
