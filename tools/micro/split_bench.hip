@@ -120,6 +120,33 @@ int main(int argc, char** argv) {
         timed("half 1 twice, two streams", [&] {
             OK(emph_conv1d_winograd4_half(x, ld, y, ld, dsplit, dbias, c, c, 1, dconv, n_conv, nullptr, 0, 1, s0));
             OK(emph_conv1d_winograd4_half(x, ld, y, ld, dsplit, dbias, c, c, 1, dconv, n_conv, nullptr, 0, 1, s1)); });
+        // ---- does a front-end workgroup run BESIDE a conv workgroup on the same CU?
+        float* mel; CHECK(hipMalloc(&mel, 80 * ld * 4));
+        auto frontend = [&](hipStream_t stream) {
+            OK(emph_logmel(audio, 0, seg, dfe, n_fe, dtable, dstart, dcount, doffset, dvalues, (int)values.size(),
+                           mel, ld, 0, -1, nullptr, nullptr, 0, stream));
+        };
+        auto pair = [&](const char* what, int convs, int fronts, auto conv_body) {
+            for (int warm = 0; warm < 2; ++warm) { for (int i = 0; i < convs; ++i) conv_body(s0); for (int i = 0; i < fronts; ++i) frontend(s1); }
+            CHECK(hipDeviceSynchronize());
+            auto t0 = std::chrono::high_resolution_clock::now();
+            for (int i = 0; i < convs; ++i) conv_body(s0);
+            CHECK(hipDeviceSynchronize());
+            auto t1 = std::chrono::high_resolution_clock::now();
+            for (int i = 0; i < fronts; ++i) frontend(s1);
+            CHECK(hipDeviceSynchronize());
+            auto t2 = std::chrono::high_resolution_clock::now();
+            for (int i = 0; i < std::max(convs, fronts); ++i) { if (i < convs) conv_body(s0); if (i < fronts) frontend(s1); }
+            CHECK(hipDeviceSynchronize());
+            auto t3 = std::chrono::high_resolution_clock::now();
+            auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            printf("%-34s %d convs alone %.0f us, %d front-ends alone %.0f us, together on two streams %.0f us\n", what, convs,
+                   us(t0, t1), fronts, us(t1, t2), us(t2, t3));
+        };
+        pair("whole layer (153.6 KB) + front-end", 30, 10, [&](hipStream_t queue) { OK(emph_conv1d_winograd4(x, ld, y, ld, dwhole, dbias, c, c, 1, dconv, n_conv, queue)); });
+        pair("half 0 (92 KB) + front-end", 30, 10, [&](hipStream_t queue) { OK(emph_conv1d_winograd4_half(x, ld, y, ld, dsplit, dbias, c, c, 1, dconv, n_conv, nullptr, 0, 0, queue)); });
+        pair("half 1 (61 KB) + front-end", 30, 10, [&](hipStream_t queue) { OK(emph_conv1d_winograd4_half(x, ld, y, ld, dsplit, dbias, c, c, 1, dconv, n_conv, nullptr, 0, 1, queue)); });
+        CHECK(hipFree(mel));
         CHECK(hipFree(x)); CHECK(hipFree(y));
     }
 
