@@ -363,17 +363,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // 32 distinct banks):
 //     K[d][64 keys]   row stride 80 floats  (A fragment: K[4 s + kk][key0 + col])
 //     V[key][D]       row stride D + 4      (A fragment: V[key0 + 4 kk + r][16 m + col])
-constexpr int kQueryTiles = 2;     // 16-query tiles per wave: eight waves of 32 queries
-constexpr int kGroupThreads = 256 * 4 / kQueryTiles;
-template <int D>
-__global__ __launch_bounds__(kGroupThreads)
+//
+// WAVES = 8: 256 queries per workgroup, two workgroups per CU; WAVES = 16: 512
+// queries, one workgroup per CU - the same sixteen waves per CU, but a segment's
+// keys and values are staged once per 512 queries instead of once per 256.
+constexpr int kQueryTiles = 2;     // 16-query tiles per wave: waves of 32 queries
+template <int D, int WAVES>
+__global__ __launch_bounds__(64 * WAVES)
 __attribute__((amdgpu_waves_per_eu(8 / kQueryTiles, 8 / kQueryTiles)))
 void attention_group_kernel(
     const float* __restrict__ qk, const float* __restrict__ v, float* __restrict__ out,
     int64_t ld, int channels, const int32_t* __restrict__ tiles,
     const int32_t* __restrict__ key_counts) {
     constexpr int QT = kQueryTiles;       // 16-query tiles per wave
-    constexpr int THREADS = kGroupThreads;
+    constexpr int THREADS = 64 * WAVES;
     constexpr int KSTEPS = D / 4;
     constexpr int MT = (D + 15) / 16;
     constexpr int STAGE = 64;             // keys per stage
@@ -389,8 +392,19 @@ void attention_group_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 15;
     const int kk = lane >> 4;
-    const int head = blockIdx.y;
-    const Tile span = load_tile(tiles, blockIdx.x);
+    // XCD-aware order: the hardware deals workgroups round-robin over the eight
+    // XCDs (linear id L goes to XCD L % 8), each with an L2 of its own, and the
+    // four tiles of a segment stream the same keys and values.  Walking the
+    // (head, tile) space so that XCD i takes the i-th EIGHTH of it - consecutive
+    // tiles in consecutive slots of one XCD - lets the second to fourth reader of
+    // a segment's keys and values hit in that XCD's L2 (in dispatch order, tiles
+    // t .. t + 3 of a segment sat on four different XCDs: four HBM fetches).
+    const int linear = blockIdx.x + gridDim.x * blockIdx.y;
+    const int total = gridDim.x * gridDim.y;
+    const int per_xcd = total >> 3;
+    const int logical = linear < 8 * per_xcd ? (linear & 7) * per_xcd + (linear >> 3) : linear;
+    const int head = logical / static_cast<int>(gridDim.x);
+    const Tile span = load_tile(tiles, logical - head * static_cast<int>(gridDim.x));
     const int q0 = span.first + 16 * QT * wave;
     const int queries = span.count;
     const int length = key_counts != nullptr ? min(key_counts[span.segment], span.count)
@@ -662,9 +676,9 @@ int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
                    int32_t n_tiles, int32_t tile_n, const int32_t* key_counts,
                    void* stream) {
     if (n_tiles == 0) return EMPH_OK;
-    EMPH_REQUIRE(tile_n == 64 || tile_n == 256, EMPH_EINVAL,
-                 "emph_attention: tile_n %d (64: one wave per tile; 256: a workgroup per "
-                 "tile with keys and values staged in LDS)", tile_n);
+    EMPH_REQUIRE(tile_n == 64 || tile_n == 256 || tile_n == 512, EMPH_EINVAL,
+                 "emph_attention: tile_n %d (64: one wave per tile; 256 / 512: a workgroup "
+                 "of 8 / 16 waves per tile with keys and values staged in LDS)", tile_n);
     EMPH_REQUIRE(qk && v && out && tiles, EMPH_EINVAL,
                  "emph_attention: null pointer");
     EMPH_REQUIRE(heads > 0 && channels % heads == 0, EMPH_EINVAL,
@@ -673,24 +687,25 @@ int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
     const int d = channels / heads;
     hipStream_t s = static_cast<hipStream_t>(stream);
     dim3 grid(n_tiles, heads);
-    if (tile_n == 256) {
+    if (tile_n >= 256) {
+#define EMPH_GROUP(D)                                                                     \
+    do {                                                                                  \
+        if (tile_n == 256)                                                                \
+            EMPH_LAUNCH((attention_group_kernel<D, 8>), grid, dim3(512), 0, s, qk, v, out, \
+                        ld, channels, tiles, key_counts);                                 \
+        else                                                                              \
+            EMPH_LAUNCH((attention_group_kernel<D, 16>), grid, dim3(1024), 0, s, qk, v,   \
+                        out, ld, channels, tiles, key_counts);                            \
+    } while (0)
         switch (d) {
-            case 32:
-                EMPH_LAUNCH(attention_group_kernel<32>, grid, dim3(kGroupThreads), 0, s, qk, v, out, ld,
-                            channels, tiles, key_counts);
-                break;
-            case 40:
-                EMPH_LAUNCH(attention_group_kernel<40>, grid, dim3(kGroupThreads), 0, s, qk, v, out, ld,
-                            channels, tiles, key_counts);
-                break;
-            case 64:
-                EMPH_LAUNCH(attention_group_kernel<64>, grid, dim3(kGroupThreads), 0, s, qk, v, out, ld,
-                            channels, tiles, key_counts);
-                break;
+            case 32: EMPH_GROUP(32); break;
+            case 40: EMPH_GROUP(40); break;
+            case 64: EMPH_GROUP(64); break;
             default:
                 set_error("emph_attention: head dimension %d not in {32, 40, 64}", d);
                 return EMPH_ERANGE;
         }
+#undef EMPH_GROUP
         return check_launch("emph_attention");
     }
     switch (d) {
