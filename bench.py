@@ -95,9 +95,6 @@ def parse_args():
                         help='launch kernel by kernel instead of replaying '
                              'the captured HIP graph')
     parser.add_argument('--no-preroll', action='store_true')
-    parser.add_argument('--attention-group', type=int, default=None,
-                        help='queries per attention workgroup on the frame '
-                             'axis (256 or 512; --config transformer)')
     parser.add_argument('--cpu-worker', type=float, default=None,
                         help=argparse.SUPPRESS)
     return parser.parse_args()
@@ -853,8 +850,6 @@ def main():
             args.backend, rank=rank, world_size=world,
             device_id=device if args.backend == 'nccl' else None)
 
-    if args.attention_group:
-        emphases_amd.engine.ATTENTION_GROUP = args.attention_group
     config = cfg.DEFAULT if args.config == 'conv' else \
         cfg.Config(architecture='transformer')
     state = None if args.config == 'conv' else \

@@ -441,8 +441,13 @@ int emph_add_position(float* x, int64_t ldx, const float* table,
  *   tiles int32 [n_tiles][4]        tile table, block = tile_n queries
  *   tile_n 64: one wave per tile, keys / values read from L2 by every wave
  *              (short segments: the word axis);
- *          256: a workgroup of four waves per tile with the key / value blocks
- *              staged ONCE per workgroup in LDS (long segments: the frame axis)
+ *          256: a workgroup of eight waves per tile with the key / value blocks
+ *              staged ONCE per workgroup in LDS (long segments: the frame axis);
+ *              workgroups walk the (head, tile) space in XCD order, so that
+ *              the tiles of a segment share one XCD's L2;
+ *          512: the same with sixteen waves (keys / values staged once per 512
+ *              queries; one workgroup per CU: 1 % faster alone, 1 % slower
+ *              with two batches in flight - the engine uses 256)
  *   key_counts int32 [n_seg] or NULL  src_key_padding_mask (transformer.py:
  *                                   26-29) as the number of leading positions
  *                                   of each segment that are real keys; the

@@ -467,7 +467,7 @@ def test_output_layer(kernel_size, post):
 ###############################################################################
 
 
-@pytest.mark.parametrize('tile_n', [64, 256])
+@pytest.mark.parametrize('tile_n', [64, 256, 512])
 @pytest.mark.parametrize('channels,heads', [(80, 2), (64, 2), (128, 2)])
 def test_attention(channels, heads, tile_n):
     lib = runtime.library()
