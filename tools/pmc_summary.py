@@ -33,7 +33,12 @@ TRANSFORMER = {
     'attention_group_kernel': (
         'attention_frames', 4 * CHANNELS * FRAMES * 4),      # Q, K, V read + O written
     'qkv_kernel': ('qkv_projection_frames', 4 * CHANNELS * FRAMES * 4 + 3 * 25600),
-    'transformer_block_kernel': (
+    # out_proj .. LayerNorm2 fused with the NEXT layer's Q / K / V projections
+    # (layers 0-4): reads x and the attended values, writes x, Q, K and V
+    'transformer_block_kernel<5, 2, true>': (
+        'transformer_block_qkv_frames', 6 * CHANNELS * FRAMES * 4 + 6 * 25600),
+    # the last layer's block: reads x and the attended values, writes x
+    'transformer_block_kernel<5, 2, false>': (
         'transformer_block_frames', 3 * CHANNELS * FRAMES * 4 + 3 * 25600),
 }
 
