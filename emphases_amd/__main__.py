@@ -1,5 +1,14 @@
-"""Command line of the reference (`emphases/__main__.py:12-50`): same flags."""
+"""Command line of the reference (`emphases/__main__.py:12-50`): same flags.
+
+Under `torchrun` (WORLD_SIZE > 1: one process per GPU) the files are sharded
+over the ranks by `dist.from_files_to_files`; every rank writes its own
+outputs and `--gpu` is ignored (the rank's GPU is `LOCAL_RANK`):
+
+    torchrun --standalone --nproc-per-node 8 -m emphases_amd \
+        --text_files *.TextGrid --audio_files *.wav
+"""
 import argparse
+import os
 from pathlib import Path
 
 import emphases_amd
@@ -28,5 +37,24 @@ def parse_args():
     return parser.parse_args()
 
 
+def main():
+    arguments = vars(parse_args())
+    if int(os.environ.get('WORLD_SIZE', 1)) <= 1:
+        emphases_amd.from_files_to_files(**arguments)
+        return
+    import torch
+    from emphases_amd import dist
+    backend = os.environ.get('EMPHASES_DIST_BACKEND', 'nccl')
+    device = None
+    if backend == 'nccl':
+        device = torch.device('cuda', dist.local_device())
+    torch.distributed.init_process_group(backend, device_id=device)
+    try:
+        arguments.pop('gpu')
+        dist.from_files_to_files(**arguments, gather=False)
+    finally:
+        torch.distributed.destroy_process_group()
+
+
 if __name__ == '__main__':
-    emphases_amd.from_files_to_files(**vars(parse_args()))
+    main()

@@ -19,6 +19,8 @@
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+
 #include "common.h"
 
 namespace {
@@ -151,8 +153,18 @@ class Pool {
     bool stop_ = false;
 };
 
-std::mutex g_pool_mutex;
+std::mutex* g_pool_mutex = new std::mutex;
 Pool* g_pool = nullptr;
+
+// fork(): the child has this thread only - the pool's workers do not exist
+// there and its mutexes may have been held by one of them.  The child forgets
+// the parent's pool (and lock) without touching them and builds its own on its
+// first gather.
+void forget_pool_in_child() {
+    g_pool = nullptr;
+    g_pool_mutex = new std::mutex;
+}
+const int g_atfork = pthread_atfork(nullptr, nullptr, forget_pool_in_child);
 
 }  // namespace
 
@@ -166,7 +178,7 @@ int emph_host_gather(const void* const* host_sources, const int64_t* host_bytes,
                  "emph_host_gather: null pointer");
     EMPH_REQUIRE(threads >= 1 && threads <= 64, EMPH_EINVAL,
                  "emph_host_gather: %d threads (1 .. 64)", threads);
-    std::lock_guard<std::mutex> guard(g_pool_mutex);       // one gather at a time
+    std::lock_guard<std::mutex> guard(*g_pool_mutex);      // one gather at a time
     if (g_pool == nullptr) g_pool = new Pool(threads - 1);
     g_pool->grow(threads - 1);
     Job job;

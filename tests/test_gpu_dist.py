@@ -160,3 +160,21 @@ def test_sharded_file_api(tmp_path):
             saved = torch.load(directory / f'w{world}_{index}.pt')
             assert torch.equal(saved, want[index])
             assert (directory / f'w{world}_{index}.TextGrid').exists()
+    # the command line under two ranks (what `torchrun -m emphases_amd` starts):
+    # every rank writes its own shard of the outputs
+    few = 24
+    port = _free_port()
+    children = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE='2', MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0',
+                   EMPHASES_DIST_BACKEND='gloo')
+        children.append(subprocess.Popen(
+            [sys.executable, '-m', 'emphases_amd', '--text_files', *texts[:few],
+             '--audio_files', *audios[:few], '--output_prefixes',
+             *[str(directory / f'cli_{i}') for i in range(few)]],
+            env=env, cwd=ROOT))
+    assert all(child.wait(timeout=600) == 0 for child in children)
+    for index in range(few):
+        assert torch.equal(torch.load(directory / f'cli_{index}.pt'), want[index])

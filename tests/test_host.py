@@ -583,3 +583,39 @@ def test_dropout_checkpoints_load():
     assert 'frame_encoder.3.weight' in raw
     loaded = weights.load(raw)
     assert all(np.array_equal(loaded[name], state[name]) for name in state)
+
+
+def test_host_gather_and_fork():
+    """emph_host_gather (the persistent pool of copy threads behind
+    `session._Lane.stage`): pieces of any size and alignment land where they
+    should, and a forked child - which inherits the library but not its
+    worker threads - gathers with a pool of its own instead of waiting for
+    the parent's."""
+    import os
+    from emphases_amd import runtime
+    lib = runtime.library()
+    generator = np.random.default_rng(3)
+
+    def gather(threads):
+        sizes = [1, 4095, 4096, 70001, 3 << 20, 17, 0, 1 << 20]
+        sources = [generator.integers(0, 255, n, dtype=np.uint8) for n in sizes]
+        offsets = np.cumsum([5] + [n + 3 for n in sizes[:-1]]).astype(np.int64)
+        destination = np.full(int(offsets[-1]) + sizes[-1] + 9, 0xAB, np.uint8)
+        pointers = np.array([s.ctypes.data for s in sources], dtype=np.int64)
+        nbytes = np.array(sizes, dtype=np.int64)
+        runtime.check(lib.emph_host_gather(
+            pointers.ctypes.data, nbytes.ctypes.data, offsets.ctypes.data,
+            len(sizes), destination.ctypes.data, threads), 'emph_host_gather')
+        expect = np.full_like(destination, 0xAB)
+        for source, offset in zip(sources, offsets):
+            expect[offset:offset + source.size] = source
+        return bool(np.array_equal(destination, expect))
+
+    assert gather(1) and gather(6) and gather(3)
+    assert lib.emph_host_gather(None, None, None, 1, None, 4) != 0
+    pid = os.fork()
+    if pid == 0:                       # the child: must not hang or crash
+        os._exit(0 if gather(4) and gather(2) else 1)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+    assert gather(5)

@@ -109,6 +109,9 @@ int main(int argc, char** argv) {
             printf("%-46s %.2f us per layer\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count() / 100);
         };
         timed("whole layer, one stream", [&] { OK(emph_conv1d_winograd4(x, ld, y, ld, dwhole, dbias, c, c, 1, dconv, n_conv, s0)); });
+        // inputs that every XCD's L2 holds (rows 1024 floats apart alias into 0.6 MB): what
+        // would the layer gain if its activations were always an L2 hit?
+        timed("whole layer, inputs L2-resident (aliased rows)", [&] { OK(emph_conv1d_winograd4(x, 1024, y, ld, dwhole, dbias, c, c, 1, dconv, n_conv, s0)); });
         timed("half 0 alone", [&] { OK(emph_conv1d_winograd4_half(x, ld, y, ld, dsplit, dbias, c, c, 1, dconv, n_conv, nullptr, 0, 0, s0)); });
         timed("half 1 alone", [&] { OK(emph_conv1d_winograd4_half(x, ld, y, ld, dsplit, dbias, c, c, 1, dconv, n_conv, nullptr, 0, 1, s0)); });
         timed("half 0 and half 1, two streams, no dependency", [&] {
