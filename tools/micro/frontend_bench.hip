@@ -25,6 +25,9 @@ __device__ unsigned long long* g_stamps = nullptr;
     } while (0)
 #endif
 #include "../../emphases_amd/csrc/frontend.hip"
+#ifdef WITH_PIPELINED
+#include "logmel_pipelined.inc"
+#endif
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 int main() {
@@ -77,6 +80,32 @@ int main() {
     CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     printf("frontend: %d blocks, %.2f us/launch (%.1f ns/frame)\n", n_tiles, ms * 1e3 / 20, ms * 1e6 / 20 / (segments * frames));
+#ifdef WITH_PIPELINED
+    {
+        // the two-frames-in-flight experiment against the shipped kernel
+        std::vector<float> plain(80 * ld), piped(80 * ld);
+        CHECK(hipMemcpy(plain.data(), out, plain.size() * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemset(out, 0, 80 * ld * 4));
+        const size_t bytes = 4 * emph::kPipeWaveFloats * sizeof(float);
+        auto kernel = emph::logmel_pipelined_kernel<false>;
+        CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        auto piped_launch = [&]() {
+            hipLaunchKernelGGL(kernel, dim3(emph::frontend_grid(n_tiles)), dim3(256), bytes, 0, audio, seg, dtiles, dtable,
+                               dstart, dcount, doffset, dvalues, (int)values.size(), out, ld, 0, 0, n_tiles);
+        };
+        for (int i = 0; i < 3; ++i) piped_launch();
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(piped.data(), out, piped.size() * 4, hipMemcpyDeviceToHost));
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < 20; ++i) piped_launch();
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        size_t differ = 0;
+        for (size_t i = 0; i < plain.size(); ++i) differ += plain[i] != piped[i];
+        printf("two frames in flight per wave: %.2f us/launch, %zu of %zu values differ from the shipped kernel\n",
+               ms * 1e3 / 20, differ, plain.size());
+    }
+#endif
     const size_t slots = static_cast<size_t>(n_tiles) * 4 * 16;
     unsigned long long* stamps; CHECK(hipMalloc(&stamps, slots * 8)); CHECK(hipMemset(stamps, 0, slots * 8));
     CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &stamps, sizeof(stamps)));
