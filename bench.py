@@ -481,8 +481,13 @@ def from_profiles(config, dominant):
         result['traffic'] = entry.get('traffic_bytes')
         result['traffic_raw'] = entry.get('traffic_bytes_raw')
         result['algorithmic_bytes'] = entry.get('algorithmic_bytes')
-        result['mfma_pipe_busy'] = entry.get('mfma_pipe_busy')
         result['pmc_file'] = os.path.relpath(summary, ROOT)
+    utilisation = profile_file('pmc_utilisation.json')
+    if utilisation:
+        with open(utilisation) as file:
+            entry = json.load(file).get(dominant, {})
+        result['mfma_pipe_busy'] = entry.get('mfma_pipe_busy')
+        result['mfma_pipe_busy_file'] = os.path.relpath(utilisation, ROOT)
     return result
 
 
