@@ -249,6 +249,10 @@ def from_files_to_files(text_files, audio_files, output_prefixes=None,
     text_files, audio_files = list(text_files), list(audio_files)
     if len(text_files) != len(audio_files):
         raise ValueError('one audio file per text file')
+    for file in text_files:
+        if not str(file).endswith(('.TextGrid', '.json')):
+            from . import core
+            core.from_text_and_audio(None, None, None)   # raises: no forced alignment
     if output_prefixes is None:
         output_prefixes = [Path(file).stem for file in text_files]
     output_prefixes = list(output_prefixes)

@@ -337,6 +337,58 @@ def test_wav_roundtrip_and_resample(tmp_path):
     assert emphases_amd.resample(tone, 16000) is tone
 
 
+def test_wav_headers_alone(tmp_path):
+    """load.wav_info (what a sharded run plans from) agrees with the full
+    reader on every format it accepts, reads no samples, and copes with odd
+    chunk lists: a LIST chunk (odd size, padded) in front of the data, a
+    WAVE_FORMAT_EXTENSIBLE header, a data chunk that claims more bytes than
+    the file holds."""
+    import struct
+
+    def riff(fmt, data, extra=b'', claimed=None):
+        chunks = b'fmt ' + struct.pack('<I', len(fmt)) + fmt + extra + \
+            b'data' + struct.pack('<I', len(data) if claimed is None
+                                  else claimed) + data
+        return b'RIFF' + struct.pack('<I', 4 + len(chunks)) + b'WAVE' + chunks
+
+    def pcm_format(code, channels, rate, bits, extensible=False):
+        block = channels * bits // 8
+        head = struct.pack('<HHIIHH', 0xFFFE if extensible else code, channels,
+                           rate, rate * block, block, bits)
+        if extensible:
+            head += struct.pack('<HHI', 22, bits, 0) + \
+                struct.pack('<H', code) + bytes(14)
+        return head
+
+    cases = {
+        'pcm16_stereo': (pcm_format(1, 2, 22050, 16), 2, 22050, 16, 300),
+        'pcm8': (pcm_format(1, 1, 8000, 8), 1, 8000, 8, 77),
+        'pcm24': (pcm_format(1, 1, 44100, 24), 1, 44100, 24, 41),
+        'float32': (pcm_format(3, 1, 16000, 32), 1, 16000, 32, 1234),
+        'extensible': (pcm_format(1, 1, 48000, 16, True), 1, 48000, 16, 99),
+    }
+    for name, (fmt, channels, rate, bits, samples) in cases.items():
+        data = bytes(range(256)) * (samples * channels * bits // 8 // 256 + 1)
+        data = data[:samples * channels * bits // 8]
+        file = tmp_path / f'{name}.wav'
+        extra = b'LIST' + struct.pack('<I', 5) + b'abcde\0' \
+            if name == 'pcm24' else b''
+        file.write_bytes(riff(fmt, data, extra))
+        assert load.wav_info(file) == (rate, channels, samples), name
+        audio, loaded_rate = load.wav(file)
+        assert loaded_rate == rate and tuple(audio.shape) == (channels, samples)
+    # truncated: the data chunk claims 1000 samples, 600 are there
+    file = tmp_path / 'short.wav'
+    file.write_bytes(riff(pcm_format(1, 1, 16000, 16), bytes(1200), claimed=2000))
+    assert load.wav_info(file) == (16000, 1, 600)
+    assert load.wav(file)[0].shape == (1, 600)
+    for junk in (b'RIFX' + bytes(40), riff(pcm_format(1, 1, 16000, 16), b'')[:36]):
+        file = tmp_path / 'junk.wav'
+        file.write_bytes(junk)
+        with pytest.raises(ValueError):
+            load.wav_info(file)
+
+
 ###############################################################################
 # C ABI
 ###############################################################################
