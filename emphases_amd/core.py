@@ -55,10 +55,13 @@ def _engine(checkpoint, device_index, config, conv_tile=None):
 def get_engine(checkpoint=None, gpu=None, config=None, conv_tile=None):
     """Cached `Engine` per (checkpoint, device, config, conv_tile) — the
     explicit form of the reference's function-attribute cache
-    (`core.py:298-315`).  `conv_tile`: positions per frame-rate conv tile
-    (64 / 32 / 16); None lets `Engine.frame_tile` pick by batch size.  Scores
-    of different tiles agree to 1e-6, scores of the same tile are bitwise
-    reproducible whatever else is in the batch: sharded runs pin it."""
+    (`core.py:298-315`).  `conv_tile`: positions per frame-rate conv tile.
+    None (default): the kernel family of a layer follows from the
+    configuration alone, so an utterance's scores are BITWISE the same alone,
+    in any batch and on any shard; 64 / 32 / 16 pin a tile; 'auto' picks the
+    lowest-latency variant by batch size (a few utterances then take the
+    direct form, which agrees with the Winograd kernels to 1e-6, not
+    bitwise)."""
     device = runtime.require_gpu(gpu)
     index = device.index if device.index is not None else \
         torch.cuda.current_device()

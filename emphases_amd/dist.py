@@ -13,9 +13,9 @@ for tests):
    WAV headers — a rank never reads audio it does not compute);
 2. `exchange_counts` — one all_gather of the per-utterance score counts, which
    follow from the plan (`batch.score_counts`), BEFORE anything is computed;
-3. every rank runs its shard through its own `Engine` / `Session`, with the
-   conv tile pinned (`CONV_TILE`) so that the kernel variant does not depend on
-   the shard size;
+3. every rank runs its shard through its own `Engine` / `Session`; the
+   kernel variant of a layer follows from the configuration, not from the
+   shard size (`Engine.frame_tile`);
 4. `exchange_scores` — one all_gather of the padded score vectors (a few
    hundred KB in total: latency bound; which utterance sits where follows from
    the assignment every rank computed and the counts of step 2, so nothing is
@@ -61,64 +61,135 @@ def collective_device(group=None):
     return torch.device('cpu')
 
 
-def exchange_counts(local_counts, shards, group=None, device=None):
+class RankFailure(RuntimeError):
+    """Raised on EVERY rank when some rank could not do its part: a rank that
+    fails (an unreadable file, a corrupt alignment, a kernel error) still joins
+    the collective with a sentinel payload instead of leaving the others
+    blocked in it until the process group times out."""
+
+
+def _raise_for(failed, rank, stage, failure):
+    if not failed:
+        return
+    message = f'rank(s) {failed} failed {stage}'
+    if rank in failed and failure is not None:
+        raise RankFailure(f'{message}: {failure!r}') from failure
+    raise RankFailure(message)
+
+
+def exchange_counts(local_counts, shards, group=None, device=None,
+                    failure=None):
     """Collective 1 of 2: how many scores each utterance of each rank will
     have -> int64 [world, widest] on the host (row r: rank r's utterances in
     the order of `shards[r]`, zero padded).  Called BEFORE anything is
     computed (the counts follow from the plan, `batch.score_counts`), so the
     device-to-host copy of its result waits for nothing and the score exchange
-    that closes the run needs no size negotiation."""
+    that closes the run needs no size negotiation.
+
+    `failure`: the exception that kept this rank from planning its shard; the
+    rank then sends -1 counts and every rank raises `RankFailure`."""
     dist = torch.distributed
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     device = device or collective_device(group)
-    if len(shards) != world or len(local_counts) != len(shards[rank]):
+    if len(shards) != world:
         raise ValueError('shards do not describe this process group')
+    if failure is None and len(local_counts) != len(shards[rank]):
+        failure = ValueError(
+            f'{len(local_counts)} counts for {len(shards[rank])} utterances')
     widest = max(max(len(shard) for shard in shards), 1)
     counts = torch.zeros(widest, dtype=torch.int64)
-    counts[:len(local_counts)] = torch.as_tensor(
-        np.asarray(local_counts, dtype=np.int64))
+    if failure is None:
+        counts[:len(local_counts)] = torch.as_tensor(
+            np.asarray(local_counts, dtype=np.int64))
+    else:
+        counts[:] = -1
     counts = counts.to(device)
     all_counts = torch.empty(world * widest, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(all_counts, counts, group=group)
-    return all_counts.cpu().reshape(world, widest)
+    all_counts = all_counts.cpu().reshape(world, widest)
+    _raise_for([r for r in range(world) if int(all_counts[r].min()) < 0],
+               rank, 'before the score-count exchange', failure)
+    return all_counts
 
 
-def exchange_scores(local_scores, all_counts, shards, group=None, device=None):
+def score_order(all_counts, shards):
+    """Where every score of the gathered payload goes: `(order, sizes)` with
+    `flat = payloads[order]` the scores in input order and `sizes[i]` the
+    number of scores of utterance i.  Host arithmetic on the counts of
+    collective 1 and the assignment (numpy, once per job)."""
+    counts = np.asarray(all_counts, dtype=np.int64)
+    world = counts.shape[0]
+    most = max(int(counts.sum(axis=1).max()), 1)
+    total = sum(len(shard) for shard in shards)
+    sizes = np.full(total, -1, dtype=np.int64)
+    starts = np.zeros(total, dtype=np.int64)
+    for source in range(world):
+        shard = np.asarray(shards[source], dtype=np.int64)
+        own = counts[source, :len(shard)]
+        sizes[shard] = own
+        starts[shard] = source * (most + 1) + np.cumsum(own) - own
+    if (sizes < 0).any():
+        missing = np.flatnonzero(sizes < 0).tolist()
+        raise RuntimeError(f'no rank produced scores for utterances {missing}')
+    offsets = np.cumsum(sizes) - sizes
+    order = np.repeat(starts - offsets, sizes) + np.arange(int(sizes.sum()))
+    return order, sizes, most
+
+
+def exchange_scores(local_scores, all_counts, shards, group=None, device=None,
+                    failure=None, flat=False):
     """Collective 2 of 2: every rank's scores back to back, padded to the
     largest rank's total (known to every rank from `all_counts`: no host
-    synchronisation between the kernels and this collective).  Returns a list
-    of 1-D tensors in input order, on `device` (every rank)."""
+    synchronisation between the kernels and this collective) plus ONE status
+    word, so that a rank whose compute failed (`failure`, or scores that do
+    not have the planned sizes) still joins and every rank raises
+    `RankFailure` afterwards instead of hanging.
+
+    local_scores: list of 1-D tensors in the order of `shards[rank]`, or ONE
+        1-D tensor holding them back to back (the packed word axis).
+    Returns the scores in input order on `device` (every rank): a list of 1-D
+    tensors, or with `flat=True` `(scores [total], sizes int64 [utterances])`
+    - one gather on the device and no per-utterance work on the host."""
     dist = torch.distributed
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     device = device or collective_device(group)
-    expected = all_counts[rank, :len(shards[rank])].tolist()
-    if [int(score.numel()) for score in local_scores] != expected:
-        raise RuntimeError(
-            'scores do not have the planned sizes: '
-            f'{[int(s.numel()) for s in local_scores]} vs {expected}')
-    most = max(int(all_counts.sum(dim=1).max()), 1)
-    payload = torch.zeros(most, dtype=torch.float32, device=device)
-    if local_scores:
-        flat = torch.cat(
-            [score.reshape(-1).to(torch.float32) for score in local_scores])
-        payload[:flat.numel()] = flat.to(device)
-    payloads = torch.empty(world * most, dtype=torch.float32, device=device)
+    order, sizes, most = score_order(all_counts, shards)
+    expected = np.asarray(all_counts[rank, :len(shards[rank])], dtype=np.int64)
+    payload = torch.zeros(most + 1, dtype=torch.float32, device=device)
+    if failure is None:
+        try:
+            if torch.is_tensor(local_scores):
+                got = int(local_scores.numel())
+                flat_local = local_scores.reshape(-1)
+            else:
+                got = [int(score.numel()) for score in local_scores]
+                flat_local = torch.cat(
+                    [score.reshape(-1).to(torch.float32)
+                     for score in local_scores]) if local_scores else None
+            if (got != int(expected.sum())) if torch.is_tensor(local_scores) \
+                    else (got != expected.tolist()):
+                raise RuntimeError(
+                    'scores do not have the planned sizes: '
+                    f'{got} vs {expected.tolist()}')
+            if flat_local is not None and flat_local.numel():
+                payload[:flat_local.numel()] = flat_local.to(
+                    device=device, dtype=torch.float32)
+        except Exception as error:       # noqa: BLE001
+            failure = error
+    if failure is not None:
+        payload[most] = 1.
+    payloads = torch.empty(
+        world * (most + 1), dtype=torch.float32, device=device)
     dist.all_gather_into_tensor(payloads, payload, group=group)
-
-    total = sum(len(shard) for shard in shards)
-    result = [None] * total
-    for source in range(world):
-        cursor = source * most
-        for index, size in zip(
-                shards[source], all_counts[source].tolist()):
-            result[int(index)] = payloads[cursor:cursor + size]
-            cursor += size
-    if any(item is None for item in result):
-        missing = [i for i, item in enumerate(result) if item is None]
-        raise RuntimeError(f'no rank produced scores for utterances {missing}')
-    return result
+    status = payloads[most::most + 1].cpu()
+    _raise_for([r for r in range(world) if float(status[r]) != 0.],
+               rank, 'to compute its shard', failure)
+    scores = payloads[torch.as_tensor(order, device=device)]
+    if flat:
+        return scores, torch.as_tensor(sizes)
+    return list(torch.split(scores, sizes.tolist()))
 
 
 def gather_scores(local_scores, shards, group=None, device=None):
@@ -150,12 +221,14 @@ def local_device():
     return index
 
 
-# Positions per frame-rate conv tile of a sharded run.  `Engine.frame_tile`
-# would pick by shard size (a shard of a handful of utterances takes
-# 16-position direct-form tiles instead of the F(4,3) kernel's 64), and scores
-# of different kernels agree to 1e-6, not bitwise: a sharded job pins the tile
-# so that its scores do not depend on the world size.
-CONV_TILE = 64
+# Conv tile of a sharded run.  Since round 4 the engine's default
+# (`conv_tile=None`) fixes the kernel family of every frame-rate layer by the
+# configuration, never by the batch (`Engine.frame_tile`), so a shard of a
+# handful of utterances runs the kernels a 10 000-utterance batch runs and the
+# scores do not depend on the world size; sharded calls simply use that
+# default.  (Round 3 had to pin 64 here because the default picked by shard
+# size.)
+CONV_TILE = None
 
 
 def length_at_16k(samples, sample_rate):
@@ -173,6 +246,19 @@ def frames_at_16k(samples, sample_rate):
     return length_at_16k(samples, sample_rate) // cfg.HOPSIZE
 
 
+def bind_device(group=None, compute=None):
+    """Make this rank's GPU the current device BEFORE its first collective or
+    engine call: `nccl` (= RCCL) takes collective tensors on the current
+    device, so a rank that has not bound yet would put them on `cuda:0` next
+    to every other rank's ("duplicate GPU").  Also for a rank whose shard is
+    empty.  With an injected `compute` under a host backend (the gloo CPU
+    tests) there is no GPU to bind."""
+    backend = str(torch.distributed.get_backend(group)).lower()
+    if 'nccl' in backend or compute is None:
+        return local_device()
+    return None
+
+
 def from_alignments_and_audios(alignments, audios, sample_rate=16000,
                                checkpoint=None, batch_size=None, config=None,
                                compute=None, group=None, conv_tile=CONV_TILE):
@@ -180,10 +266,12 @@ def from_alignments_and_audios(alignments, audios, sample_rate=16000,
     the SAME full lists (tensors already in memory; for a corpus on disk use
     `from_files_to_files`, which loads only the shard); each computes its LPT
     shard on its own GPU (`LOCAL_RANK`, bound here with
-    `torch.cuda.set_device`) and all ranks return all scores in input order
-    (on the collective's device: the GPU for nccl/RCCL, the CPU for gloo).
-    `conv_tile` is pinned (`CONV_TILE`), so the result is bitwise the same for
-    every world size, 1 included.
+    `torch.cuda.set_device` before the first collective) and all ranks return
+    all scores in input order (on the collective's device: the GPU for
+    nccl/RCCL, the CPU for gloo).  The kernel family does not depend on the
+    batch (`Engine.frame_tile`), so the result is bitwise the same for every
+    world size, 1 included.  A rank that
+    fails still joins both collectives and every rank raises `RankFailure`.
 
     `compute(alignments, audios) -> list of [1, W] tensors` can replace the
     HIP engine (the gloo CPU test injects the oracle there)."""
@@ -191,26 +279,37 @@ def from_alignments_and_audios(alignments, audios, sample_rate=16000,
     dist = torch.distributed
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    gpu = bind_device(group, compute)
     architecture = getattr(config, 'architecture', 'convolution')
     frames = [frames_at_16k(audio.shape[-1], sample_rate) for audio in audios]
     shards = assign(cost(frames, architecture), world)
     mine = shards[rank]
     if compute is None:
         from . import core
-        gpu = local_device()
 
         def compute(shard_alignments, shard_audios):
             return core.from_alignments_and_audios(
                 shard_alignments, shard_audios, sample_rate, checkpoint,
                 batch_size, gpu, config, conv_tile=conv_tile)
-    lengths = [length_at_16k(audios[i].shape[-1], sample_rate) for i in mine]
-    all_counts = exchange_counts(
-        batch.score_counts([alignments[i] for i in mine], lengths, batch_size),
-        shards, group)
-    local = compute([alignments[i] for i in mine], [audios[i] for i in mine]) \
-        if len(mine) else []
+    counts, failure = [], None
+    try:
+        lengths = [length_at_16k(audios[i].shape[-1], sample_rate)
+                   for i in mine]
+        counts = batch.score_counts(
+            [alignments[i] for i in mine], lengths, batch_size)
+    except Exception as error:       # noqa: BLE001
+        failure = error
+    all_counts = exchange_counts(counts, shards, group, failure=failure)
+    local = []
+    try:
+        if len(mine):
+            local = compute(
+                [alignments[i] for i in mine], [audios[i] for i in mine])
+    except Exception as error:       # noqa: BLE001
+        failure = error
     gathered = exchange_scores(
-        [score.reshape(-1) for score in local], all_counts, shards, group)
+        [score.reshape(-1) for score in local], all_counts, shards, group,
+        failure=failure)
     return [score[None] for score in gathered]
 
 
@@ -222,23 +321,28 @@ def from_files_to_files(text_files, audio_files, output_prefixes=None,
     process group, one process per GPU.  No rank reads what it does not
     compute:
 
+    0. the rank's GPU (`LOCAL_RANK`) becomes the current device - before the
+       first collective, and for a rank with an empty shard too;
     1. every rank reads the WAV *headers* of all files (`load.wav_info`:
        seeks, no samples) and computes the same LPT assignment by frames at
        16 kHz;
-    2. it reads the alignments of ITS shard, plans them
+    2. `gather=True`: it reads the alignments of ITS shard, plans them
        (`batch.score_counts`) and joins collective 1 (`exchange_counts`);
     3. it loads, stages and runs its shard through its own `Session` in
        batches of `utterances_per_batch` with two batches in flight
        (`core.files_to_scores`) and writes `<prefix>.TextGrid` / `<prefix>.pt`
        for its own files as the reference does (`core.py:111-112`);
     4. `gather=True`: collective 2 (`exchange_scores`) returns all scores, in
-       input order, to every rank; `gather=False`: returns this rank's
-       {index: scores} and no second collective runs.
+       input order, to every rank; `gather=False` (the command line): returns
+       this rank's {index: scores} and NO collective runs at all - nothing
+       would consume the counts.
 
-    The conv tile is pinned (`CONV_TILE`): the files a rank writes are bitwise
-    those a single process writes.  `compute(text_files, audio_files,
-    deliver)` replaces step 3's engine (the gloo CPU test passes the
-    oracle)."""
+    A rank that fails in step 2 or 3 still joins the collectives (sentinel
+    payload) and every rank raises `RankFailure`: nobody is left blocked in an
+    all_gather.  The files a rank writes are bitwise those a single process
+    writes (`core.from_files_to_files`, the single-process command line): the
+    kernel family does not depend on the batch (`Engine.frame_tile`).  `compute(text_files, audio_files, deliver)` replaces
+    step 3's engine (the gloo CPU test passes the oracle)."""
     from pathlib import Path
     from . import alignment as alignment_module
     from . import batch
@@ -246,6 +350,7 @@ def from_files_to_files(text_files, audio_files, output_prefixes=None,
     dist = torch.distributed
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    gpu = bind_device(group, compute)
     text_files, audio_files = list(text_files), list(audio_files)
     if len(text_files) != len(audio_files):
         raise ValueError('one audio file per text file')
@@ -263,11 +368,18 @@ def from_files_to_files(text_files, audio_files, output_prefixes=None,
     mine = [int(i) for i in shards[rank]]
     own_text = [text_files[i] for i in mine]
     own_audio = [audio_files[i] for i in mine]
-    lengths = [length_at_16k(headers[i][2], headers[i][0]) for i in mine]
-    all_counts = exchange_counts(
-        batch.score_counts(
-            [alignment_module.Alignment(file) for file in own_text], lengths,
-            batch_size), shards, group)
+    failure, all_counts = None, None
+    if gather:
+        counts = []
+        try:
+            lengths = [length_at_16k(headers[i][2], headers[i][0])
+                       for i in mine]
+            counts = batch.score_counts(
+                [alignment_module.Alignment(file) for file in own_text],
+                lengths, batch_size)
+        except Exception as error:       # noqa: BLE001
+            failure = error
+        all_counts = exchange_counts(counts, shards, group, failure=failure)
     local = {}
 
     def deliver(index, item, scores):
@@ -275,17 +387,22 @@ def from_files_to_files(text_files, audio_files, output_prefixes=None,
         core._save(item, scores, output_prefixes[mine[index]])
         local[mine[index]] = scores
 
-    if compute is not None:
-        compute(own_text, own_audio, deliver)
-    elif mine:
-        from . import core
-        gpu = local_device()
-        session = core.get_session(checkpoint, gpu, config, conv_tile)
-        core.files_to_scores(
-            own_text, own_audio, session, batch_size, utterances_per_batch,
-            deliver)
+    try:
+        if compute is not None:
+            compute(own_text, own_audio, deliver)
+        elif mine:
+            from . import core
+            session = core.get_session(checkpoint, gpu, config, conv_tile)
+            core.files_to_scores(
+                own_text, own_audio, session, batch_size, utterances_per_batch,
+                deliver)
+    except Exception as error:       # noqa: BLE001
+        if not gather:
+            raise
+        failure = error
     if not gather:
         return local
     gathered = exchange_scores(
-        [local[i].reshape(-1) for i in mine], all_counts, shards, group)
+        [local[i].reshape(-1) for i in mine if i in local], all_counts,
+        shards, group, failure=failure)
     return [score[None] for score in gathered]

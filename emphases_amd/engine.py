@@ -307,23 +307,40 @@ class Engine:
     ###########################################################################
 
     def frame_tile(self, plan):
-        """Positions per conv wave on the frame axis.  The chip runs 256
-        workgroups at a time (one per CU: the weights fill most of the LDS) of
-        4 waves (64-position tiles) or 8 waves (16 / 32), so a launch costs
-        (trips over the 256 CUs) x (time of one trip): pick the tile that
-        minimises it.  Microseconds per trip measured on the 80x80 k=3 layer
+        """Positions per conv wave on the frame axis.
+
+        Default (`conv_tile=None`): the kernel FAMILY of a frame-rate layer is
+        fixed by the configuration, never by the batch - F(4,3) (64-position
+        tiles) where it is legal, else F(2,3), else the direct form - so an
+        utterance's scores are bitwise the same alone, inside any batch and
+        on any shard of any world size.  Within a family the tile size only
+        partitions positions (same arithmetic per output), so it is picked by
+        cost.  `conv_tile='auto'`: the round-3 policy, lowest latency - a
+        handful of utterances takes the direct form's 16-position tiles,
+        which agree with the Winograd kernels to 1e-6, not bitwise (one 10 s
+        utterance: 4.6 us per layer less).
+
+        Cost model: the chip runs 256 workgroups at a time (one per CU: the
+        weights fill most of the LDS) of 4 waves (64-position tiles) or 8
+        waves (16 / 32), so a launch costs (trips over the 256 CUs) x (time of
+        one trip).  Microseconds per trip measured on the 80x80 k=3 layer
         (tools/micro/conv_bench.hip): Winograd 32: 24.0, Winograd 64: 26.7,
         direct 64: 33.5, direct 32: 31.3, direct 16: 16.1; Winograd F(4,3)
         (64-position tiles, identity / ReLU layers): 20.7."""
-        if self.conv_tile is not None:
+        if self.conv_tile is not None and self.conv_tile != 'auto':
             return self.conv_tile
+        if self.conv_tile is None and self.quad:
+            return 64
         frames = [segment.frames for segment in plan.segments]
         if self.winograd:
             cost = {64: 20.7 if self.quad else 26.7, 32: 23.2, 16: 16.1}
         else:
             cost = {64: 33.5, 32: 31.3, 16: 16.1}
+        candidates = (64, 32, 16) if self.quad else (32, 64, 16)
+        if self.conv_tile is None and self.winograd:
+            candidates = (32, 64)       # stay inside the F(2,3) family
         best = None
-        for tile in (64, 32, 16) if self.quad else (32, 64, 16):
+        for tile in candidates:
             tiles = sum(-(-count // tile) for count in frames)
             waves = 4 if tile == 64 else 8
             if tile == 64 and self.quad:

@@ -251,3 +251,177 @@ def test_score_counts_follow_the_plan():
     assert counts.tolist() == [int(plan.words[plan.utterance == u].sum())
                                for u in range(2)]
     assert counts.tolist() == [3, 3]
+
+
+###############################################################################
+# Device binding and failure propagation
+###############################################################################
+
+
+def _single_rank_group(tmp_path):
+    torch.distributed.init_process_group(
+        'gloo', rank=0, world_size=1,
+        init_method=f'file://{tmp_path}/rendezvous')
+
+
+def test_device_is_bound_before_the_first_collective(tmp_path, monkeypatch):
+    """Under nccl (= RCCL) a collective takes its tensors on the CURRENT
+    device, so both sharded entry points must make the rank's GPU current
+    before collective 1 - also for a rank whose shard is empty, also when a
+    `compute` is injected.  Recorded here with the backend reported as nccl,
+    `local_device` and the collectives' device patched (no GPU in this
+    container)."""
+    import emphases_amd
+    from emphases_amd import load, synth
+    _single_rank_group(tmp_path)
+    try:
+        events = []
+        monkeypatch.setattr(
+            torch.distributed, 'get_backend', lambda group=None: 'nccl')
+        monkeypatch.setattr(
+            edist, 'local_device', lambda: events.append('bind') or 0)
+
+        def device(group=None):
+            events.append('collective')
+            return torch.device('cpu')
+        monkeypatch.setattr(edist, 'collective_device', device)
+
+        frames = [120, 90]
+        audios = [torch.from_numpy(synth.audio(i, n))
+                  for i, n in enumerate(frames)]
+        aligns = [emphases_amd.Alignment.from_frames(
+            synth.word_frames(i, n, 3, 40)) for i, n in enumerate(frames)]
+
+        def compute(shard_alignments, shard_audios):
+            events.append('compute')
+            return [torch.zeros(1, len(a)) for a in shard_alignments]
+        edist.from_alignments_and_audios(aligns, audios, compute=compute)
+        assert events[0] == 'bind' and events.count('bind') == 1
+        assert events.index('bind') < events.index('collective') \
+            < events.index('compute')
+
+        # the file API: bound first, with files ...
+        texts, waves = [], []
+        for index, (audio, alignment) in enumerate(zip(audios, aligns)):
+            load.save_wav(tmp_path / f'b{index}.wav', audio.numpy(), 16000)
+            alignment.save(tmp_path / f'b{index}.TextGrid')
+            texts.append(tmp_path / f'b{index}.TextGrid')
+            waves.append(tmp_path / f'b{index}.wav')
+
+        def file_compute(own_text, own_audio, deliver):
+            events.append('compute')
+            for index, text in enumerate(own_text):
+                alignment = emphases_amd.Alignment(text)
+                deliver(index, alignment, torch.zeros(1, len(alignment)))
+        del events[:]
+        edist.from_files_to_files(
+            texts, waves, [tmp_path / f'o{i}' for i in range(2)],
+            compute=file_compute)
+        assert events[0] == 'bind' and events.count('bind') == 1
+        assert 'collective' in events
+        # ... and with an EMPTY shard (no files at all for this rank)
+        del events[:]
+        assert edist.from_files_to_files([], [], [], compute=file_compute) == []
+        assert events[0] == 'bind'
+        # gather=False (the command line): no collective at all
+        del events[:]
+        local = edist.from_files_to_files(
+            texts, waves, [tmp_path / f'p{i}' for i in range(2)],
+            compute=file_compute, gather=False)
+        assert sorted(local) == [0, 1] and 'collective' not in events
+        assert events[0] == 'bind'
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def _failing_worker(rank, world, port, queue, directory, stage):
+    """Rank 1 fails (`stage` 'plan': a corrupt alignment file; 'compute': its
+    engine raises); rank 0 must get RankFailure instead of hanging."""
+    from pathlib import Path
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import emphases_amd
+        directory = Path(directory)
+        count = len(FILE_FRAMES)
+        texts = [directory / f'u{i}.TextGrid' for i in range(count)]
+        audios = [directory / f'u{i}.wav' for i in range(count)]
+        prefixes = [directory / f'fail_{stage}_{i}' for i in range(count)]
+
+        def compute(own_text, own_audio, deliver):
+            if rank == 1 and stage == 'compute':
+                raise OSError('the engine of rank 1 broke')
+            for index, text in enumerate(own_text):
+                alignment = emphases_amd.Alignment(text)
+                deliver(index, alignment, torch.zeros(1, len(alignment)))
+        try:
+            edist.from_files_to_files(texts, audios, prefixes, compute=compute)
+            queue.put((rank, 'returned', ''))
+        except edist.RankFailure as error:
+            queue.put((rank, 'RankFailure', str(error)))
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize('stage', ['plan', 'compute'])
+def test_a_failing_rank_does_not_hang_the_others(tmp_path, stage):
+    texts, audios = _write_corpus(tmp_path)
+    world = 2
+    if stage == 'plan':
+        # corrupt one alignment of rank 1's shard
+        frames = [edist.frames_at_16k(f * r // 100, r)
+                  for f, r in zip(FILE_FRAMES, FILE_RATES)]
+        victim = int(edist.assign(edist.cost(frames), world)[1][0])
+        texts[victim].write_text('not a TextGrid')
+    context = mp.get_context('spawn')
+    queue = context.Queue()
+    port = _free_port()
+    workers = [context.Process(
+        target=_failing_worker,
+        args=(r, world, port, queue, str(tmp_path), stage))
+        for r in range(world)]
+    for worker in workers:
+        worker.start()
+    results = sorted(queue.get(timeout=120) for _ in workers)
+    for worker in workers:
+        worker.join(timeout=60)
+        assert worker.exitcode == 0
+    assert [r[1] for r in results] == ['RankFailure', 'RankFailure']
+    assert all('[1]' in r[2] for r in results)
+    # the failing rank's error names the cause, the other's only the rank
+    assert ('broke' in results[1][2]) == (stage == 'compute')
+    assert 'broke' not in results[0][2]
+
+
+def test_flat_score_exchange(tmp_path):
+    """exchange_scores(flat=True): one tensor in input order + sizes, from a
+    packed local tensor (what the strong-scaling bench hands over)."""
+    _single_rank_group(tmp_path)
+    try:
+        shards = [np.array([0, 1, 2])]
+        counts = edist.exchange_counts([2, 0, 3], shards)
+        local = torch.arange(5, dtype=torch.float32)
+        flat, sizes = edist.exchange_scores(local, counts, shards, flat=True)
+        assert sizes.tolist() == [2, 0, 3] and torch.equal(flat, local)
+        listed = edist.exchange_scores(
+            [local[:2], local[2:2], local[2:]], counts, shards)
+        assert [s.tolist() for s in listed] == [[0., 1.], [], [2., 3., 4.]]
+        with pytest.raises(edist.RankFailure):
+            edist.exchange_scores(local[:4], counts, shards)
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_score_order_interleaves_ranks():
+    """score_order: rank payloads are (most + 1) apart (scores + status word);
+    utterances come back in input order whatever the assignment."""
+    shards = [np.array([1, 3]), np.array([0, 2, 4])]
+    counts = np.array([[2, 1, 0], [3, 0, 2]])
+    order, sizes, most = edist.score_order(counts, shards)
+    assert most == 5 and sizes.tolist() == [3, 2, 0, 1, 2]
+    # rank 0's payload starts at 0, rank 1's at most + 1 = 6
+    assert order.tolist() == [6, 7, 8, 0, 1, 2, 9, 10]

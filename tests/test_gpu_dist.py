@@ -126,6 +126,74 @@ def test_bench_with_two_ranks(tmp_path):
     assert line['roofline']['frac'] > 0 and 'cpu_baseline' not in line
 
 
+def _bench(arguments, world, backend=None, timeout=900):
+    """bench.py the way the driver launches it: one process per rank."""
+    port = _free_port()
+    children = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank),
+                   WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        children.append(subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus',
+             str(world)] + arguments +
+            (['--backend', backend] if backend else []),
+            env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True))
+    outputs = [child.communicate(timeout=timeout)[0] for child in children]
+    assert all(child.returncode == 0 for child in children)
+    return [[l for l in out.splitlines() if l.startswith('{')]
+            for out in outputs]
+
+
+@pytest.mark.timeout(1200)
+def test_bench_strong_scaling_modes(tmp_path):
+    """`bench.py --workload corpus | longform` (BASELINE configs[3] / [4]
+    strong-scaled): the whole job sharded by dist.assign, both collectives
+    inside the timed region.  One rank under nccl (= RCCL) and two gloo ranks
+    sharing the box's one GPU must report the SAME job - same utterances,
+    frames, scores and checksum (all scores on every rank, input order) -
+    and the two-rank line names its shards."""
+    import json
+    common = ['--steps', '3', '--warmup', '1', '--regions', '2',
+              '--no-cpu-baseline']
+    for workload, extra, utterances in (
+            ('corpus', ['--corpus-utterances', '600'], 600),
+            ('longform', ['--longform-utterances', '4'], 4)):
+        arguments = common + ['--workload', workload] + extra
+        (one,) = _bench(arguments, 1)
+        assert len(one) == 1
+        one = json.loads(one[0])
+        first, second = _bench(arguments, 2, 'gloo')
+        assert len(first) == 1 and not second
+        two = json.loads(first[0])
+        for line, world in ((one, 1), (two, 2)):
+            job = line['job']
+            assert line['n_gpus'] == world and line['scaling'] == 'strong'
+            assert line['unit'] == 'utterances/s' and line['steps'] == 3
+            assert job['utterances'] == utterances
+            assert len(job['frames_per_rank']) == world
+            assert sum(job['frames_per_rank']) == job['frames']
+            assert job['lpt_imbalance'] < 1.05
+            assert abs(line['value'] - utterances /
+                       (line['ms_per_step'] * 1e-3)) < 1e-6 * line['value']
+            assert line['roofline']['frac'] > 0
+            assert 'timed' in line['config']['exchange']
+        assert two['job']['scores'] == one['job']['scores']
+        assert two['job']['checksum'] == one['job']['checksum']   # bitwise
+
+
+def test_bench_refuses_a_mismatched_world():
+    """`--gpus` must be the size of the process group bench.py runs in."""
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    child = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2',
+         '--no-cpu-baseline'], env=env, cwd=ROOT, capture_output=True,
+        text=True, timeout=300)
+    assert child.returncode != 0
+    assert 'process group of 1' in child.stderr
+
+
 @pytest.mark.timeout(900)
 def test_sharded_file_api(tmp_path):
     """dist.from_files_to_files (core.py:115-179 over a process group): 200
