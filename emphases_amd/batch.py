@@ -312,7 +312,17 @@ class Plan:
     def __len__(self):
         return len(self.frames)
 
-    def tiles(self, axis, block):
+    def tiles(self, axis, block, least=None, most=None):
+        """Tile table of an axis; `least` / `most`: only the tiles of segments
+        with that many positions (which kernel takes a segment then depends
+        on the segment alone, never on what else is in the batch)."""
+        if least is not None:
+            key = (axis, block, least, most)
+            if key not in self._tiles:
+                rows = self.tiles(axis, block)
+                keep = (rows[:, 3] >= least) & (rows[:, 3] <= most)
+                self._tiles[key] = np.ascontiguousarray(rows[keep])
+            return self._tiles[key]
         key = (axis, block)
         if key not in self._tiles:
             if axis == runtime.AXIS_FRAMES:
@@ -344,9 +354,9 @@ class Plan:
         pieces = [('table', self.table.view(np.int32).ravel()),
                   ('bounds', self.bounds.ravel()),
                   ('word_segment', self.word_segment)]
-        for axis, block in tile_requests:
+        for request in tile_requests:
             pieces.append(
-                (('tiles', axis, block), self.tiles(axis, block).ravel()))
+                (('tiles',) + tuple(request), self.tiles(*request).ravel()))
         offsets = {}
         cursor = 0
         chunks = []

@@ -270,7 +270,8 @@ def preprocess(alignment, audio, sample_rate=cfg.SAMPLE_RATE, batch_size=None,
     `(features [1, NUM_FEATURES, Fc] on the device, word_bounds int64
     [1, 2, Wc] on the CPU)` per chunk."""
     engine = get_engine(None, gpu)
-    audio = resample(audio, sample_rate)[:1].reshape(-1).to(torch.float32)
+    audio = resample(audio[:1] if audio.dim() == 2 else audio, sample_rate,
+                     gpu=gpu).reshape(-1).to(torch.float32)
     segments = batch.chunk_utterance(alignment, int(audio.shape[0]), batch_size)
     if not segments:
         return
@@ -404,8 +405,16 @@ def inference_context(model=None):
         yield
 
 
-def resample(audio, sample_rate, target_rate=cfg.SAMPLE_RATE):
-    """`core.py:613-619` (torchaudio sinc resampler, third-party)."""
-    if sample_rate == target_rate:
+def resample(audio, sample_rate, target_rate=cfg.SAMPLE_RATE, gpu=None):
+    """`core.py:613-619` (torchaudio's windowed-sinc `Resample`, third-party)
+    on the device: `emph_resample`, the one resampler of the package.  audio
+    [..., S] float (or int16 = 16-bit PCM) -> float32 [..., S'], on the
+    device the input is on (a host tensor comes back on the host)."""
+    if int(sample_rate) == int(target_rate):
         return audio
-    return load.resample(audio, sample_rate, target_rate)
+    session = get_session(None, gpu if gpu is not None or not audio.is_cuda
+                          else audio.device.index)
+    rows = audio.reshape(-1, audio.shape[-1])
+    out = session.resample(
+        list(rows), sample_rate, target_rate, on_device=audio.is_cuda)
+    return torch.stack(out).reshape(audio.shape[:-1] + (out[0].shape[0],))

@@ -30,6 +30,17 @@ from . import weights as weights_module
 FRONTEND_BLOCK = None   # frames per front-end tile: emph_frontend_block()
 ATTENTION_BLOCK = 64    # queries per attention wave (csrc/transformer.hip)
 ATTENTION_GROUP = 256   # queries per attention workgroup (LDS-staged keys/values)
+# Which kernel takes a segment depends on the segment alone (scores must not
+# depend on the rest of the batch): frame-axis segments of at least
+# GROUPED_FROM positions take the workgroup attention kernel, shorter ones the
+# one-wave kernel; word-axis segments of at most FUSED_WORDS words take the
+# one-launch decoder (csrc/word_transformer.hip), longer ones the per-layer
+# kernels.
+GROUPED_FROM = ATTENTION_GROUP // 2
+FUSED_WORDS = 64
+EVERYTHING = 1 << 30
+SHORT, LONG = (0, GROUPED_FROM - 1), (GROUPED_FROM, EVERYTHING)
+FEW_WORDS, MANY_WORDS = (0, FUSED_WORDS), (FUSED_WORDS + 1, EVERYTHING)
 WORD_TILE = 16
 WINOGRAD_LDS_BUDGET = 160 * 1024
 
@@ -385,10 +396,16 @@ class Engine:
             # (the fused projection / block kernels own 32 positions per wave,
             # whatever tile the input layer's conv kernel takes)
             requests += [(runtime.AXIS_FRAMES, ATTENTION_BLOCK),
-                         (runtime.AXIS_FRAMES, ATTENTION_GROUP),
+                         (runtime.AXIS_FRAMES, ATTENTION_BLOCK) + SHORT,
+                         (runtime.AXIS_FRAMES, ATTENTION_GROUP) + LONG,
                          (runtime.AXIS_FRAMES, 32)]
             if not nested:
                 requests += [(runtime.AXIS_WORDS, ATTENTION_BLOCK)]
+                if self.word_transformer is not None:
+                    requests += [
+                        (runtime.AXIS_WORDS, ATTENTION_BLOCK) + FEW_WORDS,
+                        (runtime.AXIS_WORDS, ATTENTION_BLOCK) + MANY_WORDS,
+                        (runtime.AXIS_WORDS, self.word_block) + MANY_WORDS]
         requests = list(dict.fromkeys(requests))
         host, offsets = plan.pack_metadata(requests)
         pinned = self._pinned(('meta', nested), host)
@@ -576,17 +593,21 @@ class Engine:
         return out
 
     def _transformer(self, layers, x, ld, plan, meta, axis, block, tag,
-                     key_counts=None, positioned=False):
+                     key_counts=None, positioned=False, select=()):
         """`Transformer.forward` (transformer.py:25-30) in place on x
         (`positioned`: the producer of x has added the encoding already).
         `key_counts`: int32 device tensor, real (unpadded) positions per
-        segment, for the key-padding mask over zero-padded word pieces."""
+        segment, for the key-padding mask over zero-padded word pieces.
+        `select`: (least, most) positions - only the segments of that size
+        (their tiles), the others' columns are left alone."""
         config = self.config
         channels = config.channels
-        if block > 32 and ('tiles', axis, 32) in meta:
+        if block > 32 and ('tiles', axis, 32) + select in meta:
             block = 32
-        att_tiles, att_size = meta[('tiles', axis, ATTENTION_BLOCK)]
+        att_tiles, att_size = meta[('tiles', axis, ATTENTION_BLOCK) + select]
         att_count = att_size // runtime.TILE_FIELDS
+        if att_count == 0:
+            return x
         counts = plan.frames if axis == runtime.AXIS_FRAMES else plan.words
         if len(counts) and int(counts.max()) > cfg.MAX_POSITIONS:
             # transformer.py:40,51-52: the encoding table has 5000 rows
@@ -606,15 +627,20 @@ class Engine:
         projected = self._buffer(tag + '_projected', channels, ld)
         attention_flops = 4. * channels * float(
             (counts.astype(np.float64) ** 2).sum())
-        # long segments: a workgroup of four waves shares each key / value
+        # long segments: a workgroup of eight waves shares each key / value
         # block through LDS; short ones (the word axis, word pieces): one wave
-        # per 64 queries straight from L2
-        grouped = axis == runtime.AXIS_FRAMES and len(counts) and \
-            ('tiles', axis, ATTENTION_GROUP) in meta and \
-            float(counts.mean()) >= ATTENTION_GROUP / 2
-        if grouped:
-            group_tiles, group_size = meta[('tiles', axis, ATTENTION_GROUP)]
-            group_count = group_size // runtime.TILE_FIELDS
+        # per 64 queries straight from L2.  By SEGMENT, not by batch: two tile
+        # tables, at most two launches per layer.
+        launches = [(att_tiles, att_count, ATTENTION_BLOCK)]
+        if axis == runtime.AXIS_FRAMES and not select and \
+                ('tiles', axis, ATTENTION_GROUP) + LONG in meta:
+            launches = []
+            for key, size in (((ATTENTION_BLOCK,) + SHORT, ATTENTION_BLOCK),
+                              ((ATTENTION_GROUP,) + LONG, ATTENTION_GROUP)):
+                tiles, length = meta[('tiles', axis) + key]
+                if length:
+                    launches.append(
+                        (tiles, length // runtime.TILE_FIELDS, size))
 
         def add_layernorm(norm):
             with self._timed('add_layernorm'):
@@ -630,7 +656,7 @@ class Engine:
                 pass
             elif layer['qkv'] is not None and block <= 32:
                 packs, bias = layer['qkv']
-                tiles, size = meta[('tiles', axis, block)]
+                tiles, size = meta[('tiles', axis, block) + select]
                 with self._timed(f'qkv_projection_{tag}', 6. * channels * channels *
                                  meta['positions'][axis]):
                     runtime.check(self.lib.emph_qkv_projection(
@@ -645,18 +671,17 @@ class Engine:
                            None, transpose_out=True)
             projected_ahead = False
             with self._timed(f'attention_{tag}', attention_flops):
-                runtime.check(self.lib.emph_attention(
-                    qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld,
-                    channels, config.heads,
-                    (group_tiles if grouped else att_tiles).data_ptr(),
-                    group_count if grouped else att_count,
-                    ATTENTION_GROUP if grouped else ATTENTION_BLOCK,
-                    None if key_counts is None else key_counts.data_ptr(),
-                    runtime.stream()), 'emph_attention')
+                for tiles, count, tile_n in launches:
+                    runtime.check(self.lib.emph_attention(
+                        qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld,
+                        channels, config.heads, tiles.data_ptr(), count,
+                        tile_n,
+                        None if key_counts is None else key_counts.data_ptr(),
+                        runtime.stream()), 'emph_attention')
             if layer['block_qkv'] is not None and block <= 32 and self.fuse_qkv:
                 # (attention has consumed qk / v: the next layer's go there)
                 packs, vectors = layer['block_qkv']
-                tiles, size = meta[('tiles', axis, block)]
+                tiles, size = meta[('tiles', axis, block) + select]
                 with self._timed(f'transformer_block_qkv_{tag}', 12. * channels *
                                  channels * meta['positions'][axis]):
                     runtime.check(self.lib.emph_transformer_block_qkv(
@@ -670,7 +695,7 @@ class Engine:
                 continue
             if layer['block'] is not None and block <= 32:
                 packs, vectors = layer['block']
-                tiles, size = meta[('tiles', axis, block)]
+                tiles, size = meta[('tiles', axis, block) + select]
                 with self._timed(f'transformer_block_{tag}', 6. * channels *
                                  channels * meta['positions'][axis]):
                     runtime.check(self.lib.emph_transformer_block(
@@ -702,17 +727,24 @@ class Engine:
                 x, other = other, x
             return x
         if axis == runtime.AXIS_WORDS and self.word_transformer is not None \
-                and key_counts is None and len(plan.words) and \
-                int(plan.words.max()) <= 64:
-            tiles, size = meta[('tiles', axis, ATTENTION_BLOCK)]
-            with self._timed('word_transformer'):
-                runtime.check(self.lib.emph_word_transformer(
-                    x.data_ptr(), ld, self.position.data_ptr(),
-                    cfg.MAX_POSITIONS, config.channels, config.heads,
-                    self.word_transformer.data_ptr(), len(layers),
-                    config.layer_norm_eps, tiles.data_ptr(),
-                    size // runtime.TILE_FIELDS, runtime.stream()),
-                    'emph_word_transformer')
+                and key_counts is None and len(plan.words):
+            # segments of up to 64 words: the whole decoder in one launch;
+            # longer ones: the per-layer kernels on THEIR tiles (disjoint
+            # columns of x; which path a segment takes depends on it alone)
+            tiles, size = meta[('tiles', axis, ATTENTION_BLOCK) + FEW_WORDS]
+            if size:
+                with self._timed('word_transformer'):
+                    runtime.check(self.lib.emph_word_transformer(
+                        x.data_ptr(), ld, self.position.data_ptr(),
+                        cfg.MAX_POSITIONS, config.channels, config.heads,
+                        self.word_transformer.data_ptr(), len(layers),
+                        config.layer_norm_eps, tiles.data_ptr(),
+                        size // runtime.TILE_FIELDS, runtime.stream()),
+                        'emph_word_transformer')
+            if int(plan.words.max()) > FUSED_WORDS:
+                self._transformer(
+                    layers, x, ld, plan, meta, axis, block, tag, key_counts,
+                    positioned, select=MANY_WORDS)
             return x
         return self._transformer(
             layers, x, ld, plan, meta, axis, block, tag, key_counts, positioned)

@@ -5,8 +5,10 @@ The reference delegates both to `torchaudio` (third-party, absent here), so
 this module carries its own RIFF/WAVE reader (PCM 8/16/24/32-bit and IEEE
 float) and a restatement of torchaudio's default `Resample` — windowed-sinc
 polyphase interpolation, Hann window, `lowpass_filter_width=6`,
-`rolloff=0.99` — from its published algorithm (parity-unpinned).  Both run on
-the host: they are file plumbing, not part of the accelerated path.
+`rolloff=0.99` — from its published algorithm (parity-unpinned).  The reader
+runs on the host (file plumbing); of the resampler only the TABLE is built
+here (`resample_kernel`, float64 on the host like every weight pack): the
+arithmetic is `emph_resample` on the device, for every caller.
 """
 import math
 import struct
@@ -17,56 +19,76 @@ import torch
 from . import config as cfg
 
 
-def wav(file, raw=False):
-    """Read a RIFF/WAVE file -> (float32 tensor [channels, samples], rate).
-    `raw`: 16-bit PCM comes back as an int16 tensor (x / 32768 is what the
-    float form holds; the HIP front-end applies it on the device)."""
-    with open(file, 'rb') as handle:
-        data = handle.read()
-    if data[:4] != b'RIFF' or data[8:12] != b'WAVE':
+# (format code, bits per sample) the reader accepts
+FORMATS = {(1, 8), (1, 16), (1, 24), (1, 32), (3, 32), (3, 64)}
+
+
+def _walk(handle, file):
+    """ONE chunk walker for `wav` and `wav_info` (seeks, no sample is read):
+    `(code, channels, rate, bits, data offset, data bytes)`.  The LAST `fmt `
+    and the LAST `data` chunk count, in any order; a data chunk that claims
+    more bytes than the file holds is cut to what is there; odd-sized chunks
+    are padded to even offsets."""
+    head = handle.read(12)
+    if len(head) < 12 or head[:4] != b'RIFF' or head[8:12] != b'WAVE':
         raise ValueError(f'{file} is not a RIFF/WAVE file')
+    handle.seek(0, 2)
+    end = handle.tell()
     cursor = 12
-    fmt = None
-    samples = None
-    while cursor + 8 <= len(data):
-        tag = data[cursor:cursor + 4]
-        size = struct.unpack('<I', data[cursor + 4:cursor + 8])[0]
-        body = data[cursor + 8:cursor + 8 + size]
+    fmt = data = None
+    while cursor + 8 <= end:
+        handle.seek(cursor)
+        header = handle.read(8)
+        tag, size = header[:4], struct.unpack('<I', header[4:])[0]
         if tag == b'fmt ':
+            body = handle.read(min(size, 40))
+            if len(body) < 16:
+                raise ValueError(f'{file}: fmt chunk of {len(body)} bytes')
             code, channels, rate, _, _, bits = struct.unpack(
                 '<HHIIHH', body[:16])
             if code == 0xFFFE and len(body) >= 26:      # WAVE_FORMAT_EXTENSIBLE
                 code = struct.unpack('<H', body[24:26])[0]
             fmt = (code, channels, rate, bits)
         elif tag == b'data':
-            samples = body
+            data = (cursor + 8, min(size, end - cursor - 8))
         cursor += 8 + size + (size & 1)
-    if fmt is None or samples is None:
+    if fmt is None or data is None:
         raise ValueError(f'{file} has no fmt/data chunk')
     code, channels, rate, bits = fmt
+    if (code, bits) not in FORMATS or channels < 1:
+        raise ValueError(
+            f'{file}: unsupported WAVE format {code}/{bits} '
+            f'({channels} channels)')
+    return code, channels, rate, bits, data[0], data[1]
+
+
+def wav(file, raw=False):
+    """Read a RIFF/WAVE file -> (float32 tensor [channels, samples], rate).
+    `raw`: 16-bit PCM comes back as an int16 tensor (x / 32768 is what the
+    float form holds; the HIP front-end applies it on the device)."""
+    with open(file, 'rb') as handle:
+        code, channels, rate, bits, offset, nbytes = _walk(handle, file)
+        frame = bits // 8 * channels
+        nbytes = nbytes // frame * frame
+        handle.seek(offset)
+        samples = np.fromfile(handle, dtype=np.uint8, count=nbytes)
     if code == 1 and bits == 8:
-        values = (np.frombuffer(samples, dtype=np.uint8).astype(np.float32)
-                  - 128.) / 128.
+        values = (samples.astype(np.float32) - 128.) / 128.
     elif code == 1 and bits == 16 and raw:
-        values = np.frombuffer(samples, dtype='<i2').astype(np.int16)
+        values = samples.view('<i2').astype(np.int16, copy=False)
     elif code == 1 and bits == 16:
-        values = np.frombuffer(samples, dtype='<i2').astype(np.float32) / 32768.
+        values = samples.view('<i2').astype(np.float32) / 32768.
     elif code == 1 and bits == 24:
-        raw = np.frombuffer(samples[:len(samples) // 3 * 3], dtype=np.uint8)
-        raw = raw.reshape(-1, 3).astype(np.int32)
-        values = (raw[:, 0] | (raw[:, 1] << 8) | (raw[:, 2] << 16))
+        triples = samples.reshape(-1, 3).astype(np.int32)
+        values = triples[:, 0] | (triples[:, 1] << 8) | (triples[:, 2] << 16)
         values = np.where(values >= 1 << 23, values - (1 << 24), values)
         values = values.astype(np.float32) / float(1 << 23)
     elif code == 1 and bits == 32:
-        values = np.frombuffer(samples, dtype='<i4').astype(np.float32) / \
-            float(1 << 31)
+        values = samples.view('<i4').astype(np.float32) / float(1 << 31)
     elif code == 3 and bits == 32:
-        values = np.frombuffer(samples, dtype='<f4').astype(np.float32)
-    elif code == 3 and bits == 64:
-        values = np.frombuffer(samples, dtype='<f8').astype(np.float32)
+        values = samples.view('<f4').astype(np.float32, copy=False)
     else:
-        raise ValueError(f'{file}: unsupported WAVE format {code}/{bits}')
-    values = values[:len(values) // channels * channels]
+        values = samples.view('<f8').astype(np.float32)
     return torch.from_numpy(
         np.ascontiguousarray(values.reshape(-1, channels).T)), rate
 
@@ -74,36 +96,11 @@ def wav(file, raw=False):
 def wav_info(file):
     """(sample rate, channels, samples per channel) from the headers of a
     RIFF/WAVE file alone: the chunk list is walked with seeks, the samples are
-    not read (what a sharded run plans from, `dist.from_files_to_files`)."""
+    not read (what a sharded run plans from, `dist.from_files_to_files`).
+    Same walker, same validation as `wav`: the two cannot disagree."""
     with open(file, 'rb') as handle:
-        head = handle.read(12)
-        if head[:4] != b'RIFF' or head[8:12] != b'WAVE':
-            raise ValueError(f'{file} is not a RIFF/WAVE file')
-        fmt = None
-        while True:
-            header = handle.read(8)
-            if len(header) < 8:
-                break
-            tag, size = header[:4], struct.unpack('<I', header[4:])[0]
-            if tag == b'fmt ':
-                body = handle.read(size)
-                _, channels, rate, _, _, bits = struct.unpack(
-                    '<HHIIHH', body[:16])
-                fmt = (rate, channels, bits)
-                handle.seek(size & 1, 1)
-            elif tag == b'data':
-                if fmt is None:
-                    break
-                rate, channels, bits = fmt
-                # (a data chunk that claims more than the file holds: `wav`
-                # reads what is there)
-                here = handle.tell()
-                handle.seek(0, 2)
-                size = min(size, handle.tell() - here)
-                return rate, channels, size // (bits // 8) // channels
-            else:
-                handle.seek(size + (size & 1), 1)
-    raise ValueError(f'{file} has no fmt/data chunk')
+        _, channels, rate, bits, _, nbytes = _walk(handle, file)
+    return rate, channels, nbytes // (bits // 8 * channels)
 
 
 def save_wav(file, audio, sample_rate=cfg.SAMPLE_RATE):
@@ -126,11 +123,10 @@ def audio(file, raw=False):
     16 kHz 16-bit PCM file is returned as int16 (no conversion, half the
     bytes); anything else as float32 like the reference."""
     samples, rate = wav(file, raw)
-    if samples.dtype == torch.int16:
-        if rate == cfg.SAMPLE_RATE:
-            return samples
-        samples = samples.to(torch.float32) / 32768.
-    return resample(samples, rate)
+    if rate == cfg.SAMPLE_RATE:
+        return samples
+    from . import core
+    return core.resample(samples, rate)       # on the device: emph_resample
 
 
 def resample_kernel(sample_rate, target_rate=cfg.SAMPLE_RATE,
@@ -158,23 +154,3 @@ def resample_kernel(sample_rate, target_rate=cfg.SAMPLE_RATE,
 
 def resampled_length(length, orig, new):
     return int(math.ceil(new * length / orig))
-
-
-def resample(audio, sample_rate, target_rate=cfg.SAMPLE_RATE,
-             lowpass_filter_width=6, rolloff=0.99):
-    """Windowed-sinc resampling on the HOST (torchaudio.transforms.Resample
-    defaults): file plumbing and the checker of the device version
-    (`emph_resample`, which the batch API uses)."""
-    sample_rate, target_rate = int(sample_rate), int(target_rate)
-    if sample_rate == target_rate:
-        return audio
-    kernel, orig, new, width = resample_kernel(
-        sample_rate, target_rate, lowpass_filter_width, rolloff)
-    shape = audio.shape
-    flat = audio.reshape(-1, shape[-1]).to(torch.float32).cpu()
-    length = flat.shape[-1]
-    flat = torch.nn.functional.pad(flat, (width, width + orig))
-    result = torch.nn.functional.conv1d(flat[:, None], kernel, stride=orig)
-    result = result.transpose(1, 2).reshape(flat.shape[0], -1)
-    target = resampled_length(length, orig, new)
-    return result[..., :target].reshape(shape[:-1] + (target,))

@@ -222,20 +222,22 @@ class Session:
         self.lanes = [_Lane(engine) for _ in range(max(1, depth))]
         self._cursor = 0
         self._lock = threading.Lock()
-        self._kernels = {}        # sample rate -> resampling kernel on the device
+        self._kernels = {}        # (rate, target) -> resampling kernel on the device
 
-    def _resample(self, lane, audios, lengths, dtype, sample_rate):
+    def _resample(self, lane, audios, lengths, dtype, sample_rate,
+                  target_rate=cfg.SAMPLE_RATE):
         """`emphases.resample` (`core.py:613-619`) for the whole batch on the
         device: stage the audio at its own rate, one `emph_resample` launch
-        into the lane's packed 16 kHz buffer.  Returns (packed float32 device
-        tensor, lengths at 16 kHz)."""
+        into the lane's packed buffer at `target_rate`.  Returns (packed
+        float32 device tensor, lengths at the target rate)."""
         from . import runtime
-        if sample_rate not in self._kernels:
-            kernel, orig, new, width = load.resample_kernel(sample_rate)
-            self._kernels[sample_rate] = (
+        rates = (int(sample_rate), int(target_rate))
+        if rates not in self._kernels:
+            kernel, orig, new, width = load.resample_kernel(*rates)
+            self._kernels[rates] = (
                 kernel.reshape(new, -1).contiguous().to(lane.device),
                 orig, new, width)
-        kernel, orig, new, width = self._kernels[sample_rate]
+        kernel, orig, new, width = self._kernels[rates]
         targets = [load.resampled_length(n, orig, new) for n in lengths]
         source = np.cumsum([0] + lengths)
         target = np.cumsum([0] + targets)
@@ -253,6 +255,44 @@ class Session:
             kernel.data_ptr(), orig, new, width, out.data_ptr(),
             runtime.stream()), 'emph_resample')
         return out, targets
+
+    def resample(self, audios, sample_rate, target_rate=cfg.SAMPLE_RATE,
+                 on_device=False):
+        """`emphases.resample` (`core.py:613-619`) of 1-D tensors (float32, or
+        int16 = 16-bit PCM) on the device - the ONE resampler of the package:
+        the batch API, the step API (`core.preprocess`), `load.audio` and the
+        pitch tracker's 16 kHz input all come through `emph_resample`.
+        Returns float32 tensors (on the device, or on the host)."""
+        audios = [audio.reshape(-1) for audio in audios]
+        if not audios:
+            return []
+        pcm = all(audio.dtype == torch.int16 for audio in audios)
+        dtype = torch.int16 if pcm else torch.float32
+        if not pcm:
+            audios = [audio.to(torch.float32) / 32768.
+                      if audio.dtype == torch.int16 else audio.to(torch.float32)
+                      for audio in audios]
+        lengths = [int(audio.shape[0]) for audio in audios]
+        _, orig, new, _ = load.resample_kernel(sample_rate, target_rate)
+        targets = [load.resampled_length(n, orig, new) for n in lengths]
+        with self._lock:
+            lane = self.lanes[self._cursor % len(self.lanes)]
+            self._cursor += 1
+        with lane.lock:
+            if lane.pending is not None:
+                lane.pending.result()
+            lane._reserve(max(sum(targets) * 4, sum(lengths) * 4), 1)
+            if any(audio.is_cuda for audio in audios):
+                lane.stream.wait_stream(torch.cuda.current_stream(lane.device))
+            with torch.cuda.device(lane.device), \
+                    torch.cuda.stream(lane.stream):
+                packed, _ = self._resample(
+                    lane, audios, lengths, dtype, sample_rate, target_rate)
+                packed = packed.clone() if on_device else packed.cpu()
+            lane.stream.synchronize()
+        if on_device:
+            packed.record_stream(torch.cuda.current_stream(lane.device))
+        return list(packed.split(targets))
 
     def submit(self, alignments, audios, sample_rate=cfg.SAMPLE_RATE,
                batch_size=None, on_device=False, pitch_tracker=None):
@@ -341,11 +381,12 @@ class Session:
                     engine.config.periodicity_feature:
                 from . import core
                 # (the tracker runs on the host and wants 16 kHz audio)
-                heard = audios if not resampling else [
-                    load.resample(
-                        (a.to(torch.float32) / 32768.
-                         if a.dtype == torch.int16 else a).cpu(),
-                        sample_rate) for a in audios]
+                heard = audios
+                if resampling:
+                    heard, _ = self._resample(
+                        lane, audios, raw_lengths, dtype_in, sample_rate)
+                    lane.stream.synchronize()
+                    heard = list(heard.cpu().split(lengths))
                 tracks = core._tracks(
                     engine, plan, heard, pitch_tracker, lane.device.index)
             if resampling:

@@ -579,7 +579,7 @@ def test_file_api_and_cli(tmp_path, cases):
     assert len(saved) == len(words)
     # a batch of files at different sample rates: the 8 kHz one is resampled
     # on the device (emph_resample), a rate per submission
-    low = load.resample(torch.from_numpy(audio), 16000, 8000)
+    low = emphases_amd.resample(torch.from_numpy(audio), 16000, 8000)
     load.save_wav(tmp_path / 'low.wav', low.numpy(), 8000)
     emphases_amd.from_files_to_files(
         [tmp_path / 'utt.TextGrid', tmp_path / 'utt.TextGrid'],
@@ -589,7 +589,8 @@ def test_file_api_and_cli(tmp_path, cases):
     pcm, rate = load.wav(tmp_path / 'low.wav', raw=True)
     assert rate == 8000 and pcm.dtype == torch.int16
     want = emphases_amd.from_alignment_and_audio(
-        words, load.resample(pcm.to(torch.float32) / 32768., 8000), 16000)
+        words, emphases_amd.resample(pcm.to(torch.float32) / 32768., 8000),
+        16000)
     got = torch.load(tmp_path / 'low.pt')
     assert got.shape == want.shape
     assert float((got - want).abs().max()) < 1e-5
@@ -893,3 +894,44 @@ def test_odd_lengths_and_offsets(default_engine):
         want = oracle.from_alignment_and_audio(times, audios[index], state)
         assert a.shape == want.shape
         assert np.abs(a.numpy() - want.numpy()).max() < SCORE_TOLERANCE
+
+
+@pytest.mark.parametrize('rate', [8000, 22050, 44100])
+def test_one_resampler_for_every_entry_point(rate):
+    """`emph_resample` is the only resampler of the package: the step API
+    (`preprocess`), the public `resample`, `load.audio` and the batch API all
+    come through it, so their results are BITWISE equal at any input rate
+    (round 3's step API resampled on the host with a torch CPU conv1d and
+    agreed with the batch API to 2e-6)."""
+    from oracle import resample as oracle_resample
+    seconds_long = 2.5
+    audio = torch.from_numpy(
+        synth.weights(300 + rate, (1, int(rate * seconds_long)), 0.4))
+    frames = int(16000 * seconds_long) // 160
+    words = emphases_amd.Alignment.from_frames(
+        synth.word_frames(rate, frames, 3, 40))
+    # the public resample: against the independent restatement, host in ->
+    # host out, device in -> device out, same bits
+    heard = emphases_amd.resample(audio, rate)
+    assert not heard.is_cuda and heard.dtype == torch.float32
+    want = oracle_resample.resample(audio[0].numpy(), rate)
+    assert heard.shape == (1, len(want))
+    assert np.abs(heard[0].numpy() - want).max() < 2e-6
+    on_device = emphases_amd.resample(audio.cuda(), rate)
+    assert on_device.is_cuda and torch.equal(on_device.cpu(), heard)
+    # step API at the file's rate == step API on the resampled audio
+    direct = list(emphases_amd.preprocess(words, audio, rate, gpu=0))
+    staged = list(emphases_amd.preprocess(words, heard, 16000, gpu=0))
+    assert len(direct) == len(staged) == 1
+    assert torch.equal(direct[0][0], staged[0][0])
+    assert torch.equal(direct[0][1], staged[0][1])
+    # batch API == step API, scores
+    features, bounds = direct[0]
+    stepped = emphases_amd.postprocess(emphases_amd.infer(features, bounds))
+    batched = emphases_amd.from_alignment_and_audio(words, audio, rate, gpu=0)
+    assert torch.equal(stepped[0], batched)
+    # no torch CPU convolution is reachable from the package
+    import inspect
+    from emphases_amd import load
+    assert 'conv1d' not in inspect.getsource(load)
+    assert not hasattr(load, 'resample')

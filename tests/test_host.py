@@ -317,6 +317,89 @@ item []:
     words = emphases_amd.Alignment(file)
     assert [str(w) for w in words] == ['hi', alignment.SILENCE]
     assert words.word_bounds(16000, 160, silences=True) == [(0, 50), (50, 100)]
+    # the phoneme tier is kept (the reference saves the alignment it loaded,
+    # both tiers: emphases/core.py:105-112) ...
+    assert [[str(p) for p in w.phonemes] for w in words] == \
+        [['HH', 'AY'], [alignment.SILENCE]]
+    assert [(p.start(), p.end()) for p in words.phonemes()] == \
+        [(0., .3), (.3, .5), (.5, 1.)]
+    assert words.tiers == ('words', 'phones', True)
+    # ... and written back: tier names, tier order, every interval
+    words.save(tmp_path / 'again.TextGrid')
+    again = emphases_amd.Alignment(tmp_path / 'again.TextGrid')
+    assert again.tiers == words.tiers
+    assert [str(w) for w in again] == [str(w) for w in words]
+    assert np.array_equal(again.times(), words.times())
+    assert again.phonemes() == words.phonemes()
+    first, second = (tmp_path / 'again.TextGrid').read_text().split('item [2]')
+    assert 'name = "phones"' in first and 'name = "words"' in second
+    assert 'size = 2' in first
+    # json keeps them too
+    words.save(tmp_path / 'again.json')
+    assert emphases_amd.Alignment(tmp_path / 'again.json').phonemes() == \
+        words.phonemes()
+    # the same file in Praat's SHORT text format, and as UTF-16 (what Praat
+    # writes when a label is not ASCII), with and without BOM
+    short = '\n'.join([
+        'File type = "ooTextFile"', 'Object class = "TextGrid"', '',
+        '0', '1.0', '<exists>', '2',
+        '"IntervalTier"', '"phones"', '0', '1.0', '3',
+        '0', '0.3', '"HH"', '0.3', '0.5', '"AY"', '0.5', '1.0', '"sp"',
+        '"IntervalTier"', '"words"', '0', '1.0', '2',
+        '0', '0.5', '"hi"', '0.5', '1.0', '""', ''])
+    for name, data in (
+            ('short', short.encode('utf-8')),
+            ('short_bom', b'\xef\xbb\xbf' + short.encode('utf-8')),
+            ('long16', text.encode('utf-16')),
+            ('long16be', text.encode('utf-16-be')),
+            ('short16le', short.encode('utf-16-le'))):
+        (tmp_path / f'{name}.TextGrid').write_bytes(data)
+        other = emphases_amd.Alignment(tmp_path / f'{name}.TextGrid')
+        assert [str(w) for w in other] == [str(w) for w in words], name
+        assert np.array_equal(other.times(), words.times()), name
+        assert other.phonemes() == words.phonemes(), name
+        assert other.tiers == words.tiers, name
+
+
+def test_textgrid_odd_content(tmp_path):
+    """Labels with doubled quotes, digits and '=' inside, non-ASCII text,
+    exponent notation, a point tier beside the interval tiers, a file that
+    ends early."""
+    text = '\n'.join([
+        'File type = "ooTextFile"', 'Object class = "TextGrid"', '',
+        'xmin = 0', 'xmax = 2.5e0', 'tiers? <exists>', 'size = 2', 'item []:',
+        '    item [1]:', '        class = "TextTier"',
+        '        name = "marks"', '        xmin = 0', '        xmax = 2.5',
+        '        points: size = 1', '        points [1]:',
+        '            number = 1.25', '            mark = "x = 3"',
+        '    item [2]:', '        class = "IntervalTier"',
+        '        name = "word"', '        xmin = 0', '        xmax = 2.5',
+        '        intervals: size = 3',
+        '        intervals [1]:', '            xmin = 0',
+        '            xmax = 5e-1', '            text = "say ""2.5"" = x"',
+        '        intervals [2]:', '            xmin = 0.5',
+        '            xmax = 1.75', '            text = "naïve café"',
+        '        intervals [3]:', '            xmin = 1.75',
+        '            xmax = 2.5', '            text = "42"', ''])
+    file = tmp_path / 'odd.TextGrid'
+    file.write_text(text, encoding='utf-8')
+    words = emphases_amd.Alignment(file)
+    assert [str(w) for w in words] == [
+        'say "2.5" = x', 'naïve café', '42']
+    assert words.times().tolist() == [[0., .5], [.5, 1.75], [1.75, 2.5]]
+    assert words.tiers[0] == 'word' and not words.phonemes()
+    words.save(tmp_path / 'odd_again.TextGrid')
+    again = emphases_amd.Alignment(tmp_path / 'odd_again.TextGrid')
+    assert [str(w) for w in again] == [str(w) for w in words]
+    assert 'name = "word"' in (tmp_path / 'odd_again.TextGrid').read_text(
+        encoding='utf-8')
+    (tmp_path / 'cut.TextGrid').write_text(
+        text[:text.index('intervals [3]')], encoding='utf-8')
+    with pytest.raises(ValueError):
+        emphases_amd.Alignment(tmp_path / 'cut.TextGrid')
+    (tmp_path / 'not.TextGrid').write_text('hello')
+    with pytest.raises(ValueError):
+        emphases_amd.Alignment(tmp_path / 'not.TextGrid')
 
 
 def test_wav_roundtrip_and_resample(tmp_path):
@@ -326,14 +409,18 @@ def test_wav_roundtrip_and_resample(tmp_path):
     loaded, rate = load.wav(file)
     assert rate == 16000 and np.array_equal(loaded.numpy(), audio)
     assert np.array_equal(load.audio(file).numpy(), audio)
-    # 8 kHz tone survives 2x upsampling
+    # the resampling TABLE is host arithmetic (the kernel that applies it is
+    # `emph_resample`, tests/test_gpu_ops.py): every phase of the polyphase
+    # filter passes DC with the windowed sinc's gain
     n = np.arange(8000)
     tone = torch.from_numpy(
         np.sin(2 * np.pi * 440 * n / 8000).astype(np.float32))[None]
-    up = load.resample(tone, 8000)
-    assert up.shape == (1, 16000)
-    want = np.sin(2 * np.pi * 440 * np.arange(16000) / 16000)
-    assert np.abs(up[0, 200:-200].numpy() - want[200:-200]).max() < 2e-2
+    for rate in (8000, 22050, 44100, 48000):
+        kernel, orig, new, width = load.resample_kernel(rate)
+        assert kernel.shape == (new, 1, 2 * width + orig)
+        gains = kernel.double().sum(dim=(1, 2))
+        assert float((gains - 1).abs().max()) < 2e-3
+        assert load.resampled_length(rate, orig, new) == 16000
     assert emphases_amd.resample(tone, 16000) is tone
 
 
@@ -387,6 +474,27 @@ def test_wav_headers_alone(tmp_path):
         file.write_bytes(junk)
         with pytest.raises(ValueError):
             load.wav_info(file)
+    # one walker behind both readers: the data chunk BEFORE the fmt chunk, two
+    # data chunks (the last one counts), unsupported codes / bit depths and a
+    # short fmt chunk are the same answer (or the same ValueError) from both
+    fmt = pcm_format(1, 1, 16000, 16)
+    first, last = bytes(range(200)), bytes(range(100, 160))
+    body = b'data' + struct.pack('<I', len(first)) + first + \
+        b'fmt ' + struct.pack('<I', len(fmt)) + fmt + \
+        b'data' + struct.pack('<I', len(last)) + last
+    file = tmp_path / 'order.wav'
+    file.write_bytes(b'RIFF' + struct.pack('<I', 4 + len(body)) + b'WAVE' + body)
+    assert load.wav_info(file) == (16000, 1, 30)
+    audio, _ = load.wav(file, raw=True)
+    assert audio.shape == (1, 30) and \
+        audio.numpy().tobytes() == last
+    for bad in (pcm_format(2, 1, 16000, 4), pcm_format(1, 1, 16000, 12),
+                pcm_format(7, 1, 8000, 8), pcm_format(1, 1, 16000, 16)[:12],
+                pcm_format(1, 0, 16000, 16)):
+        file.write_bytes(riff(bad, bytes(64)))
+        for reader in (load.wav_info, load.wav):
+            with pytest.raises(ValueError):
+                reader(file)
 
 
 ###############################################################################

@@ -214,14 +214,25 @@ def test_resample_known_answers(rate):
 
 
 @pytest.mark.parametrize('rate', RATES)
-def test_host_resample_matches_oracle(rate):
-    """The product's host resampler (`emphases_amd.load.resample`, file
-    plumbing) against the independent restatement."""
+def test_resample_table_matches_oracle(rate):
+    """The product's polyphase TABLE (`emphases_amd.load.resample_kernel`,
+    built on the host like every weight pack; `emph_resample` applies it on
+    the device) against the independent restatement: the table is applied
+    here, in the test, as the strided correlation it describes."""
     from emphases_amd import load
     from oracle import resample as oracle_resample
+    kernel, orig, new, width = load.resample_kernel(rate)
+    taps = kernel.reshape(new, -1).numpy().astype(np.float64)
     for index, length in enumerate((rate // 3 + 17, 5, 1)):
         audio = synth.weights(200 + index, (length,), 0.9)
-        got = load.resample(torch.from_numpy(audio)[None], rate)[0].numpy()
+        padded = np.concatenate(
+            [np.zeros(width), audio.astype(np.float64),
+             np.zeros(width + orig)])
+        steps = (len(padded) - taps.shape[1]) // orig + 1
+        windows = np.lib.stride_tricks.sliding_window_view(
+            padded, taps.shape[1])[::orig][:steps]
+        got = (windows @ taps.T).reshape(-1)[
+            :load.resampled_length(length, orig, new)]
         want = oracle_resample.resample(audio, rate)
         assert got.shape == want.shape
         assert np.abs(got - want).max() < 1e-6
