@@ -335,6 +335,67 @@ class Plan:
                 self._tiles[key] = _tiles(self.words, self.word_off, block)
         return self._tiles[key]
 
+    def word_sum_tables(self, tile=64):
+        """Tables of the fused per-word sum (`emph_conv1d_winograd4_word_sums`
+        + `emph_word_sums`; `emphases/core.py:438-454`): the last frame-rate
+        layer keeps, per `tile`-frame tile of a segment, the running sum of
+        its frames and stores it only at the frames a word needs -
+
+            word [s, e) (clamped to its chunk like a Python slice) meets tile
+            k in [a, b) = [max(s, k tile), min(e, (k + 1) tile)):
+                + running sum at frame b - 1
+                - running sum at frame a - 1     (if a is not the tile's first)
+
+        Returns a dict of int32 arrays: `slot_map` [ld_frames] (packed frame
+        column -> row of the sums buffer, -1), `terms` (signed rows: r adds,
+        ~r subtracts; a word's terms tile by tile, plus before minus),
+        `first` [ld_words + 1] (CSR over packed word columns), `lengths`
+        [ld_words] (e - s; -1 on alignment padding columns), and `n_slots`."""
+        cached = self._tiles.get(('word_sums', tile))
+        if cached is not None:
+            return cached
+        count = len(self.frames)
+        total = self.total_words
+        segment = np.repeat(np.arange(count, dtype=np.int64), self.words)
+        limit = self.frames[segment] if total else np.zeros(0, dtype=np.int64)
+        raw = self.segment_bounds.astype(np.int64)
+        start = np.clip(raw[0], 0, limit)
+        end = np.maximum(np.clip(raw[1], 0, limit), start)
+        first_tile = start // tile
+        parts = np.where(end > start, (end - 1) // tile - first_tile + 1, 0)
+        word = np.repeat(np.arange(total, dtype=np.int64), parts)
+        part_first = np.cumsum(parts) - parts
+        k = first_tile[word] + np.arange(int(parts.sum()), dtype=np.int64) - \
+            part_first[word]
+        a = np.maximum(start[word], k * tile)
+        b = np.minimum(end[word], (k + 1) * tile)
+        column = self.frame_off[segment[word]] if total else a
+        plus = column + b - 1
+        has_minus = a > k * tile
+        minus = column + a - 1
+        marked = np.unique(np.concatenate([plus, minus[has_minus]]))
+        slot_map = np.full(self.ld_frames, -1, dtype=np.int32)
+        slot_map[marked] = np.arange(len(marked), dtype=np.int32)
+        # terms of a part: (+, -) or (+); of a word: its parts in tile order
+        per_part = 1 + has_minus.astype(np.int64)
+        where = np.cumsum(per_part) - per_part
+        terms = np.zeros(int(per_part.sum()), dtype=np.int32)
+        terms[where] = slot_map[plus]
+        terms[where[has_minus] + 1] = ~slot_map[minus[has_minus]]
+        per_word = np.bincount(word, weights=per_part, minlength=total).astype(
+            np.int64) if total else np.zeros(0, dtype=np.int64)
+        per_column = np.zeros(self.ld_words + 1, dtype=np.int64)
+        lengths = np.full(self.ld_words, -1, dtype=np.int32)
+        if total:
+            per_column[self._columns + 1] = per_word
+            lengths[self._columns] = (end - start).astype(np.int32)
+        tables = {
+            'slot_map': slot_map, 'terms': terms,
+            'first': np.cumsum(per_column).astype(np.int32),
+            'lengths': lengths, 'n_slots': int(len(marked))}
+        self._tiles[('word_sums', tile)] = tables
+        return tables
+
     def pieces(self, method):
         """Layout for DOWNSAMPLE_LOCATION = 'input' (`model/core.py:41-87`,
         `core.py:552-586`): every word of a chunk becomes its own sequence,
@@ -348,12 +409,18 @@ class Plan:
         """Packed word-axis column of every word, in segment order."""
         return self._columns
 
-    def pack_metadata(self, tile_requests):
+    def pack_metadata(self, tile_requests, word_sums=False):
         """All integer metadata as one int32 array plus the element offset of
-        every piece (the int64 table first, so it stays 8-byte aligned)."""
+        every piece (the int64 table first, so it stays 8-byte aligned;
+        every piece starts on a 16-byte boundary).  `word_sums`: with the
+        tables of `word_sum_tables()`."""
         pieces = [('table', self.table.view(np.int32).ravel()),
                   ('bounds', self.bounds.ravel()),
                   ('word_segment', self.word_segment)]
+        if word_sums:
+            tables = self.word_sum_tables()
+            pieces += [(('word_sums', name), tables[name])
+                       for name in ('slot_map', 'terms', 'first', 'lengths')]
         for request in tile_requests:
             pieces.append(
                 (('tiles',) + tuple(request), self.tiles(*request).ravel()))

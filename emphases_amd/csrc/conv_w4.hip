@@ -56,12 +56,23 @@ struct Run6 {
 // of DIFFERENT layers - of the two batches in flight - side by side, or one half
 // beside front-end workgroups, and one's weight transfer and store burst run
 // under the other's MFMAs instead of idling the matrix pipe.
-template <int M_TILES, bool POSITION, bool HALF>
+//
+// WORD_SUMS: the layer is the LAST frame-rate layer in front of the per-word sum
+// (emphases/core.py:438-454, DOWNSAMPLE_METHOD 'sum' / 'average').  Its output is
+// never written: a tile forms the running sum of its 64 positions per channel
+// (in-lane over the quad, then a 16-lane row scan on DPP) and stores it only at
+// the positions `slot_map` marks - the last frame of a word (or of a word's part
+// in this tile) and the frame in front of a word's first - as one 16-byte run of
+// four channels into `y` = sums[slot][ldy].  A word's sum is then a handful of
+// signed terms (emph_word_sums): 1.2 MB leave the chip instead of 20.5 MB, and
+// the 320 B / frame pass of emph_segment_reduce is gone.
+template <int M_TILES, bool POSITION, bool HALF, bool WORD_SUMS = false>
 __global__ __launch_bounds__(HALF ? 256 : 512) void conv1d_winograd4_kernel(
     const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
     const float* __restrict__ pack, const float* __restrict__ bias, int c_in, int c_out,
     int act, const int32_t* __restrict__ tiles, int n_tiles, int bias_offset,
-    const float* __restrict__ position, int max_positions, int half) {
+    const float* __restrict__ position, int max_positions, int half,
+    const int32_t* __restrict__ slot_map = nullptr) {
     extern __shared__ __align__(16) float weights[];   // [groups][6][m_tiles][64]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -83,6 +94,7 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void conv1d_winograd4_kernel(
     bool inside[6];
     bool edge = false;              // wave-uniform: the tile touches its segment's ends
     const float* lane_rows = x;     // row kk of the lane's quad
+    int4 slots = {-1, -1, -1, -1};  // WORD_SUMS: where this lane's positions report
     auto open_tile = [&](int group) {
         const int tile = group * 4 + (wave & 3);
         active = tile < n_tiles && m_count > 0;
@@ -95,6 +107,10 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void conv1d_winograd4_kernel(
         }
         edge = t0 == 0 || t0 + 65 > span.count;
         lane_rows = x + span.offset + t0 + 4 * col - 1 + static_cast<int64_t>(kk) * ldx;
+        // (requested a whole K loop ahead of its use; columns past the segment's
+        // end are padding of the same buffer, never reported)
+        if (WORD_SUMS && active)
+            slots = *reinterpret_cast<const int4*>(slot_map + span.offset + t0 + 4 * col);
     };
     // c_in is a multiple of 4 (checked by the launcher), so rows 4 it + kk always
     // exist: the address is a wave-uniform offset on a per-tile lane pointer.
@@ -208,6 +224,60 @@ __global__ __launch_bounds__(HALF ? 256 : 512) void conv1d_winograd4_kernel(
         // ---- output transform, bias, ReLU, one 16-byte store per row and quad
         const bool relu = act == EMPH_ACT_RELU;
         const int t = t0 + 4 * col;
+        if (WORD_SUMS) {
+            // `slots`: where this lane's four positions report (-1: nobody needs
+            // the running sum there)
+#pragma unroll
+            for (int m = 0; m < COUNT; ++m) {
+                const int channel0 = 16 * (m_begin + m) + 4 * kk;
+                const f32x4 add = *reinterpret_cast<const f32x4*>(bias_lds + channel0);
+                f32x4 sum[4];       // [position of the quad][channel r]
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m1 = acc[1][m][r], m2 = acc[2][m][r];
+                    const float m3 = acc[3][m][r], m4 = acc[4][m][r];
+                    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                    float o0 = acc[0][m][r] + s12 + s34 + add[r];
+                    float o1 = fmaf(2.f, d34, d12) + add[r];
+                    float o2 = fmaf(4.f, s34, s12) + add[r];
+                    float o3 = fmaf(8.f, d34, d12) + acc[5][m][r] + add[r];
+                    if (relu) {
+                        o0 = o0 < 0.f ? 0.f : o0;
+                        o1 = o1 < 0.f ? 0.f : o1;
+                        o2 = o2 < 0.f ? 0.f : o2;
+                        o3 = o3 < 0.f ? 0.f : o3;
+                    }
+                    // running sum over the tile: the quad in the lane, then the 16
+                    // quads of the row (lanes of one kk) on DPP, in a fixed order
+                    o1 += o0;
+                    o2 += o1;
+                    o3 += o2;
+                    float scan = o3;
+                    scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                        0, __builtin_bit_cast(int, scan), 0x111, 0xf, 0xf, true));  // row_shr:1
+                    scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                        0, __builtin_bit_cast(int, scan), 0x112, 0xf, 0xf, true));  // row_shr:2
+                    scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                        0, __builtin_bit_cast(int, scan), 0x114, 0xf, 0xf, true));  // row_shr:4
+                    scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                        0, __builtin_bit_cast(int, scan), 0x118, 0xf, 0xf, true));  // row_shr:8
+                    const float before = scan - o3;     // the quads to the left
+                    sum[0][r] = o0 + before;
+                    sum[1][r] = o1 + before;
+                    sum[2][r] = o2 + before;
+                    sum[3][r] = o3 + before;
+                }
+                if (channel0 >= c_out) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int slot = j == 0 ? slots.x : j == 1 ? slots.y : j == 2 ? slots.z : slots.w;
+                    if (slot >= 0 && t + j < span.count)
+                        *reinterpret_cast<f32x4*>(y + static_cast<int64_t>(slot) * ldy + channel0) =
+                            sum[j];
+                }
+            }
+            return;
+        }
         const bool vector_ok = (ldy & 3) == 0 && (span.offset & 3) == 0 &&
                                (reinterpret_cast<uintptr_t>(y) & 15) == 0;
 #pragma unroll
@@ -336,7 +406,7 @@ static int launch_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
                             const float* pack, const float* bias, int32_t c_in, int32_t c_out,
                             int32_t activation, const int32_t* tiles, int32_t n_tiles,
                             const float* position, int32_t max_positions, int32_t half,
-                            void* stream) {
+                            void* stream, const int32_t* slot_map = nullptr) {
     if (n_tiles == 0) return EMPH_OK;
     EMPH_REQUIRE(x && y && pack && tiles, EMPH_EINVAL, "emph_conv1d_winograd4: null pointer");
     EMPH_REQUIRE(activation == EMPH_ACT_NONE || activation == EMPH_ACT_RELU, EMPH_ERANGE,
@@ -361,20 +431,21 @@ static int launch_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int groups = (n_tiles + 3) / 4;
     dim3 grid(groups < 256 || half >= 0 ? groups : 256);
-#define EMPH_W4_LAUNCH(M_TILES, POSITION, HALF)                                                \
+#define EMPH_W4_LAUNCH(M_TILES, POSITION, HALF, ...)                                           \
     do {                                                                                       \
-        auto kernel = conv1d_winograd4_kernel<M_TILES, POSITION, HALF>;                        \
+        auto kernel = conv1d_winograd4_kernel<M_TILES, POSITION, HALF, ##__VA_ARGS__>;         \
         static LdsReservation reserved;                                                        \
         if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,     \
                                      "emph_conv1d_winograd4"))                                 \
             return status;                                                                     \
         EMPH_LAUNCH(kernel, grid, dim3(HALF ? 256 : 512), lds, s, x, ldx, y, ldy, pack, bias,  \
                     c_in, c_out, activation, tiles, n_tiles, bias_offset, position,            \
-                    max_positions, half);                                                      \
+                    max_positions, half, slot_map);                                            \
     } while (0)
 #define EMPH_W4(M_TILES)                                                                       \
     do {                                                                                       \
-        if (half >= 0) {                                                                       \
+        if (slot_map != nullptr) EMPH_W4_LAUNCH(M_TILES, false, false, true);                  \
+        else if (half >= 0) {                                                                  \
             if (position != nullptr) EMPH_W4_LAUNCH(M_TILES, true, true);                      \
             else EMPH_W4_LAUNCH(M_TILES, false, true);                                         \
         } else if (position != nullptr) EMPH_W4_LAUNCH(M_TILES, true, false);                  \
@@ -402,6 +473,23 @@ int emph_conv1d_winograd4(const float* x, int64_t ldx, float* y, int64_t ldy,
                           void* stream) {
     return launch_winograd4(x, ldx, y, ldy, pack, bias, c_in, c_out, activation, tiles, n_tiles,
                             nullptr, 0, -1, stream);
+}
+
+int emph_conv1d_winograd4_word_sums(const float* x, int64_t ldx, float* sums, int64_t ld_sums,
+                                    const float* pack, const float* bias, int32_t c_in,
+                                    int32_t c_out, int32_t activation, const int32_t* tiles,
+                                    int32_t n_tiles, const int32_t* slot_map, void* stream) {
+    EMPH_REQUIRE(slot_map != nullptr && sums != nullptr, EMPH_EINVAL,
+                 "emph_conv1d_winograd4_word_sums: null pointer");
+    EMPH_REQUIRE(c_out % 4 == 0 && ld_sums >= c_out && ld_sums % 4 == 0 &&
+                     (reinterpret_cast<uintptr_t>(sums) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(slot_map) & 15) == 0,
+                 EMPH_EINVAL,
+                 "emph_conv1d_winograd4_word_sums: %d channels in rows of %lld floats (both "
+                 "multiples of 4, 16-byte aligned tables)",
+                 c_out, static_cast<long long>(ld_sums));
+    return launch_winograd4(x, ldx, sums, ld_sums, pack, bias, c_in, c_out, activation, tiles,
+                            n_tiles, nullptr, 0, -1, stream, slot_map);
 }
 
 int emph_conv1d_winograd4_half(const float* x, int64_t ldx, float* y, int64_t ldy,

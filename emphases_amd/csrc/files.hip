@@ -1,0 +1,1056 @@
+// The file boundary of emphases.from_files_to_files (emphases/core.py:115-179) for a
+// whole batch of files, on a pool of host threads (no device code):
+//
+//   pypar.Alignment(text_file)              core.py:49,107    Praat TextGrid -> words
+//   emphases.load.audio(audio_file)         load.py:11-17     RIFF/WAVE -> samples
+//   alignment.save(prefix.TextGrid)         core.py:111
+//   torch.save(scores, prefix.pt)           core.py:112
+//
+// The reference does this one file at a time on the Python thread; the device path
+// behind it takes a few microseconds per utterance, so at corpus scale the files,
+// not the kernels, set the rate.  Here the TextGrids of a batch are parsed and the
+// WAVE headers walked in parallel, the samples are read straight into the
+// (pinned) staging buffer of the batch - no intermediate bytes object, no
+// Python per file - and the outputs are written in parallel.
+//
+// This is the same grammar and the same walker as emphases_amd/alignment.py and
+// emphases_amd/load.py (which stay the readers of the one-file API and of JSON
+// alignments); tests/test_host.py holds the two against each other, byte for byte
+// on the written files.
+#include <errno.h>
+#include <fcntl.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <charconv>
+#include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <pthread.h>
+
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// A pool that runs `count` independent items of several callers' jobs at once
+// (two Python threads pipeline consecutive batches through the library).
+// ---------------------------------------------------------------------------
+
+struct Task {
+    std::function<void(int)> run;
+    int count = 0;
+    int helpers = 0;
+    std::atomic<int> next{0};
+    std::atomic<int> done{0};
+    int inside = 0;                   // pool threads inside drain() (pool mutex)
+};
+
+class Workers {
+  public:
+    void grow(int threads) {
+        std::lock_guard<std::mutex> lock(mutex_);
+        while (static_cast<int>(threads_.size()) < threads)
+            threads_.emplace_back([this] { loop(); });
+    }
+    void run(Task& task) {
+        if (task.count <= 0) return;
+        if (task.helpers > 0) {
+            grow(task.helpers);
+            {
+                std::lock_guard<std::mutex> lock(mutex_);
+                queue_.push_back(&task);
+            }
+            wake_.notify_all();
+        }
+        drain(task);                                  // the caller works too
+        if (task.helpers > 0) {
+            std::unique_lock<std::mutex> lock(mutex_);
+            for (auto it = queue_.begin(); it != queue_.end(); ++it)
+                if (*it == &task) {
+                    queue_.erase(it);
+                    break;
+                }
+            finished_.wait(lock, [&] {
+                return task.done.load() >= task.count && task.inside == 0;
+            });
+        }
+    }
+
+  private:
+    static void drain(Task& task) {
+        for (;;) {
+            const int index = task.next.fetch_add(1);
+            if (index >= task.count) return;
+            task.run(index);
+            task.done.fetch_add(1);
+        }
+    }
+    void loop() {
+        for (;;) {
+            Task* task = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(mutex_);
+                wake_.wait(lock, [&] {
+                    for (Task* candidate : queue_)
+                        if (candidate->next.load() < candidate->count &&
+                            candidate->inside < candidate->helpers)
+                            return true;
+                    return false;
+                });
+                for (Task* candidate : queue_)
+                    if (candidate->next.load() < candidate->count &&
+                        candidate->inside < candidate->helpers) {
+                        task = candidate;
+                        break;
+                    }
+                ++task->inside;
+            }
+            drain(*task);
+            {
+                std::lock_guard<std::mutex> lock(mutex_);
+                --task->inside;
+            }
+            finished_.notify_all();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::deque<Task*> queue_;
+    std::mutex mutex_;
+    std::condition_variable wake_, finished_;
+};
+
+Workers* g_workers = new Workers;
+// fork(): the child has the calling thread only; it builds its own pool
+void forget_workers_in_child() { g_workers = new Workers; }
+const int g_atfork = pthread_atfork(nullptr, nullptr, forget_workers_in_child);
+
+void parallel(int count, int threads, std::function<void(int)> run) {
+    Task task;
+    task.run = std::move(run);
+    task.count = count;
+    task.helpers = count > 1 ? (threads - 1 < count - 1 ? threads - 1 : count - 1) : 0;
+    if (task.helpers < 0) task.helpers = 0;
+    g_workers->run(task);
+}
+
+// ---------------------------------------------------------------------------
+// Files
+// ---------------------------------------------------------------------------
+
+bool read_whole(const char* path, std::string* data, std::string* error) {
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) {
+        *error = std::string(path) + ": " + strerror(errno);
+        return false;
+    }
+    struct stat info;
+    if (fstat(fd, &info) != 0) {
+        *error = std::string(path) + ": " + strerror(errno);
+        close(fd);
+        return false;
+    }
+    data->resize(static_cast<size_t>(info.st_size));
+    size_t got = 0;
+    while (got < data->size()) {
+        const ssize_t n = pread(fd, &(*data)[got], data->size() - got, static_cast<off_t>(got));
+        if (n <= 0) break;
+        got += static_cast<size_t>(n);
+    }
+    close(fd);
+    data->resize(got);
+    return true;
+}
+
+bool write_whole(const std::string& path, const std::string& data, std::string* error) {
+    const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    if (fd < 0) {
+        *error = path + ": " + strerror(errno);
+        return false;
+    }
+    size_t put = 0;
+    while (put < data.size()) {
+        const ssize_t n = write(fd, data.data() + put, data.size() - put);
+        if (n <= 0) {
+            *error = path + ": " + strerror(errno);
+            close(fd);
+            return false;
+        }
+        put += static_cast<size_t>(n);
+    }
+    close(fd);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// RIFF/WAVE headers: emphases_amd/load.py `_walk`, line for line
+// ---------------------------------------------------------------------------
+
+struct Wave {
+    int64_t code = 0, channels = 0, rate = 0, bits = 0, offset = 0, bytes = 0;
+};
+
+uint32_t le32(const unsigned char* p) {
+    return p[0] | (p[1] << 8) | (p[2] << 16) | (static_cast<uint32_t>(p[3]) << 24);
+}
+uint32_t le16(const unsigned char* p) { return p[0] | (p[1] << 8); }
+
+bool walk_wave(const char* path, Wave* wave, std::string* error) {
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) {
+        *error = std::string(path) + ": " + strerror(errno);
+        return false;
+    }
+    struct stat info;
+    unsigned char head[12];
+    if (fstat(fd, &info) != 0 || pread(fd, head, 12, 0) != 12 || memcmp(head, "RIFF", 4) ||
+        memcmp(head + 8, "WAVE", 4)) {
+        close(fd);
+        *error = std::string(path) + " is not a RIFF/WAVE file";
+        return false;
+    }
+    const int64_t end = info.st_size;
+    int64_t cursor = 12;
+    bool have_fmt = false, have_data = false;
+    while (cursor + 8 <= end) {
+        unsigned char header[8];
+        if (pread(fd, header, 8, cursor) != 8) break;
+        const int64_t size = le32(header + 4);
+        if (!memcmp(header, "fmt ", 4)) {
+            unsigned char body[40];
+            const int64_t want = size < 40 ? size : 40;
+            const ssize_t got = pread(fd, body, static_cast<size_t>(want), cursor + 8);
+            if (got < 16) {
+                close(fd);
+                *error = std::string(path) + ": fmt chunk of " +
+                         std::to_string(got < 0 ? 0 : got) + " bytes";
+                return false;
+            }
+            wave->code = le16(body);
+            wave->channels = le16(body + 2);
+            wave->rate = le32(body + 4);
+            wave->bits = le16(body + 14);
+            if (wave->code == 0xFFFE && got >= 26) wave->code = le16(body + 24);
+            have_fmt = true;
+        } else if (!memcmp(header, "data", 4)) {
+            wave->offset = cursor + 8;
+            wave->bytes = size < end - cursor - 8 ? size : end - cursor - 8;
+            have_data = true;
+        }
+        cursor += 8 + size + (size & 1);
+    }
+    close(fd);
+    if (!have_fmt || !have_data) {
+        *error = std::string(path) + " has no fmt/data chunk";
+        return false;
+    }
+    const int64_t c = wave->code, b = wave->bits;
+    const bool known = (c == 1 && (b == 8 || b == 16 || b == 24 || b == 32)) ||
+                       (c == 3 && (b == 32 || b == 64));
+    if (!known || wave->channels < 1) {
+        *error = std::string(path) + ": unsupported WAVE format " + std::to_string(c) + "/" +
+                 std::to_string(b) + " (" + std::to_string(wave->channels) + " channels)";
+        return false;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// Praat TextGrid: emphases_amd/alignment.py (decode, _values, _tiers_from_textgrid,
+// _words_from_textgrid, _fill_gaps, _textgrid)
+// ---------------------------------------------------------------------------
+
+const char kSilence[] = "<silent>";
+
+void append_utf8(std::string* out, uint32_t code) {
+    if (code < 0x80) {
+        out->push_back(static_cast<char>(code));
+    } else if (code < 0x800) {
+        out->push_back(static_cast<char>(0xC0 | (code >> 6)));
+        out->push_back(static_cast<char>(0x80 | (code & 0x3F)));
+    } else if (code < 0x10000) {
+        out->push_back(static_cast<char>(0xE0 | (code >> 12)));
+        out->push_back(static_cast<char>(0x80 | ((code >> 6) & 0x3F)));
+        out->push_back(static_cast<char>(0x80 | (code & 0x3F)));
+    } else {
+        out->push_back(static_cast<char>(0xF0 | (code >> 18)));
+        out->push_back(static_cast<char>(0x80 | ((code >> 12) & 0x3F)));
+        out->push_back(static_cast<char>(0x80 | ((code >> 6) & 0x3F)));
+        out->push_back(static_cast<char>(0x80 | (code & 0x3F)));
+    }
+}
+
+std::string utf16_to_utf8(const unsigned char* data, size_t bytes, bool big) {
+    std::string out;
+    out.reserve(bytes / 2);
+    auto unit = [&](size_t i) -> uint32_t {
+        return big ? (data[i] << 8) | data[i + 1] : data[i] | (data[i + 1] << 8);
+    };
+    for (size_t i = 0; i + 1 < bytes; i += 2) {
+        uint32_t code = unit(i);
+        if (code >= 0xD800 && code < 0xDC00 && i + 3 < bytes) {
+            const uint32_t low = unit(i + 2);
+            if (low >= 0xDC00 && low < 0xE000) {
+                code = 0x10000 + ((code - 0xD800) << 10) + (low - 0xDC00);
+                i += 2;
+            }
+        }
+        append_utf8(&out, code);
+    }
+    return out;
+}
+
+// alignment.decode: UTF-16 by BOM or by the zero bytes of the ASCII header,
+// UTF-8 with or without BOM
+std::string decode(const std::string& raw) {
+    const unsigned char* d = reinterpret_cast<const unsigned char*>(raw.data());
+    const size_t n = raw.size();
+    if (n >= 2 && d[0] == 0xFF && d[1] == 0xFE) return utf16_to_utf8(d + 2, n - 2, false);
+    if (n >= 2 && d[0] == 0xFE && d[1] == 0xFF) return utf16_to_utf8(d + 2, n - 2, true);
+    if (n >= 3 && d[0] == 0xEF && d[1] == 0xBB && d[2] == 0xBF) return raw.substr(3);
+    if (n >= 4 && d[1] == 0 && d[0] != 0) return utf16_to_utf8(d, n, false);
+    if (n >= 4 && d[0] == 0 && d[1] != 0) return utf16_to_utf8(d, n, true);
+    return raw;
+}
+
+struct Value {
+    enum Kind { kString, kFlag, kNumber } kind;
+    std::string text;
+    double number = 0.;
+};
+
+bool is_word(unsigned char c) {
+    return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') ||
+           c == '_' || c >= 0x80;
+}
+bool is_digit(unsigned char c) { return c >= '0' && c <= '9'; }
+
+// alignment._VALUE, as a scanner: "strings" (a quote inside is doubled), <flags>,
+// numbers that neither follow [\w.\[] nor run into [\w\]]
+void scan_values(const std::string& text, std::vector<Value>* values) {
+    const size_t n = text.size();
+    size_t i = 0;
+    while (i < n) {
+        const unsigned char c = static_cast<unsigned char>(text[i]);
+        if (c == '"') {
+            std::string body;
+            size_t j = i + 1;
+            bool closed = false;
+            while (j < n) {
+                if (text[j] == '"') {
+                    if (j + 1 < n && text[j + 1] == '"') {
+                        body.push_back('"');
+                        j += 2;
+                        continue;
+                    }
+                    closed = true;
+                    break;
+                }
+                body.push_back(text[j]);
+                ++j;
+            }
+            if (closed) {
+                values->push_back({Value::kString, std::move(body), 0.});
+                i = j + 1;
+                continue;
+            }
+            ++i;
+            continue;
+        }
+        if (c == '<') {
+            size_t j = i + 1;
+            while (j < n && is_word(static_cast<unsigned char>(text[j]))) ++j;
+            if (j > i + 1 && j < n && text[j] == '>') {
+                values->push_back({Value::kFlag, text.substr(i + 1, j - i - 1), 0.});
+                i = j + 1;
+                continue;
+            }
+            ++i;
+            continue;
+        }
+        if (is_digit(c) || c == '-' || c == '+' || c == '.') {
+            const unsigned char before = i ? static_cast<unsigned char>(text[i - 1]) : ' ';
+            if (!(i && (is_word(before) || before == '.' || before == '['))) {
+                size_t j = i;
+                if (text[j] == '-' || text[j] == '+') ++j;
+                size_t digits = j;
+                while (j < n && is_digit(static_cast<unsigned char>(text[j]))) ++j;
+                bool mantissa = j > digits;
+                if (mantissa) {                          // \d+\.?\d*
+                    if (j < n && text[j] == '.') {
+                        ++j;
+                        while (j < n && is_digit(static_cast<unsigned char>(text[j]))) ++j;
+                    }
+                } else if (j < n && text[j] == '.') {    // \.\d+
+                    size_t k = j + 1;
+                    while (k < n && is_digit(static_cast<unsigned char>(text[k]))) ++k;
+                    if (k > j + 1) {
+                        mantissa = true;
+                        j = k;
+                    }
+                }
+                if (mantissa) {
+                    if (j < n && (text[j] == 'e' || text[j] == 'E')) {
+                        size_t k = j + 1;
+                        if (k < n && (text[k] == '-' || text[k] == '+')) ++k;
+                        size_t exponent = k;
+                        while (k < n && is_digit(static_cast<unsigned char>(text[k]))) ++k;
+                        if (k > exponent) j = k;
+                    }
+                    // the regex backtracks over trailing digits to satisfy the
+                    // lookahead; a number that runs into a letter is no number at all
+                    // for the files this reads, so it is skipped whole
+                    const unsigned char after = j < n ? static_cast<unsigned char>(text[j]) : ' ';
+                    if (!(j < n && (is_word(after) || after == ']'))) {
+                        Value value{Value::kNumber, std::string(), 0.};
+                        value.number = strtod(text.substr(i, j - i).c_str(), nullptr);
+                        values->push_back(std::move(value));
+                        i = j;
+                        continue;
+                    }
+                    i = j;
+                    continue;
+                }
+            }
+        }
+        ++i;
+    }
+}
+
+struct Item {
+    double start = 0., end = 0.;
+    std::string text;
+    int word = -1;                    // phonemes: index of the word (after gap filling)
+    bool filler = false;              // a silence inserted between two words
+};
+
+struct Grid {
+    std::vector<Item> words;          // gap-free, silences named kSilence
+    std::vector<Item> phones;
+    std::string word_tier = "words", phone_tier = "phones";
+    bool phones_first = false;
+    bool has_phones = false;
+};
+
+bool is_silence(const std::string& text) {
+    bool blank = true;
+    for (unsigned char c : text)
+        if (!(c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f))) blank = false;
+    return blank || text == "sp" || text == kSilence;
+}
+
+std::string lower(const std::string& text) {
+    std::string out = text;
+    for (char& c : out)
+        if (c >= 'A' && c <= 'Z') c = static_cast<char>(c - 'A' + 'a');
+    return out;
+}
+
+bool parse_grid(const std::string& text, Grid* grid, std::string* error) {
+    std::vector<Value> values;
+    scan_values(text, &values);
+    size_t at = 0;
+    bool short_of = false;
+    auto take = [&](Value::Kind kind, const char* name) -> const Value* {
+        if (at >= values.size()) {
+            short_of = true;
+            return nullptr;
+        }
+        if (values[at].kind != kind) {
+            *error = std::string("TextGrid: expected ") + name;
+            return nullptr;
+        }
+        return &values[at++];
+    };
+    auto fail = [&]() {
+        if (short_of) *error = "TextGrid ends in the middle of a tier";
+        return false;
+    };
+    const Value* v;
+    if (!(v = take(Value::kString, "str")) || v->text != "ooTextFile") {
+        if (v) *error = "not a TextGrid text file";
+        return fail();
+    }
+    if (!(v = take(Value::kString, "str")) || v->text != "TextGrid") {
+        if (v) *error = "not a TextGrid text file";
+        return fail();
+    }
+    if (!take(Value::kNumber, "float") || !take(Value::kNumber, "float")) return fail();
+    if (!(v = take(Value::kFlag, "tuple"))) return fail();
+    struct Tier {
+        std::string name;
+        std::vector<Item> items;
+    };
+    std::vector<Tier> tiers;              // interval tiers only
+    if (v->text == "exists") {
+        if (!(v = take(Value::kNumber, "float"))) return fail();
+        const int count = static_cast<int>(v->number);
+        for (int t = 0; t < count; ++t) {
+            const Value* kind = take(Value::kString, "str");
+            if (!kind) return fail();
+            const Value* name = take(Value::kString, "str");
+            if (!name) return fail();
+            if (!take(Value::kNumber, "float") || !take(Value::kNumber, "float")) return fail();
+            const Value* size = take(Value::kNumber, "float");
+            if (!size) return fail();
+            const int items = static_cast<int>(size->number);
+            const bool interval = kind->text == "IntervalTier";
+            Tier tier;
+            tier.name = name->text;
+            for (int k = 0; k < items; ++k) {
+                Item item;
+                const Value* a = take(Value::kNumber, "float");
+                if (!a) return fail();
+                item.start = item.end = a->number;
+                if (interval) {
+                    const Value* b = take(Value::kNumber, "float");
+                    if (!b) return fail();
+                    item.end = b->number;
+                }
+                const Value* label = take(Value::kString, "str");
+                if (!label) return fail();
+                item.text = label->text;
+                if (interval) tier.items.push_back(std::move(item));
+            }
+            if (interval) tiers.push_back(std::move(tier));
+        }
+    }
+    if (tiers.empty()) {
+        *error = "TextGrid holds no interval tiers";
+        return false;
+    }
+    // which tier holds the words, which the phonemes (alignment._words_from_textgrid)
+    const int count = static_cast<int>(tiers.size());
+    int word_index = -1;
+    for (int i = 0; i < count && word_index < 0; ++i) {
+        const std::string name = lower(tiers[i].name);
+        if (name == "words" || name == "word") word_index = i;
+    }
+    if (word_index < 0) {
+        word_index = 0;
+        for (int i = 1; i < count; ++i)
+            if (tiers[i].items.size() < tiers[word_index].items.size()) word_index = i;
+    }
+    int phone_index = -1;
+    for (int i = 0; i < count && phone_index < 0; ++i) {
+        if (i == word_index) continue;
+        const std::string name = lower(tiers[i].name);
+        if (name == "phones" || name == "phone" || name == "phonemes" || name == "phoneme")
+            phone_index = i;
+    }
+    if (phone_index < 0 && count > 1) {
+        int finest = -1;
+        for (int i = 0; i < count; ++i) {
+            if (i == word_index) continue;
+            if (finest < 0 || tiers[i].items.size() > tiers[finest].items.size()) finest = i;
+        }
+        if (tiers[finest].items.size() >= tiers[word_index].items.size()) phone_index = finest;
+    }
+    std::vector<Item> words = std::move(tiers[word_index].items);
+    for (Item& word : words)
+        if (is_silence(word.text)) word.text = kSilence;
+    grid->word_tier = tiers[word_index].name;
+    if (phone_index >= 0) {
+        grid->has_phones = true;
+        grid->phone_tier = tiers[phone_index].name;
+        grid->phones_first = phone_index < word_index;
+        grid->phones = std::move(tiers[phone_index].items);
+        size_t cursor = 0;
+        for (Item& phone : grid->phones) {
+            if (is_silence(phone.text)) phone.text = kSilence;
+            const double middle = 0.5 * (phone.start + phone.end);
+            while (cursor + 1 < words.size() && middle >= words[cursor].end) ++cursor;
+            phone.word = static_cast<int>(cursor);        // index BEFORE gap filling
+        }
+        if (words.empty()) grid->phones.clear();
+    }
+    // alignment._fill_gaps: silences so that consecutive words touch
+    std::vector<int> moved(words.size(), 0);
+    for (size_t i = 0; i < words.size(); ++i) {
+        if (!grid->words.empty() && words[i].start > grid->words.back().end) {
+            Item filler;
+            filler.start = grid->words.back().end;
+            filler.end = words[i].start;
+            filler.text = kSilence;
+            filler.filler = true;
+            grid->words.push_back(std::move(filler));
+        }
+        moved[i] = static_cast<int>(grid->words.size());
+        grid->words.push_back(std::move(words[i]));
+    }
+    for (Item& phone : grid->phones) phone.word = moved[phone.word];
+    return true;
+}
+
+// repr(float) of CPython: shortest digits that read back, positional notation
+// for 1e-4 <= |x| < 1e16, else d.ddde+XX
+std::string python_repr(double value) {
+    if (value == 0.) return std::signbit(value) ? "-0.0" : "0.0";
+    char buffer[64];
+    auto result = std::to_chars(buffer, buffer + sizeof(buffer), value, std::chars_format::scientific);
+    std::string text(buffer, result.ptr);
+    std::string sign;
+    if (text[0] == '-') {
+        sign = "-";
+        text = text.substr(1);
+    }
+    const size_t e = text.find('e');
+    std::string digits = text.substr(0, e);
+    const int exponent = atoi(text.c_str() + e + 1);
+    const size_t dot = digits.find('.');
+    if (dot != std::string::npos) digits.erase(dot, 1);
+    const int count = static_cast<int>(digits.size());
+    std::string out;
+    if (exponent >= -4 && exponent < 16) {
+        if (exponent < 0) {
+            out = "0." + std::string(static_cast<size_t>(-exponent - 1), '0') + digits;
+        } else if (count <= exponent + 1) {
+            out = digits + std::string(static_cast<size_t>(exponent + 1 - count), '0') + ".0";
+        } else {
+            out = digits.substr(0, static_cast<size_t>(exponent + 1)) + "." +
+                  digits.substr(static_cast<size_t>(exponent + 1));
+        }
+    } else {
+        out = digits.substr(0, 1);
+        if (count > 1) out += "." + digits.substr(1);
+        char tail[16];
+        snprintf(tail, sizeof(tail), "e%c%02d", exponent < 0 ? '-' : '+', abs(exponent));
+        out += tail;
+    }
+    return sign + out;
+}
+
+// alignment._number: integers without a fraction
+std::string number(double value) {
+    if (value == static_cast<double>(static_cast<long long>(value)) &&
+        (value < 0 ? -value : value) < 1e15)
+        return std::to_string(static_cast<long long>(value));
+    return python_repr(value);
+}
+
+void tier_lines(std::string* out, int index, const std::string& name,
+                const std::vector<const Item*>& items, double xmax) {
+    *out += "    item [" + std::to_string(index) + "]:\n";
+    *out += "        class = \"IntervalTier\"\n";
+    *out += "        name = \"" + name + "\"\n";
+    *out += "        xmin = 0\n";
+    *out += "        xmax = " + number(xmax) + "\n";
+    *out += "        intervals: size = " + std::to_string(items.size()) + "\n";
+    int i = 0;
+    for (const Item* item : items) {
+        std::string label;
+        if (item->text != kSilence)
+            for (char c : item->text) {
+                label.push_back(c);
+                if (c == '"') label.push_back('"');
+            }
+        *out += "        intervals [" + std::to_string(++i) + "]:\n";
+        *out += "            xmin = " + number(item->start) + "\n";
+        *out += "            xmax = " + number(item->end) + "\n";
+        *out += "            text = \"" + label + "\"\n";
+    }
+}
+
+// alignment._textgrid
+std::string grid_text(const Grid& grid) {
+    const double xmax = grid.words.empty() ? 0. : grid.words.back().end;
+    std::vector<const Item*> words, phones;
+    for (const Item& word : grid.words) words.push_back(&word);
+    for (const Item& phone : grid.phones) phones.push_back(&phone);
+    const bool two = !phones.empty();
+    std::string out = "File type = \"ooTextFile\"\nObject class = \"TextGrid\"\n\nxmin = 0\n";
+    out += "xmax = " + number(xmax) + "\ntiers? <exists>\n";
+    out += std::string("size = ") + (two ? "2" : "1") + "\nitem []:\n";
+    int index = 0;
+    if (two && grid.phones_first) tier_lines(&out, ++index, grid.phone_tier, phones, xmax);
+    tier_lines(&out, ++index, grid.word_tier, words, xmax);
+    if (two && !grid.phones_first) tier_lines(&out, ++index, grid.phone_tier, phones, xmax);
+    return out;
+}
+
+// ---------------------------------------------------------------------------
+// torch.save(tensor float32 [1, W] on the CPU): the zip container
+// torch.serialization writes (records <stem>/data.pkl, byteorder, data/0,
+// version, ...; stored, payloads 64-byte aligned), readable by torch.load
+// ---------------------------------------------------------------------------
+
+uint32_t crc32_of(const unsigned char* data, size_t bytes) {
+    static uint32_t table[256];
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+    });
+    uint32_t crc = 0xFFFFFFFFu;
+    for (size_t i = 0; i < bytes; ++i) crc = table[(crc ^ data[i]) & 0xFF] ^ (crc >> 8);
+    return crc ^ 0xFFFFFFFFu;
+}
+
+void put16(std::string* out, uint32_t v) {
+    out->push_back(static_cast<char>(v & 0xFF));
+    out->push_back(static_cast<char>((v >> 8) & 0xFF));
+}
+void put32(std::string* out, uint32_t v) {
+    put16(out, v & 0xFFFF);
+    put16(out, v >> 16);
+}
+
+void pickle_int(std::string* out, int64_t value) {
+    if (value < 256) {
+        out->push_back('K');
+        out->push_back(static_cast<char>(value));
+    } else if (value < 65536) {
+        out->push_back('M');
+        put16(out, static_cast<uint32_t>(value));
+    } else {
+        out->push_back('J');
+        put32(out, static_cast<uint32_t>(value));
+    }
+}
+
+// pickle protocol 2 of torch._utils._rebuild_tensor_v2(FloatStorage '0' on 'cpu'
+// of `count` elements, offset 0, size (1, count), stride (count, 1), no grad)
+std::string tensor_pickle(int64_t count) {
+    std::string p;
+    p += "\x80\x02" "ctorch._utils\n_rebuild_tensor_v2\nq";
+    p.push_back('\0');
+    p += "((X\x07";
+    p.append(3, '\0');
+    p += "storageq\x01" "ctorch\nFloatStorage\nq\x02X\x01";
+    p.append(3, '\0');
+    p += "0q\x03X\x03";
+    p.append(3, '\0');
+    p += "cpuq\x04";
+    pickle_int(&p, count);
+    p += "tq\x05QK";
+    p.push_back('\0');
+    p += "K\x01";
+    pickle_int(&p, count);
+    p += "\x86q\x06";
+    pickle_int(&p, count);
+    p += "K\x01\x86q\x07\x89" "ccollections\nOrderedDict\nq\x08)Rq\ttq\nRq\x0b.";
+    return p;
+}
+
+struct Record {
+    std::string name;
+    uint32_t crc, size, offset;
+};
+
+void zip_record(std::string* out, std::vector<Record>* records, const std::string& name,
+                const unsigned char* data, size_t bytes) {
+    // an extra field "FB" + padding puts the payload on a 64-byte boundary
+    const size_t header = 30 + name.size() + 4;
+    const size_t start = out->size() + header;
+    const size_t padding = (64 - start % 64) % 64;
+    Record record{name, crc32_of(data, bytes), static_cast<uint32_t>(bytes),
+                  static_cast<uint32_t>(out->size())};
+    put32(out, 0x04034b50u);
+    put16(out, 20);                 // version needed
+    put16(out, 0x0800);             // UTF-8 names
+    put16(out, 0);                  // stored
+    put16(out, 0);
+    put16(out, 0x21);               // 1980-01-01
+    put32(out, record.crc);
+    put32(out, record.size);
+    put32(out, record.size);
+    put16(out, static_cast<uint32_t>(name.size()));
+    put16(out, static_cast<uint32_t>(4 + padding));
+    *out += name;
+    *out += "FB";
+    put16(out, static_cast<uint32_t>(padding));
+    out->append(padding, 'Z');
+    out->append(reinterpret_cast<const char*>(data), bytes);
+    records->push_back(std::move(record));
+}
+
+std::string tensor_file(const std::string& stem, const float* scores, int64_t count) {
+    std::string out;
+    std::vector<Record> records;
+    const std::string pickle = tensor_pickle(count);
+    auto text = [&](const std::string& name, const std::string& body) {
+        zip_record(&out, &records, stem + "/" + name,
+                   reinterpret_cast<const unsigned char*>(body.data()), body.size());
+    };
+    text("data.pkl", pickle);
+    text(".format_version", "1");
+    text(".storage_alignment", "64");
+    text("byteorder", "little");
+    zip_record(&out, &records, stem + "/data/0", reinterpret_cast<const unsigned char*>(scores),
+               static_cast<size_t>(count) * sizeof(float));
+    text("version", "3\n");
+    text(".data/serialization_id", "0000000000000000000000000000000000000000");
+    const size_t directory = out.size();
+    for (const Record& record : records) {
+        put32(&out, 0x02014b50u);
+        put16(&out, 20);
+        put16(&out, 20);
+        put16(&out, 0x0800);
+        put16(&out, 0);
+        put16(&out, 0);
+        put16(&out, 0x21);
+        put32(&out, record.crc);
+        put32(&out, record.size);
+        put32(&out, record.size);
+        put16(&out, static_cast<uint32_t>(record.name.size()));
+        put16(&out, 0);
+        put16(&out, 0);
+        put16(&out, 0);
+        put16(&out, 0);
+        put32(&out, 0);
+        put32(&out, record.offset);
+        out += record.name;
+    }
+    const size_t directory_bytes = out.size() - directory;
+    put32(&out, 0x06054b50u);
+    put16(&out, 0);
+    put16(&out, 0);
+    put16(&out, static_cast<uint32_t>(records.size()));
+    put16(&out, static_cast<uint32_t>(records.size()));
+    put32(&out, static_cast<uint32_t>(directory_bytes));
+    put32(&out, static_cast<uint32_t>(directory));
+    put16(&out, 0);
+    return out;
+}
+
+std::string stem_of(const std::string& path) {
+    const size_t slash = path.find_last_of('/');
+    std::string name = slash == std::string::npos ? path : path.substr(slash + 1);
+    const size_t dot = name.find_last_of('.');
+    if (dot != std::string::npos && dot > 0) name = name.substr(0, dot);
+    return name;
+}
+
+}  // namespace
+
+// One batch of (alignment file, audio file) pairs.
+struct emph_file_batch {
+    struct File {
+        std::string text_path, audio_path;
+        Grid grid;
+        Wave wave;
+        int status = 0;               // bit 0: alignment failed, bit 1: audio failed
+        std::string error;
+    };
+    std::vector<File> files;
+};
+
+using namespace emph;
+
+extern "C" {
+
+int emph_files_open(const char* const* text_paths, const char* const* audio_paths, int32_t count,
+                    int32_t threads, emph_file_batch** batch) {
+    EMPH_REQUIRE(batch != nullptr && count >= 0 && threads >= 1 && threads <= 64 &&
+                     (count == 0 || (text_paths && audio_paths)),
+                 EMPH_EINVAL, "emph_files_open: bad arguments");
+    emph_file_batch* opened = new emph_file_batch;
+    opened->files.resize(static_cast<size_t>(count));
+    parallel(count, threads, [&](int i) {
+        emph_file_batch::File& file = opened->files[static_cast<size_t>(i)];
+        file.text_path = text_paths[i];
+        file.audio_path = audio_paths[i];
+        std::string raw, error;
+        if (!read_whole(text_paths[i], &raw, &error) ||
+            !parse_grid(decode(raw), &file.grid, &error)) {
+            file.status |= 1;
+            file.error = error;
+        }
+        if (!walk_wave(audio_paths[i], &file.wave, &error)) {
+            file.status |= 2;
+            if (file.error.empty()) file.error = error;
+        }
+    });
+    *batch = opened;
+    return EMPH_OK;
+}
+
+void emph_files_close(emph_file_batch* batch) { delete batch; }
+
+const char* emph_files_error(const emph_file_batch* batch, int32_t index) {
+    if (batch == nullptr || index < 0 || index >= static_cast<int32_t>(batch->files.size()))
+        return "";
+    return batch->files[static_cast<size_t>(index)].error.c_str();
+}
+
+// sizes[i] = {status, words, phonemes, bytes of word labels, bytes of phoneme
+// labels, WAVE format code, channels, sample rate, bits per sample, data offset,
+// data bytes, phonemes-first}
+int emph_files_sizes(const emph_file_batch* batch, int64_t* sizes) {
+    EMPH_REQUIRE(batch && sizes, EMPH_EINVAL, "emph_files_sizes: null pointer");
+    for (size_t i = 0; i < batch->files.size(); ++i) {
+        const emph_file_batch::File& file = batch->files[i];
+        int64_t* row = sizes + 12 * i;
+        int64_t word_bytes = 0, phone_bytes = 0;
+        for (const Item& word : file.grid.words) word_bytes += static_cast<int64_t>(word.text.size());
+        for (const Item& phone : file.grid.phones)
+            phone_bytes += static_cast<int64_t>(phone.text.size());
+        row[0] = file.status;
+        row[1] = static_cast<int64_t>(file.grid.words.size());
+        row[2] = file.grid.has_phones ? static_cast<int64_t>(file.grid.phones.size()) : -1;
+        row[3] = word_bytes;
+        row[4] = phone_bytes;
+        row[5] = file.wave.code;
+        row[6] = file.wave.channels;
+        row[7] = file.wave.rate;
+        row[8] = file.wave.bits;
+        row[9] = file.wave.offset;
+        row[10] = file.wave.bytes;
+        row[11] = file.grid.phones_first ? 1 : 0;
+    }
+    return EMPH_OK;
+}
+
+// The alignments of all files back to back: times [sum words][2] seconds (gaps
+// filled with silences), labels as UTF-8 bytes with their END offsets, the same
+// for the phonemes plus the (gap-filled) index of the word each belongs to, and
+// per file the two tier names separated by '\n' in `tier_names` with END offsets
+// (any output pointer may be NULL).
+int emph_files_alignments(const emph_file_batch* batch, double* word_times, char* word_text,
+                          int64_t* word_text_end, double* phone_times, char* phone_text,
+                          int64_t* phone_text_end, int32_t* phone_word, char* tier_names,
+                          int64_t* tier_names_end) {
+    EMPH_REQUIRE(batch != nullptr, EMPH_EINVAL, "emph_files_alignments: null pointer");
+    int64_t w = 0, wb = 0, p = 0, pb = 0, tb = 0;
+    for (size_t i = 0; i < batch->files.size(); ++i) {
+        const Grid& grid = batch->files[i].grid;
+        for (const Item& word : grid.words) {
+            if (word_times) {
+                word_times[2 * w] = word.start;
+                word_times[2 * w + 1] = word.end;
+            }
+            if (word_text) memcpy(word_text + wb, word.text.data(), word.text.size());
+            wb += static_cast<int64_t>(word.text.size());
+            if (word_text_end) word_text_end[w] = wb;
+            ++w;
+        }
+        for (const Item& phone : grid.phones) {
+            if (phone_times) {
+                phone_times[2 * p] = phone.start;
+                phone_times[2 * p + 1] = phone.end;
+            }
+            if (phone_text) memcpy(phone_text + pb, phone.text.data(), phone.text.size());
+            pb += static_cast<int64_t>(phone.text.size());
+            if (phone_text_end) phone_text_end[p] = pb;
+            if (phone_word) phone_word[p] = phone.word;
+            ++p;
+        }
+        const std::string names = grid.word_tier + "\n" + grid.phone_tier;
+        if (tier_names) memcpy(tier_names + tb, names.data(), names.size());
+        tb += static_cast<int64_t>(names.size());
+        if (tier_names_end) tier_names_end[i] = tb;
+    }
+    return EMPH_OK;
+}
+
+int64_t emph_files_tier_name_bytes(const emph_file_batch* batch) {
+    if (batch == nullptr) return 0;
+    int64_t total = 0;
+    for (const emph_file_batch::File& file : batch->files)
+        total += static_cast<int64_t>(file.grid.word_tier.size() + 1 + file.grid.phone_tier.size());
+    return total;
+}
+
+// The data chunks of files which[0 .. count) (mono 16-bit PCM or float32: their
+// bytes ARE the packed staging layout), file which[k] at destination + where[k],
+// bytes[k] of them (at most the chunk holds).
+int emph_files_read_audio(const emph_file_batch* batch, const int32_t* which,
+                          const int64_t* where, const int64_t* bytes, int32_t count,
+                          void* destination, int32_t threads) {
+    if (count == 0) return EMPH_OK;
+    EMPH_REQUIRE(batch && which && where && bytes && destination && threads >= 1 &&
+                     threads <= 64,
+                 EMPH_EINVAL, "emph_files_read_audio: bad arguments");
+    std::atomic<int> failed{-1};
+    // (a 5-minute file is split into pieces so that a few long files spread over
+    // the threads like many short ones)
+    constexpr int64_t kPiece = 4 << 20;
+    struct Piece {
+        int file;
+        int64_t from, bytes, to;
+    };
+    std::vector<Piece> pieces;
+    for (int32_t k = 0; k < count; ++k) {
+        EMPH_REQUIRE(which[k] >= 0 && which[k] < static_cast<int32_t>(batch->files.size()),
+                     EMPH_EINVAL, "emph_files_read_audio: file %d", which[k]);
+        const Wave& wave = batch->files[static_cast<size_t>(which[k])].wave;
+        EMPH_REQUIRE(bytes[k] >= 0 && bytes[k] <= wave.bytes, EMPH_EINVAL,
+                     "emph_files_read_audio: %lld bytes of a %lld-byte data chunk",
+                     static_cast<long long>(bytes[k]), static_cast<long long>(wave.bytes));
+        for (int64_t at = 0; at < bytes[k]; at += kPiece)
+            pieces.push_back({which[k], wave.offset + at,
+                              bytes[k] - at < kPiece ? bytes[k] - at : kPiece, where[k] + at});
+    }
+    parallel(static_cast<int>(pieces.size()), threads, [&](int index) {
+        const Piece& piece = pieces[static_cast<size_t>(index)];
+        const std::string& path = batch->files[static_cast<size_t>(piece.file)].audio_path;
+        const int fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+        if (fd < 0) {
+            failed.store(piece.file);
+            return;
+        }
+        char* target = static_cast<char*>(destination) + piece.to;
+        int64_t got = 0;
+        while (got < piece.bytes) {
+            const ssize_t n = pread(fd, target + got, static_cast<size_t>(piece.bytes - got),
+                                    static_cast<off_t>(piece.from + got));
+            if (n <= 0) break;
+            got += n;
+        }
+        close(fd);
+        if (got < piece.bytes) failed.store(piece.file);
+    });
+    EMPH_REQUIRE(failed.load() < 0, EMPH_EINVAL, "emph_files_read_audio: could not read %s",
+                 batch->files[static_cast<size_t>(failed.load())].audio_path.c_str());
+    return EMPH_OK;
+}
+
+// What the reference leaves behind for file which[k] (core.py:111-112):
+// <prefix>.TextGrid = the alignment it loaded, <prefix>.pt = torch.save of the
+// float32 scores [1, W] = scores[first[k] .. first[k + 1]).
+int emph_files_write(const emph_file_batch* batch, const int32_t* which,
+                     const char* const* prefixes, const float* scores, const int64_t* first,
+                     int32_t count, int32_t threads) {
+    if (count == 0) return EMPH_OK;
+    EMPH_REQUIRE(batch && which && prefixes && scores && first && threads >= 1 && threads <= 64,
+                 EMPH_EINVAL, "emph_files_write: bad arguments");
+    std::mutex guard;
+    std::string problem;
+    parallel(count, threads, [&](int k) {
+        std::string error;
+        const std::string prefix = prefixes[k];
+        bool ok = which[k] >= 0 && which[k] < static_cast<int32_t>(batch->files.size());
+        if (ok) {
+            const emph_file_batch::File& file = batch->files[static_cast<size_t>(which[k])];
+            ok = write_whole(prefix + ".TextGrid", grid_text(file.grid), &error) &&
+                 write_whole(prefix + ".pt",
+                             tensor_file(stem_of(prefix + ".pt"), scores + first[k],
+                                         first[k + 1] - first[k]),
+                             &error);
+        } else {
+            error = "no such file in the batch";
+        }
+        if (!ok) {
+            std::lock_guard<std::mutex> lock(guard);
+            if (problem.empty()) problem = error;
+        }
+    });
+    EMPH_REQUIRE(problem.empty(), EMPH_EINVAL, "emph_files_write: %s", problem.c_str());
+    return EMPH_OK;
+}
+
+}  // extern "C"

@@ -15,9 +15,10 @@ using namespace emph;
 extern "C" {
 
 int64_t emph_prominence_workspace_floats(int32_t features, int32_t channels,
-                                         int64_t ld_frames, int64_t ld_words) {
+                                         int64_t ld_frames, int64_t ld_words,
+                                         int32_t n_slots) {
     return (static_cast<int64_t>(features) + 2 * channels) * ld_frames +
-           static_cast<int64_t>(channels) * ld_words;
+           static_cast<int64_t>(channels) * (ld_words + n_slots);
 }
 
 int emph_prominence_forward(const emph_conv_model* model, const void* audio,
@@ -28,7 +29,8 @@ int emph_prominence_forward(const emph_conv_model* model, const void* audio,
                             const int32_t* word_tiles, int32_t n_word_tiles,
                             const int32_t* bounds, const int32_t* word_segment,
                             int64_t ld_frames, int64_t ld_words, float* workspace,
-                            float* logits, float* scores, void* stream) {
+                            float* logits, float* scores,
+                            const emph_word_sum_tables* word_sums, void* stream) {
     EMPH_REQUIRE(model != nullptr, EMPH_EINVAL, "emph_prominence_forward: model is null");
     const emph_conv_model& m = *model;
     EMPH_REQUIRE(audio && seg && workspace, EMPH_EINVAL,
@@ -55,6 +57,13 @@ int emph_prominence_forward(const emph_conv_model* model, const void* audio,
     float* current = features + static_cast<int64_t>(m.features) * ld_frames;
     float* other = current + static_cast<int64_t>(c) * ld_frames;
     float* words = other + static_cast<int64_t>(c) * ld_frames;
+    float* sums = words + static_cast<int64_t>(c) * ld_words;
+    const bool fold = word_sums != nullptr && m.encoder_layers > 0;
+    EMPH_REQUIRE(!fold || (quad && (m.reduction == EMPH_REDUCE_SUM ||
+                                    m.reduction == EMPH_REDUCE_AVERAGE)),
+                 EMPH_EINVAL,
+                 "emph_prominence_forward: word_sums needs conv_variant 1 and a sum / average "
+                 "reduction");
 
     int status = emph_logmel(audio, audio_format, seg, frontend_tiles, n_frontend_tiles, m.table,
                              m.mel_start, m.mel_count, m.mel_offset, m.mel_values, m.mel_nnz,
@@ -73,6 +82,15 @@ int emph_prominence_forward(const emph_conv_model* model, const void* audio,
     const int64_t pack_floats =
         quad ? emph_conv_winograd4_pack_size(c, c) : emph_conv_winograd_pack_size(c, c);
     for (int layer = 0; layer < m.encoder_layers; ++layer) {
+        if (fold && layer == m.encoder_layers - 1) {
+            // the last frame-rate layer: running sums at the marked frames only
+            status = emph_conv1d_winograd4_word_sums(
+                current, ld_frames, sums, c, m.encoder_packs + layer * pack_floats,
+                m.encoder_biases + static_cast<int64_t>(layer) * c, c, c, m.activation,
+                frame_tiles, n_frame_tiles, word_sums->slot_map, stream);
+            if (status) return status;
+            break;
+        }
         status = conv(current, other, m.encoder_packs + layer * pack_floats,
                       m.encoder_biases + static_cast<int64_t>(layer) * c, c, m.activation);
         if (status) return status;
@@ -80,8 +98,11 @@ int emph_prominence_forward(const emph_conv_model* model, const void* audio,
         current = other;
         other = swap;
     }
-    status = emph_segment_reduce(current, ld_frames, bounds, words, ld_words, c, seg,
-                                 word_segment, ld_words, m.reduction, stream);
+    status = fold ? emph_word_sums(sums, c, word_sums->terms, word_sums->first,
+                                   word_sums->lengths, words, ld_words, c, ld_words,
+                                   m.reduction, stream)
+                  : emph_segment_reduce(current, ld_frames, bounds, words, ld_words, c, seg,
+                                        word_segment, ld_words, m.reduction, stream);
     if (status) return status;
     return emph_word_decoder(words, ld_words, word_tiles, n_word_tiles, c, m.decoder_packs,
                              m.decoder_biases, m.decoder_layers, m.decoder_kernel_size,

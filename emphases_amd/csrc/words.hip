@@ -100,6 +100,48 @@ __global__ __launch_bounds__(256) void segment_reduce_kernel(
     }
 }
 
+// The per-word sums from the running sums the last frame-rate layer left behind
+// (conv1d_winograd4_kernel<..., WORD_SUMS>): word w = a handful of signed terms,
+// terms[first[w] .. first[w + 1]): a slot s >= 0 adds sums[s][:], ~s < 0
+// subtracts it (the running sum at the frame in front of the word's part of a
+// 64-frame tile), in the order of the table - a fixed order, so the result does
+// not depend on the launch.  A thread owns four channels of a word (one 16-byte
+// load per term); out is the [channels][ldw] layout emph_segment_reduce writes.
+__global__ __launch_bounds__(256) void word_sums_kernel(
+    const float* __restrict__ sums, int64_t ld_sums, const int32_t* __restrict__ terms,
+    const int32_t* __restrict__ first, const int32_t* __restrict__ lengths,
+    float* __restrict__ out, int64_t ldw, int channels, int64_t columns, int mode) {
+    const int groups = channels >> 2;
+    const int64_t index = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t word = index / groups;
+    const int group = static_cast<int>(index - word * groups);
+    if (word >= columns) return;
+    const int begin = first[word], end = first[word + 1];
+    const int frames = lengths[word];
+    if (frames < 0) return;                       // alignment padding column
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = begin; k < end; ++k) {
+        const int term = terms[k];
+        const int slot = term < 0 ? ~term : term;
+        const float4 v = *reinterpret_cast<const float4*>(
+            sums + static_cast<int64_t>(slot) * ld_sums + 4 * group);
+        if (term < 0) {
+            acc.x -= v.x, acc.y -= v.y, acc.z -= v.z, acc.w -= v.w;
+        } else {
+            acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+        }
+    }
+    if (mode == EMPH_REDUCE_AVERAGE) {
+        const float count = static_cast<float>(frames);    // 0 / 0 = NaN, as torch.mean
+        acc.x /= count, acc.y /= count, acc.z /= count, acc.w /= count;
+    }
+    float* target = out + static_cast<int64_t>(4 * group) * ldw + word;
+    target[0] = acc.x;
+    target[ldw] = acc.y;
+    target[2 * ldw] = acc.z;
+    target[3 * ldw] = acc.w;
+}
+
 // One workgroup per piece: copy `length` columns of every row, zero the rest
 // of the piece's `padded` columns.
 __global__ __launch_bounds__(256) void gather_columns_kernel(
@@ -185,6 +227,25 @@ int emph_segment_reduce(const float* x, int64_t ldx, const int32_t* bounds,
     EMPH_LAUNCH(segment_reduce_kernel<5>, dim3(blocks, slices), dim3(256), 0, s, x, ldx,
                        bounds, out, ldw, channels, seg, word_segment, total_words, mode);
     return check_launch("emph_segment_reduce");
+}
+
+int emph_word_sums(const float* sums, int64_t ld_sums, const int32_t* terms,
+                   const int32_t* first, const int32_t* lengths, float* out, int64_t ldw,
+                   int32_t channels, int64_t columns, int32_t mode, void* stream) {
+    if (columns == 0) return EMPH_OK;
+    EMPH_REQUIRE(sums && terms && first && lengths && out, EMPH_EINVAL,
+                 "emph_word_sums: null pointer");
+    EMPH_REQUIRE(mode == EMPH_REDUCE_SUM || mode == EMPH_REDUCE_AVERAGE, EMPH_EINVAL,
+                 "emph_word_sums: mode %d (sum or average)", mode);
+    EMPH_REQUIRE(channels > 0 && channels % 4 == 0 && ld_sums >= channels &&
+                     ld_sums % 4 == 0 && columns <= ldw &&
+                     (reinterpret_cast<uintptr_t>(sums) & 15) == 0,
+                 EMPH_EINVAL, "emph_word_sums: bad shape");
+    const int64_t threads = columns * (channels / 4);
+    EMPH_LAUNCH(word_sums_kernel, dim3(static_cast<unsigned>((threads + 255) / 256)),
+                dim3(256), 0, static_cast<hipStream_t>(stream), sums, ld_sums, terms, first,
+                lengths, out, ldw, channels, columns, mode);
+    return check_launch("emph_word_sums");
 }
 
 int emph_gather_columns(const float* x, int64_t ldx, float* y, int64_t ldy,

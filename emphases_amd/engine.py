@@ -182,6 +182,15 @@ class Engine:
         self.fuse_qkv = os.environ.get('EMPHASES_FUSE_QKV', '1') != '0'
         self.quad = winograd and config.activation in (None, 'relu') and \
             all(layer.winograd4 is not None for layer in frame_layers)
+        # the per-word sum folded into the last frame-rate layer's epilogue
+        # (emph_conv1d_winograd4_word_sums + emph_word_sums): by configuration,
+        # never by batch
+        self.fold = bool(
+            self.quad and config.architecture == 'convolution' and
+            config.downsample_location != 'input' and
+            config.downsample_method in ('sum', 'average') and
+            len(self.frame_encoder) > 0 and config.channels % 4 == 0 and
+            os.environ.get('EMPHASES_FOLD_WORD_SUMS', '1') != '0')
         self.model = self._conv_model()
 
     def lane(self):
@@ -407,13 +416,20 @@ class Engine:
                         (runtime.AXIS_WORDS, ATTENTION_BLOCK) + MANY_WORDS,
                         (runtime.AXIS_WORDS, self.word_block) + MANY_WORDS]
         requests = list(dict.fromkeys(requests))
-        host, offsets = plan.pack_metadata(requests)
+        fold = self.fold and not nested and tile == 64
+        host, offsets = plan.pack_metadata(requests, word_sums=fold)
         pinned = self._pinned(('meta', nested), host)
         device_buffer = pinned.to(self.device, non_blocking=True)
         views = {'_buffer': device_buffer, '_pinned': pinned, 'tile': tile,
                  'positions': (plan.total_frames, plan.total_words)}
         for name, (start, size) in offsets.items():
             views[name] = (device_buffer[start:start + size], size)
+        if fold:
+            views['n_slots'] = plan.word_sum_tables()['n_slots']
+            views['word_sum_tables'] = runtime.WordSumTables(
+                *[views[('word_sums', name)][0].data_ptr() for name in (
+                    'slot_map', 'terms', 'first', 'lengths')],
+                views['n_slots'])
         if self.config.downsample_location == 'input' and not nested and \
                 len(plan.segments):
             # every word is its own padded sequence: a second packed layout
@@ -715,6 +731,35 @@ class Engine:
             add_layernorm(layer['norm2'])
         return x
 
+    def _word_sums(self, x, ld_f, out, ld_w, plan, meta):
+        """The last frame-rate layer + `emphases.downsample` ('sum' /
+        'average', `core.py:438-454`) without the layer's output ever being
+        written: running sums at the frames the words need, then a few signed
+        terms per word."""
+        config = self.config
+        layer = self.frame_encoder[-1]
+        channels = config.channels
+        tiles, size = meta[('tiles', runtime.AXIS_FRAMES, 64)]
+        sums = self._buffer('word_sums', max(meta['n_slots'], 1), channels)
+        view = lambda name: meta[('word_sums', name)][0]  # noqa: E731
+        flops = 2. * layer.c_in * layer.c_out * 3 * plan.total_frames
+        with self._timed(
+                f'conv1d_winograd4_frames_{layer.c_in}x{layer.c_out}_k3', flops):
+            runtime.check(self.lib.emph_conv1d_winograd4_word_sums(
+                x.data_ptr(), ld_f, sums.data_ptr(), channels,
+                layer.winograd4.data_ptr(), layer.bias.data_ptr(), layer.c_in,
+                layer.c_out, runtime.ACTIVATIONS[config.activation],
+                tiles.data_ptr(), size // runtime.TILE_FIELDS,
+                view('slot_map').data_ptr(), runtime.stream()),
+                'emph_conv1d_winograd4_word_sums')
+        with self._timed('word_sums'):
+            runtime.check(self.lib.emph_word_sums(
+                sums.data_ptr(), channels, view('terms').data_ptr(),
+                view('first').data_ptr(), view('lengths').data_ptr(),
+                out.data_ptr(), ld_w, channels, ld_w,
+                runtime.REDUCTIONS[config.downsample_method],
+                runtime.stream()), 'emph_word_sums')
+
     def _stack_forward(self, layers, x, other, ld, plan, meta, axis, block,
                        tag, key_counts=None, positioned=False):
         """Frame encoder / word decoder; returns the tensor holding the
@@ -777,8 +822,10 @@ class Engine:
             check_bounds(plan, config.downsample_method)
             logits = self._buffer('logits', ld_w)
             scores = self._buffer('scores', ld_w)
+            tables = meta.get('word_sum_tables')
             floats = self.lib.emph_prominence_workspace_floats(
-                config.num_features, channels, ld_f, ld_w)
+                config.num_features, channels, ld_f, ld_w,
+                meta.get('n_slots', 0))
             workspace = self._buffer('fused', int(floats))
             frontend_tiles, frontend_size = meta[
                 ('tiles', frames, FRONTEND_BLOCK)]
@@ -794,6 +841,7 @@ class Engine:
                 meta['bounds'][0].data_ptr(),
                 meta['word_segment'][0].data_ptr(), ld_f, ld_w,
                 workspace.data_ptr(), logits.data_ptr(), scores.data_ptr(),
+                None if tables is None else ctypes.byref(tables),
                 runtime.stream()), 'emph_prominence_forward')
             return scores, logits
         if features is None:
@@ -847,20 +895,28 @@ class Engine:
             if stages is not None:
                 stages['features'] = features.clone()
                 stages['input_layer'] = a.clone()
+            # (the stage dump wants the encoder's own output: the taps keep
+            # the unfolded reduce, which agrees to summation order)
+            fold = 'word_sum_tables' in meta and stages is None
             encoded = self._stack_forward(
-                self.frame_encoder, a, b, ld_f, plan, meta, frames, block,
-                'frames', positioned=positioned)
+                self.frame_encoder[:-1] if fold else self.frame_encoder, a, b,
+                ld_f, plan, meta, frames, block, 'frames',
+                positioned=positioned)
             if stages is not None:
                 stages['encoder'] = encoded.clone()
 
             check_bounds(plan, config.downsample_method)
-            with self._timed('segment_reduce'):
-                runtime.check(self.lib.emph_segment_reduce(
-                    encoded.data_ptr(), ld_f, meta['bounds'][0].data_ptr(),
-                    wa.data_ptr(), ld_w, channels, table.data_ptr(),
-                    meta['word_segment'][0].data_ptr(), ld_w,
-                    runtime.REDUCTIONS[config.downsample_method],
-                    runtime.stream()), 'emph_segment_reduce')
+            if fold:
+                self._word_sums(encoded, ld_f, wa, ld_w, plan, meta)
+            else:
+                with self._timed('segment_reduce'):
+                    runtime.check(self.lib.emph_segment_reduce(
+                        encoded.data_ptr(), ld_f,
+                        meta['bounds'][0].data_ptr(), wa.data_ptr(), ld_w,
+                        channels, table.data_ptr(),
+                        meta['word_segment'][0].data_ptr(), ld_w,
+                        runtime.REDUCTIONS[config.downsample_method],
+                        runtime.stream()), 'emph_segment_reduce')
         if stages is not None:
             stages['downsampled'] = wa.clone()
         if self.fused_words:

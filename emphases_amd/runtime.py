@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -74,6 +74,11 @@ SIGNATURES = {
     'emph_conv1d_winograd4_position': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _ptr, _i32,
         _ptr, _i32, _ptr]),
+    'emph_conv1d_winograd4_word_sums': (_c.c_int, [
+        _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _ptr, _i32,
+        _ptr, _ptr]),
+    'emph_word_sums': (_c.c_int, [
+        _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _ptr]),
     'emph_conv_winograd4_split_pack': (_c.c_int, [_ptr, _i32, _i32, _ptr]),
     'emph_conv1d_winograd4_half': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _ptr, _i32,
@@ -93,10 +98,22 @@ SIGNATURES = {
         _i32, _ptr, _ptr, _ptr]),
     'emph_qkv_projection': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
-    'emph_prominence_workspace_floats': (_i64, [_i32, _i32, _i64, _i64]),
+    'emph_prominence_workspace_floats': (
+        _i64, [_i32, _i32, _i64, _i64, _i32]),
     'emph_prominence_forward': (_c.c_int, [
         _ptr, _ptr, _i32, _ptr, _ptr, _i32, _ptr, _i32, _i32, _ptr, _i32, _ptr,
-        _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr]),
+        _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'emph_files_open': (_c.c_int, [_ptr, _ptr, _i32, _i32, _ptr]),
+    'emph_files_close': (None, [_ptr]),
+    'emph_files_error': (_c.c_char_p, [_ptr, _i32]),
+    'emph_files_sizes': (_c.c_int, [_ptr, _ptr]),
+    'emph_files_alignments': (_c.c_int, [
+        _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _ptr]),
+    'emph_files_tier_name_bytes': (_i64, [_ptr]),
+    'emph_files_read_audio': (_c.c_int, [
+        _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _i32]),
+    'emph_files_write': (_c.c_int, [
+        _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32]),
     'emph_gather_columns': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _i32, _ptr, _i32, _ptr]),
     'emph_word_decoder_block': (_i32, [_i32, _i32, _i32]),
@@ -260,6 +277,12 @@ class ConvModel(_c.Structure):
             'table', 'mel_start', 'mel_count', 'mel_offset', 'mel_values',
             'input_pack', 'input_bias', 'encoder_packs', 'encoder_biases',
             'decoder_packs', 'decoder_biases', 'out_weight', 'out_bias')]
+
+
+class WordSumTables(_c.Structure):
+    """`emph_word_sum_tables` of include/emphases_hip.h."""
+    _fields_ = [(name, _ptr) for name in (
+        'slot_map', 'terms', 'first', 'lengths')] + [('n_slots', _i32)]
 
 
 def word_decoder_pack(weight):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 23
+#define EMPH_ABI_VERSION 24
 
 /* Segment-table fields */
 enum {
@@ -114,6 +114,63 @@ const char* emph_last_error(void);
 int emph_host_gather(const void* const* host_sources, const int64_t* host_bytes,
                      const int64_t* host_offsets, int32_t count,
                      void* host_destination, int32_t threads);
+
+/* ------------------------------------------------------------------------ */
+/* The file boundary of from_files_to_files, a batch at a time               */
+/* ------------------------------------------------------------------------ */
+
+/* emphases.from_files_to_files (emphases/core.py:115-179) loads one alignment
+ * (`pypar.Alignment(text_file)`, core.py:49,107) and one audio file
+ * (`emphases.load.audio`, load.py:11-17) at a time on the Python thread and
+ * writes `<prefix>.TextGrid` + `<prefix>.pt` (core.py:111-112) the same way.
+ * These entry points do that for a BATCH of files on a pool of host threads
+ * (no device code, no Python per file): Praat TextGrids (long or short text
+ * format; UTF-8 with or without BOM, UTF-16) are parsed and the RIFF/WAVE
+ * chunk lists walked in parallel; the samples of mono 16-bit PCM / float32
+ * files are read straight into the batch's (pinned) staging buffer; outputs
+ * are written in parallel.  Same grammar, same gap filling, same walker and
+ * the same written bytes as emphases_amd/alignment.py / load.py. */
+typedef struct emph_file_batch emph_file_batch;
+
+/* Parse text_paths[i] (.TextGrid) and walk the headers of audio_paths[i]
+ * (.wav), i < count.  A file that fails is reported per file (emph_files_sizes
+ * status, emph_files_error), not as an error of the call. */
+int emph_files_open(const char* const* text_paths,
+                    const char* const* audio_paths, int32_t count,
+                    int32_t threads, emph_file_batch** batch);
+void emph_files_close(emph_file_batch* batch);
+const char* emph_files_error(const emph_file_batch* batch, int32_t index);
+
+/* sizes int64 [count][12] = {status (bit 0: alignment failed, bit 1: audio
+ * failed), words (gaps filled), phonemes (-1: no phoneme tier), bytes of word
+ * labels, bytes of phoneme labels, WAVE format code, channels, sample rate,
+ * bits per sample, data offset, data bytes, phoneme tier first?} */
+int emph_files_sizes(const emph_file_batch* batch, int64_t* sizes);
+
+/* All alignments back to back (any pointer may be NULL): word_times float64
+ * [words][2] seconds, word labels as UTF-8 bytes with END offsets per word;
+ * the same for the phonemes plus the index (within its file) of the word each
+ * belongs to; per file "word tier\nphoneme tier" with END offsets. */
+int emph_files_alignments(const emph_file_batch* batch, double* word_times,
+                          char* word_text, int64_t* word_text_end,
+                          double* phone_times, char* phone_text,
+                          int64_t* phone_text_end, int32_t* phone_word,
+                          char* tier_names, int64_t* tier_names_end);
+int64_t emph_files_tier_name_bytes(const emph_file_batch* batch);
+
+/* bytes[k] bytes of the data chunk of file which[k] to destination +
+ * where[k] (a HOST pointer: the pinned staging buffer). */
+int emph_files_read_audio(const emph_file_batch* batch, const int32_t* which,
+                          const int64_t* where, const int64_t* bytes,
+                          int32_t count, void* destination, int32_t threads);
+
+/* <prefixes[k]>.TextGrid = the alignment of file which[k] as loaded (both
+ * tiers, original tier names and order) and <prefixes[k]>.pt = torch.save of
+ * the float32 CPU tensor [1, W] = scores[first[k] .. first[k + 1]) (HOST
+ * pointer), readable by torch.load. */
+int emph_files_write(const emph_file_batch* batch, const int32_t* which,
+                     const char* const* prefixes, const float* scores,
+                     const int64_t* first, int32_t count, int32_t threads);
 
 /* ------------------------------------------------------------------------ */
 /* Front-end: framed log-mel (+ optional A-weighted loudness row)            */
@@ -287,7 +344,25 @@ int emph_conv1d_winograd4_position(const float* x, int64_t ldx, float* y,
                                    const float* position,
                                    int32_t max_positions, void* stream);
 
-/* The F(4,3) layer as TWO independent launches ("halves"): half 0 computes the
+/* The F(4,3) layer as the LAST frame-rate layer in front of the per-word sum
+ * of emphases.downsample (emphases/core.py:438-454; DOWNSAMPLE_METHOD 'sum' /
+ * 'average'): the layer's output is never written.  Each 64-position tile forms
+ * the running sum of its positions per channel (fixed order) and stores it only
+ * where `slot_map` asks: slot_map int32 [ld frames] (16-byte aligned, indexed
+ * by packed frame column) holds the row of `sums` a column reports to, or -1.
+ * sums float32 [n_slots][ld_sums], ld_sums >= c_out, both multiples of 4.
+ * emph_word_sums turns the rows into per-word sums.  Replaces
+ * emph_conv1d_winograd4 + emph_segment_reduce for that layer (same values up
+ * to summation order: a word's sum is a difference of running sums). */
+int emph_conv1d_winograd4_word_sums(const float* x, int64_t ldx, float* sums,
+                                    int64_t ld_sums, const float* pack,
+                                    const float* bias, int32_t c_in,
+                                    int32_t c_out, int32_t activation,
+                                    const int32_t* tiles, int32_t n_tiles,
+                                    const int32_t* slot_map, void* stream);
+
+/* EXPERIMENTAL (measured in DESIGN.md section 6, not used by the engine):
+ * the F(4,3) layer as TWO independent launches ("halves"): half 0 computes the
  * output channels of the first ceil(m_tiles / 2) 16-channel tiles, half 1 the
  * rest, each around its own rows of the pack only (92 KB + 61 KB of LDS for
  * 80 x 80, four waves per workgroup).  Same values, bit for bit, as
@@ -330,6 +405,22 @@ int emph_segment_reduce(const float* x, int64_t ldx, const int32_t* bounds,
                         float* out, int64_t ldw, int32_t channels,
                         const int64_t* seg, const int32_t* word_segment,
                         int64_t total_words, int32_t mode, void* stream);
+
+/* Per-word sums from the running sums emph_conv1d_winograd4_word_sums left in
+ * `sums`: word column w = the signed terms terms[first[w] .. first[w + 1]) in
+ * table order (s >= 0: + sums[s][:]; s < 0: - sums[~s][:]), divided by
+ * lengths[w] for EMPH_REDUCE_AVERAGE (0 / 0 = NaN like torch.mean).
+ *   first    int32 [columns + 1]
+ *   lengths  int32 [columns]   frames the word covers inside its chunk (the
+ *                              Python-slice clamp of core.py:446-454), -1 for
+ *                              alignment padding columns (left untouched)
+ *   out      float32 [channels][ldw]   what emph_segment_reduce writes
+ * The tables are host arithmetic on the word bounds (emphases_amd/batch.py,
+ * `Plan.word_sum_tables`). */
+int emph_word_sums(const float* sums, int64_t ld_sums, const int32_t* terms,
+                   const int32_t* first, const int32_t* lengths, float* out,
+                   int64_t ldw, int32_t channels, int64_t columns, int32_t mode,
+                   void* stream);
 
 /* ------------------------------------------------------------------------ */
 /* Output projection + postprocess                                           */
@@ -618,10 +709,22 @@ typedef struct emph_conv_model {
     const float* out_bias;        /* [1]                                       */
 } emph_conv_model;
 
+/* Tables of the fused per-word sum (emph_conv1d_winograd4_word_sums +
+ * emph_word_sums), device pointers. */
+typedef struct emph_word_sum_tables {
+    const int32_t* slot_map;      /* [ld_frames]                               */
+    const int32_t* terms;         /* signed slots                              */
+    const int32_t* first;         /* [ld_words + 1]                            */
+    const int32_t* lengths;       /* [ld_words]                                */
+    int32_t n_slots;
+} emph_word_sum_tables;
+
 /* Floats of scratch emph_prominence_forward needs (features, two activation
- * buffers on the frame axis, the word embeddings). */
+ * buffers on the frame axis, the word embeddings, `n_slots` rows of running
+ * sums). */
 int64_t emph_prominence_workspace_floats(int32_t features, int32_t channels,
-                                         int64_t ld_frames, int64_t ld_words);
+                                         int64_t ld_frames, int64_t ld_words,
+                                         int32_t n_slots);
 
 /* log-mel -> input conv -> encoder convs -> per-word reduce -> word decoder ->
  * scores for a whole ragged batch: emphases.infer + emphases.postprocess
@@ -630,7 +733,10 @@ int64_t emph_prominence_workspace_floats(int32_t features, int32_t channels,
  * kernel_size 3 and mel features.  The tables are those of the individual
  * entry points: `frontend_tiles` with blocks of emph_frontend_block() frames, `frame_tiles` with
  * block `tile_n` (32 or 64; 64 for conv_variant 1), `word_tiles` from
- * emph_word_decoder_tiles(...).  Enqueues on `stream`; allocates nothing. */
+ * emph_word_decoder_tiles(...).  `word_sums` (conv_variant 1, reduction sum /
+ * average; else NULL): the last encoder layer leaves running sums instead of
+ * its output and emph_word_sums replaces emph_segment_reduce.  Enqueues on
+ * `stream`; allocates nothing. */
 int emph_prominence_forward(const emph_conv_model* model, const void* audio,
                             int32_t audio_format, const int64_t* seg,
                             const int32_t* frontend_tiles,
@@ -640,7 +746,9 @@ int emph_prominence_forward(const emph_conv_model* model, const void* audio,
                             int32_t n_word_tiles, const int32_t* bounds,
                             const int32_t* word_segment, int64_t ld_frames,
                             int64_t ld_words, float* workspace, float* logits,
-                            float* scores, void* stream);
+                            float* scores,
+                            const emph_word_sum_tables* word_sums,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -464,14 +464,76 @@ def test_fused_forward_equals_step_by_step(cases, default_engine):
     finally:
         names = {name for name, *_ in default_engine.timers}
         default_engine.timers = None
-    assert 'word_decoder' in names and 'segment_reduce' in names
+    # (the per-word sum rides on the last frame-rate layer's epilogue)
+    assert 'word_decoder' in names and 'word_sums' in names
+    assert default_engine.fold and 'segment_reduce' not in names
     columns = plan.word_columns()
     assert torch.equal(fused[columns], stepped[columns])
     assert torch.equal(fused_logits[columns], stepped_logits[columns])
     library = runtime.library()
     assert library.emph_prominence_forward(
         None, 0, 0, 0, None, 0, None, 0, 32, None, 0, None, None, 0, 0, 0, None,
-        None, None) == -1
+        None, None, None) == -1
+
+
+@pytest.mark.parametrize('method', ['sum', 'average'])
+def test_folded_word_sums_against_segment_reduce(method):
+    """The per-word sum folded into the last frame-rate layer
+    (emph_conv1d_winograd4_word_sums + emph_word_sums: running sums per
+    64-frame tile, a few signed terms per word) against the unfolded pair
+    emph_conv1d_winograd4 + emph_segment_reduce on bounds that stress the
+    tables: words across several tiles, one-frame words, EMPTY words (sum 0,
+    average NaN), an end beyond the chunk (truncated like a Python slice), a
+    start beyond the chunk, overlapping words, frames no word covers, a
+    segment of one frame - for a ragged batch."""
+    config = cfg.Config(downsample_method=method)
+    engine = engine_module.Engine(config, None, 0)
+    assert engine.fold
+    frames = [1000, 37, 130, 64, 65, 1, 447]
+    audios = [synth.audio(60 + i, n) for i, n in enumerate(frames)]
+    rng = np.random.default_rng(5)
+    bounds = []
+    for n in frames:
+        starts = np.sort(rng.integers(0, n + 1, size=max(2, n // 9)))
+        ends = np.minimum(starts + rng.integers(0, 150, size=starts.size), n + 40)
+        ends[0] = starts[0]                      # an empty word
+        starts[-1] = n + 3                       # starts beyond the chunk
+        ends[-1] = n + 9
+        bounds.append(np.stack([starts, ends]).astype(np.int64))
+    segments = [batch.Segment(i, 0, b.shape[1], 432, n * 160, n, b)
+                for i, (n, b) in enumerate(zip(frames, bounds))]
+    lengths = [a.shape[1] for a in audios]
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+    plan = batch.Plan(segments, offsets, lengths)
+    packed = torch.cat([torch.from_numpy(a).reshape(-1) for a in audios]).cuda()
+    meta = engine.upload(plan)
+    assert 'word_sum_tables' in meta
+    stages = {}
+    engine.forward(packed, plan, meta, stages=stages)     # taps: unfolded
+    want = stages['downsampled']
+    engine.timers = []
+    try:
+        engine.forward(packed, plan, meta)                # folded, step by step
+    finally:
+        engine.timers = None
+    got = engine._buffer('words_a', config.channels, plan.ld_words)
+    columns = torch.from_numpy(plan.word_columns()).cuda()
+    got, want = got[:, columns].cpu(), want[:, columns].cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    if method == 'average':
+        assert bool(torch.isnan(want).any())
+    scale = float(want.nan_to_num().abs().max())
+    worst = float((got - want).nan_to_num().abs().max())
+    assert worst < 2e-6 * max(scale, 1.), (worst, scale)
+    # and through the one-call path: same bits as step by step
+    fused, _ = engine.forward(packed, plan, meta)
+    engine.timers = []
+    try:
+        stepped, _ = engine.forward(packed, plan, meta)
+    finally:
+        engine.timers = None
+    assert torch.equal(
+        fused[columns].nan_to_num(), stepped[columns].nan_to_num())
 
 
 def test_graph_replay_equals_eager(default_engine):
