@@ -867,6 +867,122 @@ def side_longform(device):
     return result
 
 
+def side_files_api(device, count=2048):
+    """The drop-in surface itself (`emphases/core.py:115-179`): `count`
+    synthetic 10 s utterances as 16-bit PCM .wav + .TextGrid files in
+    /dev/shm, `emphases_amd.from_files_to_files` over all of them (read,
+    parse, plan, stage, H2D, kernels, D2H, write `<prefix>.TextGrid` + `.pt`),
+    files/s; and where a batch's time goes, each phase timed by itself on one
+    batch of 256 files (they overlap in the call: two batches in flight)."""
+    import shutil
+    import tempfile
+    from emphases_amd import files, load
+    root = '/dev/shm' if os.path.isdir('/dev/shm') else None
+    directory = tempfile.mkdtemp(prefix='emph_files_', dir=root)
+    try:
+        distinct = 32
+        texts, waves, prefixes = [], [], []
+        for index in range(count):
+            wave = os.path.join(directory, f'a{index % distinct}.wav')
+            if index < distinct:
+                load.save_wav(wave, synth.audio(index, FRAMES))
+            else:       # hard links: distinct files, the same 32 signals
+                link = os.path.join(directory, f'a{index}.wav')
+                os.link(wave, link)
+                wave = link
+            text = os.path.join(directory, f'u{index}.TextGrid')
+            bounds = synth.word_frames(3000 + index, FRAMES)
+            emphases_amd.Alignment.from_frames(
+                bounds, synth.word_names(bounds.shape[1])).save(text)
+            texts.append(text)
+            waves.append(wave)
+            prefixes.append(os.path.join(directory, f'out{index}'))
+        emphases_amd.from_files_to_files(
+            texts[:512], waves[:512], prefixes[:512], gpu=device.index)
+        laps = []
+        for _ in range(3):
+            start = time.perf_counter()
+            emphases_amd.from_files_to_files(
+                texts, waves, prefixes, gpu=device.index)
+            laps.append(time.perf_counter() - start)
+        seconds = float(np.median(laps))
+        scores = torch.load(prefixes[-1] + '.pt')
+        result = {
+            'workload': (
+                f'{count} synthetic 10 s utterances as 16-bit PCM .wav + '
+                '.TextGrid files in /dev/shm through '
+                'emphases_amd.from_files_to_files (emphases/core.py:115-179): '
+                'read + parse + plan + stage + H2D + kernels + D2H + write '
+                '.TextGrid and .pt per file; batches of 256 files, two in '
+                'flight'),
+            'files': count, 'seconds': seconds, 'laps_s': laps,
+            'files_per_s': count / seconds,
+            'realtime_factor': count * 10. / seconds,
+            'last_file_scores': int(scores.numel()),
+            'reference_loop_files_per_s_python_readers': None}
+        # phases of ONE batch of 256 files, each by itself
+        some = slice(0, 256)
+
+        def clock(function, rounds=5):
+            function()
+            times = []
+            for _ in range(rounds):
+                start = time.perf_counter()
+                value = function()
+                times.append(time.perf_counter() - start)
+            return float(np.median(times)) * 1e3, value
+        phases = {}
+        phases['open_parse_and_headers_ms'], opened = clock(
+            lambda: files.FileBatch(texts[some], waves[some]))
+        alignments = [opened.alignment(i) for i in range(256)]
+        lengths = [opened.audio(i)[0].shape[0] for i in range(256)]
+        pinned = torch.empty(sum(lengths), dtype=torch.int16).pin_memory()
+        where = np.concatenate([[0], np.cumsum(lengths)[:-1]]) * 2
+        phases['read_samples_into_pinned_ms'], _ = clock(lambda: opened.read(
+            list(range(256)), where, np.asarray(lengths) * 2,
+            pinned.data_ptr()))
+        phases['plan_ms'], plan = clock(
+            lambda: batch.plan_batch(alignments, lengths, None))
+        on_device = torch.empty_like(pinned, device=device)
+
+        def h2d():
+            on_device.copy_(pinned, non_blocking=True)
+            torch.cuda.synchronize()
+        phases['h2d_ms'], _ = clock(h2d)
+        engine = emphases_amd.get_engine(None, device.index)
+        with engine.lock:
+            meta = engine.upload(plan)
+            replay, kept, _ = engine.capture(on_device, plan, meta)
+
+            def kernels():
+                replay()
+                torch.cuda.synchronize()
+            phases['kernels_ms'], _ = clock(kernels)
+        rows = [torch.rand(1, len(a)) for a in alignments]
+        phases['write_textgrid_and_pt_ms'], _ = clock(lambda: opened.write(
+            list(range(256)), prefixes[some], rows))
+        # the same batch through the Python readers / writers, one file at a
+        # time (what the package did before csrc/files.hip)
+        from emphases_amd import alignment as alignment_module
+
+        def python_files():
+            for index in range(64):
+                item = alignment_module.Alignment(texts[index])
+                load.wav(waves[index], raw=True)
+                item.save(prefixes[index] + '.TextGrid')
+                torch.save(rows[index], prefixes[index] + '.pt')
+        per_64, _ = clock(python_files, rounds=3)
+        phases['python_readers_and_writers_ms_per_256_files'] = per_64 * 4
+        result['reference_loop_files_per_s_python_readers'] = \
+            64 / (per_64 * 1e-3)
+        result['phases_of_one_256_file_batch'] = phases
+        result['host'] = {'cgroup_cpu_quota': cpu_quota(),
+                          'threads': files.THREADS}
+        return result
+    finally:
+        shutil.rmtree(directory, ignore_errors=True)
+
+
 def guarded(function, *args):
     """(the side measurements must never cost the line its headline)"""
     try:
@@ -1271,6 +1387,7 @@ def run_batch(args, rank, world, device, host):
                 result['end_to_end_api'] = guarded(
                     end_to_end_api, audios, alignments)
             if not args.no_side:
+                result['files_api'] = guarded(side_files_api, device)
                 result['configs_2_transformer'] = guarded(
                     side_transformer, device, audios, alignments, args)
                 result['configs_4_longform'] = guarded(side_longform, device)

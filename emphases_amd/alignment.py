@@ -110,10 +110,31 @@ class Alignment:
             else:
                 raise ValueError(
                     f'Alignment file format of {path} is not supported')
-        self._words = _fill_gaps(words)
+        self._word_list = _fill_gaps(words)
+        self._loader = None
         self._relative = relative
         self._times = None
         self.times()          # the batch planner reads the words as one array
+
+    @classmethod
+    def lazy(cls, times, loader):
+        """Alignment whose word TIMES are known (float64 [W, 2], gaps already
+        filled) and whose `Word` objects are built by `loader() -> (words,
+        tiers)` only when somebody asks for them: the batch planner reads
+        `times()` alone (`files.FileBatch`)."""
+        self = cls.__new__(cls)
+        self._word_list = None
+        self._loader = loader
+        self._relative = False
+        self._times = times
+        return self
+
+    @property
+    def _words(self):
+        if self._word_list is None:
+            self._word_list, self.tiers = self._loader()
+            self._loader = None
+        return self._word_list
 
     @classmethod
     def from_frames(cls, bounds, names=None, frames_per_second=100.0):
@@ -125,7 +146,8 @@ class Alignment:
             for name, s, e in zip(names, starts, ends)])
 
     def __len__(self):
-        return len(self._words)
+        return len(self._times) if self._word_list is None \
+            else len(self._word_list)
 
     def __iter__(self):
         return iter(self._words)
@@ -162,6 +184,8 @@ class Alignment:
         """float64 [W, 2] (start, end) seconds of every word (cached: the
         batch planner reads all words of all utterances as arrays)."""
         cached = self._times
+        if self._word_list is None and cached is not None:
+            return cached
         if cached is None or cached.shape[0] != len(self._words):
             import numpy as np
             cached = np.array(

@@ -204,13 +204,19 @@ def from_file_to_file(text_file, audio_file, output_prefix=None,
 
 
 def files_to_scores(text_files, audio_files, session, batch_size=None,
-                    utterances_per_batch=64, deliver=None):
+                    utterances_per_batch=256, deliver=None,
+                    deliver_batch=None):
     """The loop of `core.py:169-179` over ragged batches of
-    `utterances_per_batch` files, two batches in flight: the files of batch
-    i+1 are read and staged while batch i computes, 16-bit PCM files travel to
-    the device as 16-bit PCM, files that are not at 16 kHz are resampled on
-    the device (one submission per sample rate).  `deliver(index, alignment,
-    scores)` is called for every file, in order within a batch."""
+    `utterances_per_batch` files, two batches in flight.  A batch of files is
+    opened by the library in one call (`files.FileBatch`: TextGrids parsed and
+    WAVE headers walked on a pool of host threads), the samples of batch i+1
+    are read straight into the session's pinned staging buffer while batch i
+    computes, 16-bit PCM files travel to the device as 16-bit PCM, files that
+    are not at 16 kHz are resampled on the device (one submission per sample
+    rate).  Results: `deliver_batch(opened, local indices, global indices,
+    scores)` once per submission, or `deliver(index, alignment, scores)` per
+    file, in order within a batch."""
+    from . import files
     text_files, audio_files = list(text_files), list(audio_files)
     for file in text_files:
         if not str(file).endswith(('.TextGrid', '.json')):
@@ -218,25 +224,28 @@ def files_to_scores(text_files, audio_files, session, batch_size=None,
     in_flight = []
 
     def finish(jobs):
-        for pending, alignments, indices in jobs:
-            for item, scores, index in zip(
-                    alignments, pending.result(), indices):
-                deliver(index, item, scores)
+        for pending, opened, chosen, indices in jobs:
+            scores = pending.result()
+            if deliver_batch is not None:
+                deliver_batch(opened, chosen, indices, scores)
+            else:
+                for local, index, item in zip(chosen, indices, scores):
+                    deliver(index, opened.alignment(local), item)
 
     for first in range(0, len(text_files), utterances_per_batch):
         last = min(first + utterances_per_batch, len(text_files))
-        alignments = [
-            alignment_module.Alignment(file)
-            for file in text_files[first:last]]
-        loaded = [load.wav(file, raw=True) for file in audio_files[first:last]]
+        opened = files.FileBatch(
+            text_files[first:last], audio_files[first:last])
+        alignments = [opened.alignment(i) for i in range(last - first)]
+        loaded = [opened.audio(i) for i in range(last - first)]
         jobs = []
         for rate in sorted({rate for _, rate in loaded}):
             chosen = [i for i, (_, r) in enumerate(loaded) if r == rate]
-            picked = [alignments[i] for i in chosen]
             jobs.append((
                 session.submit(
-                    picked, [loaded[i][0] for i in chosen], rate, batch_size),
-                picked, [first + i for i in chosen]))
+                    [alignments[i] for i in chosen],
+                    [loaded[i][0] for i in chosen], rate, batch_size),
+                opened, chosen, [first + i for i in chosen]))
         finish(in_flight)
         in_flight = jobs
     finish(in_flight)
@@ -244,19 +253,21 @@ def files_to_scores(text_files, audio_files, session, batch_size=None,
 
 def from_files_to_files(text_files, audio_files, output_prefixes=None,
                         checkpoint=None, batch_size=None, gpu=None,
-                        utterances_per_batch=64, conv_tile=None):
+                        utterances_per_batch=256, conv_tile=None):
     """`core.py:115-179`, but the files are processed in ragged batches of
-    `utterances_per_batch` instead of one at a time, two batches in flight
+    `utterances_per_batch` instead of one at a time, two batches in flight,
+    read, parsed and written by the library's host threads
     (`files_to_scores`).  On several GPUs: `dist.from_files_to_files`."""
     from pathlib import Path
     text_files, audio_files = list(text_files), list(audio_files)
     if output_prefixes is None:
         output_prefixes = [Path(file).stem for file in text_files]
+    output_prefixes = list(output_prefixes)
     session = get_session(checkpoint, gpu, None, conv_tile)
     files_to_scores(
         text_files, audio_files, session, batch_size, utterances_per_batch,
-        lambda index, item, scores: _save(
-            item, scores, output_prefixes[index]))
+        deliver_batch=lambda opened, chosen, indices, scores: opened.write(
+            chosen, [output_prefixes[i] for i in indices], scores))
 
 
 ###############################################################################

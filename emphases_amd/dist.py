@@ -315,7 +315,7 @@ def from_alignments_and_audios(alignments, audios, sample_rate=16000,
 
 def from_files_to_files(text_files, audio_files, output_prefixes=None,
                         checkpoint=None, batch_size=None, config=None,
-                        group=None, utterances_per_batch=64,
+                        group=None, utterances_per_batch=256,
                         conv_tile=CONV_TILE, gather=True, compute=None):
     """`emphases.from_files_to_files` (`core.py:115-179`) over the ranks of a
     process group, one process per GPU.  No rank reads what it does not
@@ -393,9 +393,15 @@ def from_files_to_files(text_files, audio_files, output_prefixes=None,
         elif mine:
             from . import core
             session = core.get_session(checkpoint, gpu, config, conv_tile)
+            def deliver_batch(opened, chosen, indices, scores):
+                opened.write(
+                    chosen, [output_prefixes[mine[i]] for i in indices],
+                    scores)
+                for index, item in zip(indices, scores):
+                    local[mine[index]] = item
             core.files_to_scores(
                 own_text, own_audio, session, batch_size, utterances_per_batch,
-                deliver)
+                deliver_batch=deliver_batch)
     except Exception as error:       # noqa: BLE001
         if not gather:
             raise

@@ -1,0 +1,232 @@
+"""The file boundary of `from_files_to_files` (`emphases/core.py:115-179`), a
+batch at a time, on the library's pool of host threads (`csrc/files.hip`).
+
+The reference loads one alignment (`pypar.Alignment(text_file)`, `core.py:49`)
+and one audio file (`emphases.load.audio`, `load.py:11-17`) at a time on the
+Python thread and saves `<prefix>.TextGrid` / `<prefix>.pt` the same way
+(`core.py:111-112`).  The device path behind it takes a few microseconds per
+utterance, so at corpus scale the files set the rate: in Python alone a 10 s
+file costs 0.5 ms to parse, 0.5 ms to read and 0.2 ms to save.  A `FileBatch`
+opens a batch of (TextGrid, WAV) pairs in one library call (parsed and
+header-walked in parallel), hands the planner the word times as arrays
+(`Alignment` objects that build their `Word`s only when somebody asks), lets
+the session read the samples of mono 16-bit PCM / float32 files STRAIGHT into
+its pinned staging buffer (`FileAudio` stands in for the tensor), and writes
+the outputs of a batch in one call.
+
+Files the fast path does not take - JSON alignments, multi-channel or 8 / 24 /
+32-bit integer WAVE files - go through `alignment.py` / `load.py` one by one,
+with the same results; a file that cannot be read raises what those readers
+raise.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import alignment as alignment_module
+from . import load
+from . import runtime
+
+THREADS = 16
+
+
+class FileAudio:
+    """Stands in for the 1-D tensor of a mono 16-bit PCM / float32 WAVE file
+    whose samples have not been read: the session reads them straight into its
+    staging buffer (`Session` looks at `shape`, `dtype`, `is_cuda` only)."""
+    is_cuda = False
+
+    def __init__(self, batch, index, samples, dtype, rate):
+        self.batch, self.index = batch, index
+        self.shape = (int(samples),)
+        self.dtype = dtype
+        self.rate = int(rate)
+
+    def dim(self):
+        return 1
+
+    def reshape(self, *shape):
+        return self
+
+    def tensor(self):
+        """The samples as a tensor (read through `load.wav`): for callers
+        that need values on the host, e.g. a mixed int16 / float32 batch."""
+        samples, _ = load.wav(self.batch.audio_files[self.index], raw=True)
+        return samples[0]
+
+
+class FileBatch:
+    """`count` (alignment file, audio file) pairs opened by the library."""
+
+    def __init__(self, text_files, audio_files, threads=THREADS):
+        self.text_files = [str(file) for file in text_files]
+        self.audio_files = [str(file) for file in audio_files]
+        self.count = len(self.text_files)
+        self.threads = int(threads)
+        lib = runtime.library()
+        self._lib = lib
+        self._handle = ctypes.c_void_p()
+        self._text = (ctypes.c_char_p * max(self.count, 1))(
+            *[file.encode() for file in self.text_files])
+        self._audio = (ctypes.c_char_p * max(self.count, 1))(
+            *[file.encode() for file in self.audio_files])
+        runtime.check(lib.emph_files_open(
+            self._text, self._audio, self.count, self.threads,
+            ctypes.byref(self._handle)), 'emph_files_open')
+        sizes = np.zeros((self.count, 12), dtype=np.int64)
+        runtime.check(lib.emph_files_sizes(
+            self._handle, sizes.ctypes.data), 'emph_files_sizes')
+        self.sizes = sizes
+        self.status = sizes[:, 0]
+        words = sizes[:, 1]
+        self.word_first = np.concatenate([[0], np.cumsum(words)])
+        self.times = np.zeros((int(words.sum()), 2), dtype=np.float64)
+        runtime.check(lib.emph_files_alignments(
+            self._handle, self.times.ctypes.data, None, None, None, None,
+            None, None, None, None), 'emph_files_alignments')
+        self._labels = None
+
+    def close(self):
+        if self._handle:
+            self._lib.emph_files_close(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001
+            pass
+
+    def error(self, index):
+        return self._lib.emph_files_error(self._handle, index).decode(
+            'utf-8', 'replace')
+
+    ###########################################################################
+    # Alignments
+    ###########################################################################
+
+    def labels(self):
+        """Word / phoneme labels and tier names of the whole batch (fetched
+        once, on the first request: the planner needs the times only)."""
+        if self._labels is None:
+            sizes = self.sizes
+            phones = np.maximum(sizes[:, 2], 0)
+            word_blob = ctypes.create_string_buffer(int(sizes[:, 3].sum()) + 1)
+            phone_blob = ctypes.create_string_buffer(int(sizes[:, 4].sum()) + 1)
+            word_end = np.zeros(int(sizes[:, 1].sum()), dtype=np.int64)
+            phone_end = np.zeros(int(phones.sum()), dtype=np.int64)
+            phone_times = np.zeros((int(phones.sum()), 2), dtype=np.float64)
+            phone_word = np.zeros(int(phones.sum()), dtype=np.int32)
+            tier_blob = ctypes.create_string_buffer(
+                int(self._lib.emph_files_tier_name_bytes(self._handle)) + 1)
+            tier_end = np.zeros(self.count, dtype=np.int64)
+            runtime.check(self._lib.emph_files_alignments(
+                self._handle, None, word_blob, word_end.ctypes.data,
+                phone_times.ctypes.data, phone_blob, phone_end.ctypes.data,
+                phone_word.ctypes.data, tier_blob, tier_end.ctypes.data),
+                'emph_files_alignments')
+            self._labels = dict(
+                word_blob=word_blob.raw, word_end=word_end,
+                phone_blob=phone_blob.raw, phone_end=phone_end,
+                phone_times=phone_times, phone_word=phone_word,
+                phone_first=np.concatenate([[0], np.cumsum(phones)]),
+                tier_blob=tier_blob.raw, tier_end=tier_end)
+        return self._labels
+
+    def words(self, index):
+        """`Word` objects (with their `Phoneme`s) of file `index`."""
+        labels = self.labels()
+
+        def texts(blob, ends, lo, hi):
+            edges = np.concatenate([[ends[lo - 1] if lo else 0], ends[lo:hi]])
+            return [blob[a:b].decode('utf-8')
+                    for a, b in zip(edges[:-1], edges[1:])]
+        lo, hi = self.word_first[index], self.word_first[index + 1]
+        has_phones = self.sizes[index, 2] >= 0
+        words = [alignment_module.Word(name, a, b, [] if has_phones else None)
+                 for name, (a, b) in zip(
+                     texts(labels['word_blob'], labels['word_end'], lo, hi),
+                     self.times[lo:hi])]
+        if has_phones:
+            plo = labels['phone_first'][index]
+            phi = labels['phone_first'][index + 1]
+            names = texts(labels['phone_blob'], labels['phone_end'], plo, phi)
+            for name, (a, b), word in zip(
+                    names, labels['phone_times'][plo:phi],
+                    labels['phone_word'][plo:phi]):
+                words[word].phonemes.append(
+                    alignment_module.Phoneme(name, a, b))
+        return words
+
+    def tiers(self, index):
+        labels = self.labels()
+        begin = labels['tier_end'][index - 1] if index else 0
+        word_tier, phone_tier = labels['tier_blob'][
+            begin:labels['tier_end'][index]].decode('utf-8').split('\n')
+        return (word_tier, phone_tier, bool(self.sizes[index, 11]))
+
+    def alignment(self, index):
+        """`Alignment` of file `index` (its `Word`s are built on demand); a
+        file the library could not parse goes through `alignment.Alignment`,
+        which raises what it always raised."""
+        if self.status[index] & 1:
+            return alignment_module.Alignment(self.text_files[index])
+        lo, hi = self.word_first[index], self.word_first[index + 1]
+        return alignment_module.Alignment.lazy(
+            self.times[lo:hi], lambda: (self.words(index), self.tiers(index)))
+
+    ###########################################################################
+    # Audio
+    ###########################################################################
+
+    def audio(self, index):
+        """`(samples, rate)`: a `FileAudio` for mono 16-bit PCM / float32
+        files, else what `load.wav(file, raw=True)` returns."""
+        if self.status[index] & 2:
+            return load.wav(self.audio_files[index], raw=True)   # raises
+        _, _, _, _, _, code, channels, rate, bits, _, nbytes, _ = \
+            self.sizes[index]
+        if channels == 1 and (code, bits) in ((1, 16), (3, 32)):
+            dtype = torch.int16 if code == 1 else torch.float32
+            return FileAudio(self, index, nbytes // (bits // 8), dtype,
+                             rate), int(rate)
+        return load.wav(self.audio_files[index], raw=True)
+
+    def read(self, indices, where, nbytes, destination):
+        """Samples of files `indices` to host address `destination +
+        where[k]` (the pinned staging buffer)."""
+        which = np.asarray(indices, dtype=np.int32)
+        where = np.asarray(where, dtype=np.int64)
+        nbytes = np.asarray(nbytes, dtype=np.int64)
+        runtime.check(self._lib.emph_files_read_audio(
+            self._handle, which.ctypes.data, where.ctypes.data,
+            nbytes.ctypes.data, len(which), destination, self.threads),
+            'emph_files_read_audio')
+
+    ###########################################################################
+    # Outputs
+    ###########################################################################
+
+    def write(self, indices, prefixes, scores):
+        """`<prefix>.TextGrid` + `<prefix>.pt` for files `indices`
+        (`core.py:111-112`); scores: list of float32 CPU tensors [1, W]."""
+        native = [k for k, i in enumerate(indices)
+                  if not self.status[i] & 1]
+        for k, index in enumerate(indices):
+            if self.status[index] & 1:      # (a JSON alignment, say)
+                from . import core
+                core._save(self.alignment(index), scores[k], prefixes[k])
+        if not native:
+            return
+        flat = torch.cat(
+            [scores[k].reshape(-1) for k in native] + [torch.zeros(1)]).to(
+                torch.float32).contiguous()      # (never an empty buffer)
+        first = np.concatenate([[0], np.cumsum(
+            [scores[k].numel() for k in native])]).astype(np.int64)
+        which = np.array([indices[k] for k in native], dtype=np.int32)
+        paths = (ctypes.c_char_p * len(native))(
+            *[str(prefixes[k]).encode() for k in native])
+        runtime.check(self._lib.emph_files_write(
+            self._handle, which.ctypes.data, paths, flat.data_ptr(),
+            first.ctypes.data, len(native), self.threads), 'emph_files_write')

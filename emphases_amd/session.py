@@ -42,6 +42,8 @@ SPLIT_BYTES = int(os.environ.get('EMPHASES_SPLIT_BYTES', 256 << 20))
 def mono(audio):
     """1-D tensor of channel 0 (`mels.py:48` featurises channel 0 only), at
     the caller's sample rate; int16 stays int16."""
+    if not torch.is_tensor(audio):
+        return audio                  # files.FileAudio: mono by construction
     audio = audio[0] if audio.dim() == 2 else audio.reshape(-1)
     if audio.dtype not in (torch.float32, torch.int16):
         audio = audio.to(torch.float32)
@@ -97,6 +99,9 @@ class _Lane:
         device_view = buffer[:max(total, 1) * item].view(dtype)[:total]
         on_host = [i for i, a in enumerate(audios) if not a.is_cuda]
         host_view = self.staging[:max(total, 1) * item].view(dtype)[:total]
+        if any(not torch.is_tensor(audios[i]) for i in on_host):
+            return self._stage_files(
+                audios, lengths, item, offsets, host_view, device_view)
         # The gather runs in the library (`emph_host_gather`: a persistent pool
         # of copy threads; numpy copies from a Python thread pool reach 58 GB/s
         # and torch's CPU copy_ into a slice of a large tensor a tenth of that,
@@ -130,6 +135,56 @@ class _Lane:
                     first = k
         for i, audio in enumerate(audios):
             if audio.is_cuda:
+                device_view[offsets[i]:offsets[i + 1]].copy_(
+                    audio, non_blocking=True)
+        return device_view
+
+
+    def _stage_files(self, audios, lengths, item, offsets, host_view,
+                     device_view):
+        """`stage` for a batch whose audio is still on disk
+        (`files.FileAudio`): the library's threads read the data chunks
+        straight into the pinned staging buffer (`emph_files_read_audio`), a
+        few pieces at a time, each sent to the device as soon as it is read;
+        tensors among them take the copy path."""
+        from . import runtime
+        count = len(audios)
+        base = host_view.data_ptr()
+        pieces = max(1, min(4, count, int(offsets[-1]) * item // (8 << 20)))
+        edges = np.linspace(0, count, pieces + 1).astype(int)
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            if hi == lo:
+                continue
+            by_batch = {}
+            tensors = []
+            for i in range(lo, hi):
+                audio = audios[i]
+                if torch.is_tensor(audio):
+                    if not audio.is_cuda:
+                        tensors.append(i)
+                    continue
+                by_batch.setdefault(id(audio.batch), (audio.batch, []))[1] \
+                    .append(i)
+            for batch_files, members in by_batch.values():
+                batch_files.read(
+                    [audios[i].index for i in members],
+                    [int(offsets[i]) * item for i in members],
+                    [lengths[i] * item for i in members], base)
+            if tensors:
+                sources = [audios[i].contiguous() for i in tensors]
+                runtime.check(runtime.library().emph_host_gather(
+                    np.array([a.data_ptr() for a in sources],
+                             dtype=np.int64).ctypes.data,
+                    np.array([lengths[i] * item for i in tensors],
+                             dtype=np.int64).ctypes.data,
+                    np.array([int(offsets[i]) * item for i in tensors],
+                             dtype=np.int64).ctypes.data,
+                    len(tensors), base, COPY_THREADS), 'emph_host_gather')
+            start, stop = int(offsets[lo]), int(offsets[hi])
+            device_view[start:stop].copy_(
+                host_view[start:stop], non_blocking=True)
+        for i, audio in enumerate(audios):
+            if torch.is_tensor(audio) and audio.is_cuda:
                 device_view[offsets[i]:offsets[i + 1]].copy_(
                     audio, non_blocking=True)
         return device_view
@@ -332,6 +387,10 @@ class Session:
         if not pcm:
             # int16 is 16-bit PCM wherever it appears (x / 32768, exact): a
             # mixed batch gives every utterance the bits of its own call
+            # (a 16-bit file among float32 ones is read on the host for that)
+            audios = [audio if torch.is_tensor(audio) or
+                      audio.dtype != torch.int16 else audio.tensor()
+                      for audio in audios]
             audios = [audio.to(torch.float32) / 32768.
                       if audio.dtype == torch.int16 else audio
                       for audio in audios]
@@ -380,6 +439,9 @@ class Session:
             if engine.config.pitch_feature or \
                     engine.config.periodicity_feature:
                 from . import core
+                # (the tracker wants the samples on the host)
+                audios = [audio if torch.is_tensor(audio) else audio.tensor()
+                          for audio in audios]
                 # (the tracker runs on the host and wants 16 kHz audio)
                 heard = audios
                 if resampling:

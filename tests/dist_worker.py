@@ -63,6 +63,9 @@ def files_main(backend, directory, count, out):
     from emphases_amd import dist as edist, load
     torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     try:
+        # which audio files this process reads the SAMPLES of: through the
+        # library's batched reader (files.FileBatch.read) or load.wav
+        from emphases_amd import files
         read = []
         original = load.wav
 
@@ -70,6 +73,12 @@ def files_main(backend, directory, count, out):
             read.append(os.path.basename(str(file)))
             return original(file, raw)
         load.wav = tracking_wav
+        original_read = files.FileBatch.read
+
+        def tracking_read(self, indices, where, nbytes, destination):
+            read.extend(os.path.basename(self.audio_files[i]) for i in indices)
+            return original_read(self, indices, where, nbytes, destination)
+        files.FileBatch.read = tracking_read
         texts, audios, prefixes = file_lists(directory, count, f'w{world}')
         scores = edist.from_files_to_files(texts, audios, prefixes)
         torch.save({'scores': [s.cpu() for s in scores], 'read': sorted(read)},

@@ -3,6 +3,7 @@ and the C-ABI library's exported surface.  No kernel is launched here."""
 import hashlib
 import os
 import re
+import struct
 
 import numpy as np
 import pytest
@@ -779,3 +780,191 @@ def test_host_gather_and_fork():
     _, status = os.waitpid(pid, 0)
     assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
     assert gather(5)
+
+
+###############################################################################
+# The batched file boundary (csrc/files.hip) against alignment.py / load.py
+###############################################################################
+
+
+def _grid_variants(tmp_path):
+    """TextGrid files in every form the readers accept -> list of paths."""
+    long_two = '\n'.join([
+        'File type = "ooTextFile"', 'Object class = "TextGrid"', '',
+        'xmin = 0', 'xmax = 1.0', 'tiers? <exists>', 'size = 2', 'item []:',
+        '    item [1]:', '        class = "IntervalTier"',
+        '        name = "phones"', '        xmin = 0', '        xmax = 1.0',
+        '        intervals: size = 3',
+        '        intervals [1]:', '            xmin = 0',
+        '            xmax = 0.3', '            text = "HH"',
+        '        intervals [2]:', '            xmin = 0.3',
+        '            xmax = 0.5', '            text = "AY"',
+        '        intervals [3]:', '            xmin = 0.5',
+        '            xmax = 1.0', '            text = "sp"',
+        '    item [2]:', '        class = "IntervalTier"',
+        '        name = "words"', '        xmin = 0', '        xmax = 1.0',
+        '        intervals: size = 2',
+        '        intervals [1]:', '            xmin = 0',
+        '            xmax = 0.5', '            text = "hi"',
+        '        intervals [2]:', '            xmin = 0.5',
+        '            xmax = 1.0', '            text = ""', ''])
+    short = '\n'.join([
+        'File type = "ooTextFile"', 'Object class = "TextGrid"', '',
+        '0', '1.0', '<exists>', '2',
+        '"IntervalTier"', '"phones"', '0', '1.0', '3',
+        '0', '0.3', '"HH"', '0.3', '0.5', '"AY"', '0.5', '1.0', '"sp"',
+        '"IntervalTier"', '"words"', '0', '1.0', '2',
+        '0', '0.5', '"hi"', '0.5', '1.0', '""', ''])
+    odd = '\n'.join([
+        'File type = "ooTextFile"', 'Object class = "TextGrid"', '',
+        'xmin = 0', 'xmax = 2.5e0', 'tiers? <exists>', 'size = 2', 'item []:',
+        '    item [1]:', '        class = "TextTier"',
+        '        name = "marks"', '        xmin = 0', '        xmax = 2.5',
+        '        points: size = 1', '        points [1]:',
+        '            number = 1.25', '            mark = "x = 3"',
+        '    item [2]:', '        class = "IntervalTier"',
+        '        name = "word"', '        xmin = 0', '        xmax = 2.5',
+        '        intervals: size = 3',
+        '        intervals [1]:', '            xmin = 0.00001',
+        '            xmax = 5e-1', '            text = "say ""2.5"" = x"',
+        '        intervals [2]:', '            xmin = 0.75',
+        '            xmax = 1.7500000000000002',
+        '            text = "naïve café"',
+        '        intervals [3]:', '            xmin = 1.7500000000000002',
+        '            xmax = 2.5', '            text = "42"', ''])
+    # words and a finer unnamed tier, in that order; a gap between two words
+    gaps = '\n'.join([
+        'File type = "ooTextFile"', 'Object class = "TextGrid"', '',
+        '0', '3', '<exists>', '2',
+        '"IntervalTier"', '"utterance"', '0', '3', '2',
+        '0.25', '1', '"a b"', '1.5', '3', '"c"',
+        '"IntervalTier"', '"segments"', '0', '3', '4',
+        '0.25', '0.5', '"a"', '0.5', '1', '"b"', '1.5', '2', '"c1"',
+        '2', '3', '"c2"', ''])
+    variants = {
+        'long': long_two.encode(), 'short': short.encode(),
+        'short_bom': b'\xef\xbb\xbf' + short.encode(),
+        'long16': long_two.encode('utf-16'),
+        'long16be': long_two.encode('utf-16-be'),
+        'short16le': short.encode('utf-16-le'),
+        'odd': odd.encode('utf-8'), 'odd16': odd.encode('utf-16'),
+        'gaps': gaps.encode()}
+    paths = []
+    for name, data in variants.items():
+        path = tmp_path / f'{name}.TextGrid'
+        path.write_bytes(data)
+        paths.append(path)
+    words = emphases_amd.Alignment.from_frames(
+        synth.word_frames(3, 700), synth.word_names(
+            synth.word_frames(3, 700).shape[1]))
+    words.save(tmp_path / 'synthetic.TextGrid')
+    paths.append(tmp_path / 'synthetic.TextGrid')
+    return paths
+
+
+def test_file_batch_matches_the_python_readers(tmp_path):
+    """csrc/files.hip (the batched file boundary of from_files_to_files)
+    against alignment.py and load.py, file by file: word and phoneme labels
+    and times, tier names and order, gap filling; WAVE headers over odd chunk
+    lists; the samples it reads; and the files it writes - the TextGrid byte
+    for byte what `Alignment.save` writes, the .pt what `torch.save` would
+    hold (`torch.load` gives the same float32 tensor)."""
+    from emphases_amd import files
+    grids = _grid_variants(tmp_path)
+    waves = []
+    for index, grid in enumerate(grids):
+        wave = tmp_path / f'{grid.stem}.wav'
+        samples = 400 + 37 * index
+        audio = synth.weights(50 + index, (1, samples), 0.5)
+        if index % 3 == 2:
+            # float32 body, a LIST chunk (odd size) in front of it
+            body = audio.astype('<f4').tobytes()
+            fmt = struct.pack('<HHIIHH', 3, 1, 22050, 22050 * 4, 4, 32)
+            extra = b'LIST' + struct.pack('<I', 5) + b'abcde' + b'\0'
+            chunks = b'fmt ' + struct.pack('<I', 16) + fmt + extra + \
+                b'data' + struct.pack('<I', len(body)) + body
+            wave.write_bytes(b'RIFF' + struct.pack('<I', 4 + len(chunks)) +
+                             b'WAVE' + chunks)
+        else:
+            load.save_wav(wave, audio, 16000 if index % 3 == 0 else 8000)
+        waves.append(wave)
+    opened = files.FileBatch(grids, waves, threads=4)
+    assert not opened.status.any(), [opened.error(i) for i in range(len(grids))]
+    total = 0
+    for index, (grid, wave) in enumerate(zip(grids, waves)):
+        want = emphases_amd.Alignment(grid)
+        got = opened.alignment(index)
+        assert len(got) == len(want), grid.name
+        assert np.array_equal(got.times(), want.times()), grid.name
+        assert got.word_bounds(16000, 160, silences=True) == \
+            want.word_bounds(16000, 160, silences=True)
+        assert [str(w) for w in got] == [str(w) for w in want], grid.name
+        assert got.tiers == want.tiers, grid.name
+        assert got.phonemes() == want.phonemes(), grid.name
+        assert [len(w.phonemes or []) for w in got] == \
+            [len(w.phonemes or []) for w in want], grid.name
+        # audio: headers and samples
+        samples, rate = load.wav(wave, raw=True)
+        audio, got_rate = opened.audio(index)
+        assert got_rate == rate and isinstance(audio, files.FileAudio)
+        assert audio.shape == (samples.shape[1],) and \
+            audio.dtype == samples.dtype
+        buffer = np.zeros(samples.shape[1] + 8, dtype=samples.numpy().dtype)
+        opened.read([index], [16], [samples.shape[1] * buffer.itemsize],
+                    buffer.ctypes.data)
+        assert np.array_equal(buffer[16 // buffer.itemsize:][
+            :samples.shape[1]], samples[0].numpy()[
+                :len(buffer) - 16 // buffer.itemsize])
+        total += len(want)
+    assert total == len(opened.times)
+    # outputs
+    scores = [torch.from_numpy(synth.weights(
+        90 + i, (1, len(opened.alignment(i))), 1.)) for i in range(len(grids))]
+    scores[1] = torch.zeros(1, len(opened.alignment(1)))
+    prefixes = [tmp_path / f'out_{grid.stem}' for grid in grids]
+    opened.write(list(range(len(grids))), prefixes, scores)
+    for grid, prefix, item in zip(grids, prefixes, scores):
+        loaded = torch.load(f'{prefix}.pt')
+        assert loaded.dtype == torch.float32 and torch.equal(loaded, item)
+        emphases_amd.Alignment(grid).save(tmp_path / 'python.TextGrid')
+        assert open(f'{prefix}.TextGrid', 'rb').read() == \
+            (tmp_path / 'python.TextGrid').read_bytes(), grid.name
+    # a long score vector (pickle integer widths), an empty one
+    for count in (0, 255, 256, 70000):
+        item = torch.arange(count, dtype=torch.float32)[None] / 7
+        opened.write([0], [tmp_path / f'n{count}'], [item])
+        assert torch.equal(torch.load(tmp_path / f'n{count}.pt'), item)
+
+
+def test_file_batch_reports_bad_files_like_the_python_readers(tmp_path):
+    """A file the library cannot take is a per-file status, and asking for it
+    raises what alignment.py / load.py raise."""
+    from emphases_amd import files
+    good = _grid_variants(tmp_path)[0]
+    load.save_wav(tmp_path / 'good.wav', synth.weights(1, (1, 300), .3))
+    (tmp_path / 'bad.TextGrid').write_text('hello')
+    (tmp_path / 'cut.TextGrid').write_bytes(good.read_bytes()[:300])
+    (tmp_path / 'bad.wav').write_bytes(b'RIFX' + bytes(40))
+    words = emphases_amd.Alignment(good)
+    words.save(tmp_path / 'words.json')
+    stereo = synth.weights(2, (2, 200), .3)
+    load.save_wav(tmp_path / 'stereo.wav', stereo)
+    texts = [good, tmp_path / 'bad.TextGrid', tmp_path / 'cut.TextGrid',
+             tmp_path / 'missing.TextGrid', tmp_path / 'words.json', good]
+    waves = [tmp_path / 'good.wav', tmp_path / 'good.wav',
+             tmp_path / 'good.wav', tmp_path / 'good.wav',
+             tmp_path / 'stereo.wav', tmp_path / 'bad.wav']
+    opened = files.FileBatch(texts, waves)
+    assert opened.status.tolist() == [0, 1, 1, 1, 1, 2]
+    assert 'TextGrid' in opened.error(1) and opened.error(0) == ''
+    for index in (1, 2):
+        with pytest.raises(ValueError):
+            opened.alignment(index)
+    with pytest.raises(OSError):
+        opened.alignment(3)
+    # JSON alignments and multi-channel audio take the Python readers
+    assert [str(w) for w in opened.alignment(4)] == [str(w) for w in words]
+    audio, rate = opened.audio(4)
+    assert torch.is_tensor(audio) and audio.shape == (2, 200)
+    with pytest.raises(ValueError):
+        opened.audio(5)
