@@ -67,6 +67,7 @@ PROFILE_TAGS = ('r4', 'r3', 'r2', 'r1')
 # kernel name in `Engine.timers` -> substring of the rocprofv3 kernel name
 ROCPROF_NAMES = {
     'conv1d_winograd4_frames_80x80_k3': 'conv1d_winograd4_kernel',
+    'conv1d_stack_frames_80x80_k3': 'conv1d_stack_kernel',
     'attention_frames': 'attention_group_kernel',
     'frontend_logmel': 'frontend_kernel',
     'segment_reduce': 'segment_reduce_kernel',
@@ -548,7 +549,10 @@ def roofline(kernels, passes, ms_per_step, config):
     launches, seconds, flops = kernels[dominant]
     achieved = flops / seconds / 1e12
     committed = from_profiles(config, dominant)
-    executed = .5 if 'winograd4' in dominant else \
+    # Winograd F(4,3) executes half the direct form's MFMAs (the fused stack
+    # recomputes one quad of halo per side: 256 computed per 250 owned)
+    executed = .5 * 256 / 250 if 'stack' in dominant else \
+        .5 if 'winograd4' in dominant else \
         2. / 3. if 'winograd' in dominant else 1.
     result = {
         'bound': 'mfma', 'kernel': dominant,

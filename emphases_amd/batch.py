@@ -335,25 +335,68 @@ class Plan:
                 self._tiles[key] = _tiles(self.words, self.word_off, block)
         return self._tiles[key]
 
-    def word_sum_tables(self, tile=64):
-        """Tables of the fused per-word sum (`emph_conv1d_winograd4_word_sums`
-        + `emph_word_sums`; `emphases/core.py:438-454`): the last frame-rate
-        layer keeps, per `tile`-frame tile of a segment, the running sum of
-        its frames and stores it only at the frames a word needs -
+    def conv_spans(self):
+        """int32 [n, 8] table of `emph_conv1d_stack` (`emph_conv_stack_spans`):
+        every segment cut into the fewest spans one workgroup can own through
+        several fused conv layers."""
+        cached = self._tiles.get('conv_spans')
+        if cached is None:
+            lib = runtime.library()
+            frames = np.ascontiguousarray(self.frames, dtype=np.int64)
+            offsets = np.ascontiguousarray(self.frame_off, dtype=np.int64)
+            count = lib.emph_conv_stack_spans(
+                frames.ctypes.data, offsets.ctypes.data, len(frames), None)
+            cached = np.zeros((count, 8), dtype=np.int32)
+            lib.emph_conv_stack_spans(
+                frames.ctypes.data, offsets.ctypes.data, len(frames),
+                cached.ctypes.data)
+            self._tiles['conv_spans'] = cached
+        return cached
 
-            word [s, e) (clamped to its chunk like a Python slice) meets tile
-            k in [a, b) = [max(s, k tile), min(e, (k + 1) tile)):
+    def sum_restarts(self, spans=None, tile=64):
+        """Packed frame columns at which the running sum of the last
+        frame-rate layer restarts: every `tile` frames from a segment's start
+        (`emph_conv1d_winograd4_word_sums`), or - `spans` - at a span's first
+        own position and every 64 COMPUTED positions inside it
+        (`emph_conv1d_stack`)."""
+        if spans is None:
+            tiles = -(-self.frames // tile)
+            segment = np.repeat(np.arange(len(self.frames)), tiles)
+            local = np.arange(int(tiles.sum())) - np.repeat(
+                np.cumsum(tiles) - tiles, tiles)
+            return self.frame_off[segment] + local * tile
+        first, column = spans[:, 1].astype(np.int64), spans[:, 2].astype(np.int64)
+        owned, computed = spans[:, 4].astype(np.int64), spans[:, 5].astype(np.int64)
+        starts = np.maximum(
+            first[:, None], computed[:, None] + 64 * np.arange(4)[None])
+        keep = starts < (first + owned)[:, None]
+        keep[:, 1:] &= starts[:, 1:] > starts[:, :-1]
+        return np.unique((column[:, None] + starts)[keep])
+
+    def word_sum_tables(self, restarts=None):
+        """Tables of the fused per-word sum (`emph_conv1d_winograd4_word_sums`
+        or `emph_conv1d_stack`, + `emph_word_sums`; `emphases/core.py:438-454`):
+        the last frame-rate layer keeps a running sum of its frames that
+        restarts at the columns `restarts` (`sum_restarts()`; default: every
+        64 frames of a segment) and stores it only at the frames a word needs -
+
+            word [s, e) (clamped to its chunk like a Python slice) is cut at
+            the restarts inside it into parts [a, b):
                 + running sum at frame b - 1
-                - running sum at frame a - 1     (if a is not the tile's first)
+                - running sum at frame a - 1     (if a is not itself a restart)
 
         Returns a dict of int32 arrays: `slot_map` [ld_frames] (packed frame
         column -> row of the sums buffer, -1), `terms` (signed rows: r adds,
-        ~r subtracts; a word's terms tile by tile, plus before minus),
+        ~r subtracts; a word's terms part by part, plus before minus),
         `first` [ld_words + 1] (CSR over packed word columns), `lengths`
         [ld_words] (e - s; -1 on alignment padding columns), and `n_slots`."""
-        cached = self._tiles.get(('word_sums', tile))
+        key = ('word_sums', None if restarts is None else restarts.tobytes())
+        cached = self._tiles.get(key)
         if cached is not None:
             return cached
+        if restarts is None:
+            restarts = self.sum_restarts()
+        restarts = np.asarray(restarts, dtype=np.int64)
         count = len(self.frames)
         total = self.total_words
         segment = np.repeat(np.arange(count, dtype=np.int64), self.words)
@@ -361,22 +404,29 @@ class Plan:
         raw = self.segment_bounds.astype(np.int64)
         start = np.clip(raw[0], 0, limit)
         end = np.maximum(np.clip(raw[1], 0, limit), start)
-        first_tile = start // tile
-        parts = np.where(end > start, (end - 1) // tile - first_tile + 1, 0)
+        column = self.frame_off[segment] if total else start
+        begin, stop = column + start, column + end
+        # the restarts strictly inside (begin, stop) cut the word
+        inner_lo = np.searchsorted(restarts, begin, side='right')
+        inner_hi = np.searchsorted(restarts, stop, side='left')
+        parts = np.where(end > start, inner_hi - inner_lo + 1, 0)
         word = np.repeat(np.arange(total, dtype=np.int64), parts)
         part_first = np.cumsum(parts) - parts
-        k = first_tile[word] + np.arange(int(parts.sum()), dtype=np.int64) - \
-            part_first[word]
-        a = np.maximum(start[word], k * tile)
-        b = np.minimum(end[word], (k + 1) * tile)
-        column = self.frame_off[segment[word]] if total else a
-        plus = column + b - 1
-        has_minus = a > k * tile
-        minus = column + a - 1
+        k = np.arange(int(parts.sum()), dtype=np.int64) - part_first[word]
+        cut = inner_lo[word] + k                    # index of the part's END restart
+        a = np.where(k == 0, begin[word],
+                     restarts[np.clip(cut - 1, 0, max(len(restarts) - 1, 0))])
+        b = np.where(k == parts[word] - 1, stop[word],
+                     restarts[np.clip(cut, 0, max(len(restarts) - 1, 0))])
+        at = np.searchsorted(restarts, a, side='left')
+        is_restart = (at < len(restarts)) & (
+            restarts[np.clip(at, 0, max(len(restarts) - 1, 0))] == a)
+        plus = b - 1
+        has_minus = ~is_restart
+        minus = a - 1
         marked = np.unique(np.concatenate([plus, minus[has_minus]]))
         slot_map = np.full(self.ld_frames, -1, dtype=np.int32)
         slot_map[marked] = np.arange(len(marked), dtype=np.int32)
-        # terms of a part: (+, -) or (+); of a word: its parts in tile order
         per_part = 1 + has_minus.astype(np.int64)
         where = np.cumsum(per_part) - per_part
         terms = np.zeros(int(per_part.sum()), dtype=np.int32)
@@ -393,7 +443,7 @@ class Plan:
             'slot_map': slot_map, 'terms': terms,
             'first': np.cumsum(per_column).astype(np.int32),
             'lengths': lengths, 'n_slots': int(len(marked))}
-        self._tiles[('word_sums', tile)] = tables
+        self._tiles[key] = tables
         return tables
 
     def pieces(self, method):
@@ -409,16 +459,20 @@ class Plan:
         """Packed word-axis column of every word, in segment order."""
         return self._columns
 
-    def pack_metadata(self, tile_requests, word_sums=False):
+    def pack_metadata(self, tile_requests, word_sums=False, spans=False):
         """All integer metadata as one int32 array plus the element offset of
         every piece (the int64 table first, so it stays 8-byte aligned;
         every piece starts on a 16-byte boundary).  `word_sums`: with the
-        tables of `word_sum_tables()`."""
+        tables of `word_sum_tables()`; `spans`: with the span table of
+        `emph_conv1d_stack`, whose restarts the word sums then follow."""
         pieces = [('table', self.table.view(np.int32).ravel()),
                   ('bounds', self.bounds.ravel()),
                   ('word_segment', self.word_segment)]
+        if spans:
+            pieces.append(('conv_spans', self.conv_spans().ravel()))
         if word_sums:
-            tables = self.word_sum_tables()
+            tables = self.word_sum_tables(
+                self.sum_restarts(self.conv_spans()) if spans else None)
             pieces += [(('word_sums', name), tables[name])
                        for name in ('slot_map', 'terms', 'first', 'lengths')]
         for request in tile_requests:

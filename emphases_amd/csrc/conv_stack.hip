@@ -1,0 +1,463 @@
+// Up to FOUR consecutive Conv1d(80, 80, 3, 'same') + activation layers of the
+// frame encoder (emphases/model/core.py:24-31,96-100 over
+// model/layers/convolution.py:25-37) in ONE launch, Winograd F(4,3) on
+// v_mfma_f32_16x16x4_f32 like conv_w4.hip - the same arithmetic per output, so the
+// results are bit for bit those of the layer-by-layer kernel - but with the
+// activations resident in LDS from layer to layer and the weights streamed
+// through a two-slot LDS ring by loader waves.
+//
+// Why: a layer-by-layer launch spends 9.3 us of its 18.6 us in the matrix pipe; the
+// rest is launch ramp, the 153.6 KB pack transfer that nothing can run under
+// (the pack fills the LDS), and the store burst of 20.5 MB per layer
+// (DESIGN.md section 6).  Here a workgroup owns a SPAN of up to 252 consecutive
+// positions of one segment for all the layers of the launch:
+//
+//   * 256 computed positions = 4 MFMA column tiles of 16 quads = the span plus a
+//     halo of one quad on each side that continues inside the segment (a layer
+//     needs one position from each neighbour; four layers, four positions).  The
+//     halo is recomputed, 2.4 % more matrix work, instead of exchanged: a
+//     cross-workgroup hand-off per layer costs more than the layer's ramp
+//     (MI355X_MICROARCH.md, inter-workgroup visibility);
+//   * activations [80][260] floats (83.2 KB) are updated in place: accumulators
+//     live in registers, a barrier separates the last read of a layer from the
+//     first write of its output.  Index i of a row is position c0 - 1 + i, so the
+//     six inputs x[4q-1 .. 4q+4] of a quad are one aligned 16-byte and one 8-byte
+//     LDS read; positions outside the segment hold zeros ('same' padding by
+//     construction: no masks in the K loop);
+//   * weights: the layer's pack is k-major, so it streams in chunks of four
+//     k-steps (30.7 KB) through ring[2]; four loader waves request chunk g + 1 by
+//     LDS-DMA while the eight MFMA waves consume chunk g (one wave's LDS-DMA
+//     requests complete one after the other: four waves are what keeps a chunk
+//     ahead).  One barrier per chunk, one more per layer.
+//
+// The last layer of the launch writes the span to global memory, or - WORD_SUMS,
+// when it is the layer in front of the per-word sum (emphases/core.py:438-454) -
+// only the running sums the words need, exactly like
+// conv1d_winograd4_kernel<..., WORD_SUMS> (conv_w4.hip), over the span's own
+// positions.
+#include <type_traits>
+
+#include "common.h"
+
+namespace emph {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kStackChannels = 80;
+constexpr int kStackMTiles = 5;
+constexpr int kStackSteps = kStackChannels / 4;           // k-steps per layer
+constexpr int kStackChunkSteps = 4;
+constexpr int kStackChunks = kStackSteps / kStackChunkSteps;
+constexpr int kStackStepFloats = 6 * kStackMTiles * 64;   // one k-step of the pack
+constexpr int kStackChunkFloats = kStackChunkSteps * kStackStepFloats;
+constexpr int kStackWidth = 256;                          // computed positions
+constexpr int kStackStride = 260;                         // floats per activation row
+constexpr int kStackThreads = 768;                        // 8 MFMA waves + 4 loader waves
+constexpr int kStackMaxLayers = 4;
+constexpr int kSpanFields = 8;
+
+__host__ __device__ constexpr int stack_lds_floats() {
+    return kStackChannels * kStackStride + 2 * kStackChunkFloats +
+           kStackMaxLayers * kStackChannels;
+}
+
+// spans: int32 [n][8] = {segment, first owned position, frame column of the
+// segment, positions of the segment, owned positions, first computed position,
+// 0, 0}
+template <bool WORD_SUMS>
+__global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
+    const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+    const float* __restrict__ packs, const float* __restrict__ biases, int layers,
+    int relu_mask, const int32_t* __restrict__ spans, const int32_t* __restrict__ slot_map) {
+    extern __shared__ __align__(16) float lds[];
+    float* act = lds;
+    float* ring = act + kStackChannels * kStackStride;
+    float* bias_lds = ring + 2 * kStackChunkFloats;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool loader = wave >= 8;
+
+    const int4 span_a = reinterpret_cast<const int4*>(spans)[2 * blockIdx.x];
+    const int4 span_b = reinterpret_cast<const int4*>(spans)[2 * blockIdx.x + 1];
+    const int owned_first = span_a.y;
+    const int64_t column = span_a.z;          // frame column of the segment's position 0
+    const int count = span_a.w;               // positions of the segment
+    const int owned = span_b.x;
+    const int c0 = span_b.y;                  // first computed position (a multiple of 4)
+
+    constexpr int kPackFloats = kStackSteps * kStackStepFloats;
+    const int total_chunks = layers * kStackChunks;
+    auto request = [&](int g) {               // loader waves: chunk g -> ring[g & 1]
+        const int layer = g / kStackChunks;
+        const float* source = packs + static_cast<int64_t>(layer) * kPackFloats +
+                              (g - layer * kStackChunks) * kStackChunkFloats;
+        float* target = ring + (g & 1) * kStackChunkFloats;
+        // 1920 16-byte quads per chunk: 30 wave requests, dealt over the four loaders
+        for (int base = (wave - 8) * 64; base < kStackChunkFloats / 4; base += 4 * 64)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(source + 4 * (base + lane)),
+                (__attribute__((address_space(3))) void*)(target + 4 * base), 16, 0, 0);
+    };
+    if (loader) request(0);
+
+    // ---- the layer-0 input of the computed positions, zeros outside the segment
+    for (int index = threadIdx.x; index < layers * kStackChannels; index += kStackThreads)
+        bias_lds[index] = biases[index];
+    for (int index = threadIdx.x; index < kStackChannels * 65; index += kStackThreads) {
+        const int c = index / 65;
+        const int q = index - c * 65;
+        const float* row = x + static_cast<int64_t>(c) * ldx + column;
+        float* target = act + c * kStackStride;
+        if (q < 64) {
+            const int p = c0 + 4 * q;
+            float4 value = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p + 3 < count) {
+                value = *reinterpret_cast<const float4*>(row + p);
+            } else {
+                if (p < count) value.x = row[p];
+                if (p + 1 < count) value.y = row[p + 1];
+                if (p + 2 < count) value.z = row[p + 2];
+            }
+            target[4 * q + 1] = value.x;
+            *reinterpret_cast<f32x2*>(target + 4 * q + 2) = f32x2{value.y, value.z};
+            target[4 * q + 4] = value.w;
+        } else {
+            const int before = c0 - 1, after = c0 + kStackWidth;
+            target[0] = (before >= 0 && before < count) ? row[before] : 0.f;
+            target[kStackWidth + 1] = after < count ? row[after] : 0.f;
+            target[kStackWidth + 2] = after + 1 < count ? row[after + 1] : 0.f;
+            target[kStackWidth + 3] = 0.f;
+        }
+    }
+
+    if (loader) {
+        // chunk g has landed -> barrier (everyone is also done with chunk g - 1,
+        // whose slot chunk g + 1 overwrites) -> request chunk g + 1; plus the one
+        // barrier per layer between the last read and the first write of the
+        // activations
+        for (int g = 0; g < total_chunks; ++g) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+            __syncthreads();
+            if (g + 1 < total_chunks) request(g + 1);
+            // (the MFMA waves' barrier in front of a layer's in-place update: every
+            // layer but the launch's last)
+            if ((g + 1) % kStackChunks == 0 && g + 1 < total_chunks) __syncthreads();
+        }
+        return;
+    }
+
+    // ---- MFMA waves: column tile `tile` of 16 quads, m-tiles split 3 + 2 between
+    // the two waves of a SIMD (conv_w4.hip)
+    const int kk = lane >> 4;
+    const int col = lane & 15;
+    const int tile = wave & 3;
+    const int part = wave >> 2;
+    constexpr int split = (kStackMTiles + 1) >> 1;
+    const int m_begin = part ? split : 0;
+    // the lane's quad: LDS index of x[4q - 1] in row kk
+    const float* lane_rows = act + kk * kStackStride + 64 * tile + 4 * col;
+    const int p_quad = c0 + 64 * tile + 4 * col;            // position of the quad's first output
+
+    auto run = [&](auto count_tag) {
+        constexpr int COUNT = decltype(count_tag)::value;
+        for (int layer = 0; layer < layers; ++layer) {
+            f32x4 acc[6][COUNT];
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int m = 0; m < COUNT; ++m) acc[j][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            float a[6][COUNT], d[6], v[6];
+            auto load_b = [&](int step) {
+                const float* source = lane_rows + 4 * step * kStackStride;
+                const f32x4 first = *reinterpret_cast<const f32x4*>(source);
+                const f32x2 second = *reinterpret_cast<const f32x2*>(source + 4);
+                d[0] = first[0], d[1] = first[1], d[2] = first[2], d[3] = first[3];
+                d[4] = second[0], d[5] = second[1];
+            };
+            for (int chunk = 0; chunk < kStackChunks; ++chunk) {
+                // the chunk has landed (and, chunk 0: every wave has written its
+                // part of this layer's input)
+                __syncthreads();
+                if (chunk == 0) load_b(0);
+                const float* weights =
+                    ring + ((layer * kStackChunks + chunk) & 1) * kStackChunkFloats +
+                    (m_begin << 6) + lane;
+#pragma unroll
+                for (int ks = 0; ks < kStackChunkSteps; ++ks) {
+                    const int step = chunk * kStackChunkSteps + ks;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j)
+#pragma unroll
+                        for (int m = 0; m < COUNT; ++m)
+                            a[j][m] = weights[(ks * 6 * kStackMTiles + j * kStackMTiles + m) << 6];
+                    // v = B^T d (conv_w4.hip: the same operations in the same order)
+                    const float p = fmaf(-4.f, d[2], d[4]);
+                    const float q = fmaf(-4.f, d[1], d[3]);
+                    const float c = d[4] - d[2];
+                    const float e = 2.f * (d[3] - d[1]);
+                    v[0] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
+                    v[1] = p + q;
+                    v[2] = p - q;
+                    v[3] = c + e;
+                    v[4] = c - e;
+                    v[5] = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+                    if (step + 1 < kStackSteps) load_b(step + 1);
+#pragma unroll
+                    for (int j = 0; j < 6; ++j)
+#pragma unroll
+                        for (int m = 0; m < COUNT; ++m)
+                            acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                a[j][m], v[j], acc[j][m], 0, 0, 0);
+                }
+            }
+            // ---- output transform, bias, activation
+            const bool relu = (relu_mask >> layer) & 1;
+            const bool last = layer == layers - 1;
+            const float* bias_row = bias_lds + layer * kStackChannels;
+            if (!last) {
+                // every wave is done reading this layer's input: its output may
+                // take the rows' place (zeros outside the segment: 'same' padding)
+                __syncthreads();
+#pragma unroll
+                for (int m = 0; m < COUNT; ++m) {
+                    const int channel0 = 16 * (m_begin + m) + 4 * kk;
+                    const f32x4 add = *reinterpret_cast<const f32x4*>(bias_row + channel0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m1 = acc[1][m][r], m2 = acc[2][m][r];
+                        const float m3 = acc[3][m][r], m4 = acc[4][m][r];
+                        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                        float o0 = acc[0][m][r] + s12 + s34 + add[r];
+                        float o1 = fmaf(2.f, d34, d12) + add[r];
+                        float o2 = fmaf(4.f, s34, s12) + add[r];
+                        float o3 = fmaf(8.f, d34, d12) + acc[5][m][r] + add[r];
+                        if (relu) {
+                            o0 = o0 < 0.f ? 0.f : o0;
+                            o1 = o1 < 0.f ? 0.f : o1;
+                            o2 = o2 < 0.f ? 0.f : o2;
+                            o3 = o3 < 0.f ? 0.f : o3;
+                        }
+                        o0 = p_quad < count ? o0 : 0.f;
+                        o1 = p_quad + 1 < count ? o1 : 0.f;
+                        o2 = p_quad + 2 < count ? o2 : 0.f;
+                        o3 = p_quad + 3 < count ? o3 : 0.f;
+                        float* target =
+                            act + (channel0 + r) * kStackStride + 64 * tile + 4 * col + 1;
+                        target[0] = o0;
+                        *reinterpret_cast<f32x2*>(target + 1) = f32x2{o1, o2};
+                        target[3] = o3;
+                    }
+                }
+                continue;
+            }
+            // ---- the launch's last layer: the span's own positions leave the chip
+            const int t = p_quad;
+            const int owned_end = owned_first + owned;
+            if (WORD_SUMS) {
+                int4 slots = {-1, -1, -1, -1};
+                if (t < count) slots = *reinterpret_cast<const int4*>(slot_map + column + t);
+#pragma unroll
+                for (int m = 0; m < COUNT; ++m) {
+                    const int channel0 = 16 * (m_begin + m) + 4 * kk;
+                    const f32x4 add = *reinterpret_cast<const f32x4*>(bias_row + channel0);
+                    f32x4 sum[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float m1 = acc[1][m][r], m2 = acc[2][m][r];
+                        const float m3 = acc[3][m][r], m4 = acc[4][m][r];
+                        const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                        float o0 = acc[0][m][r] + s12 + s34 + add[r];
+                        float o1 = fmaf(2.f, d34, d12) + add[r];
+                        float o2 = fmaf(4.f, s34, s12) + add[r];
+                        float o3 = fmaf(8.f, d34, d12) + acc[5][m][r] + add[r];
+                        if (relu) {
+                            o0 = o0 < 0.f ? 0.f : o0;
+                            o1 = o1 < 0.f ? 0.f : o1;
+                            o2 = o2 < 0.f ? 0.f : o2;
+                            o3 = o3 < 0.f ? 0.f : o3;
+                        }
+                        // only the span's own positions count (a halo position
+                        // belongs to the neighbouring span's sums)
+                        o0 = (t >= owned_first && t < owned_end) ? o0 : 0.f;
+                        o1 = (t + 1 >= owned_first && t + 1 < owned_end) ? o1 : 0.f;
+                        o2 = (t + 2 >= owned_first && t + 2 < owned_end) ? o2 : 0.f;
+                        o3 = (t + 3 >= owned_first && t + 3 < owned_end) ? o3 : 0.f;
+                        o1 += o0;
+                        o2 += o1;
+                        o3 += o2;
+                        float scan = o3;
+                        scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, scan), 0x111, 0xf, 0xf, true));
+                        scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, scan), 0x112, 0xf, 0xf, true));
+                        scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, scan), 0x114, 0xf, 0xf, true));
+                        scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, scan), 0x118, 0xf, 0xf, true));
+                        const float before = scan - o3;
+                        sum[0][r] = o0 + before;
+                        sum[1][r] = o1 + before;
+                        sum[2][r] = o2 + before;
+                        sum[3][r] = o3 + before;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int slot = j == 0 ? slots.x : j == 1 ? slots.y : j == 2 ? slots.z : slots.w;
+                        if (slot >= 0 && t + j >= owned_first && t + j < owned_end)
+                            *reinterpret_cast<f32x4*>(y + static_cast<int64_t>(slot) * ldy +
+                                                      channel0) = sum[j];
+                    }
+                }
+                continue;
+            }
+            const bool vector_ok = (ldy & 3) == 0 && (column & 3) == 0 &&
+                                   (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+#pragma unroll
+            for (int m = 0; m < COUNT; ++m) {
+                const int channel0 = 16 * (m_begin + m) + 4 * kk;
+                const f32x4 add = *reinterpret_cast<const f32x4*>(bias_row + channel0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float m1 = acc[1][m][r], m2 = acc[2][m][r];
+                    const float m3 = acc[3][m][r], m4 = acc[4][m][r];
+                    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+                    float4 out;
+                    out.x = acc[0][m][r] + s12 + s34 + add[r];
+                    out.y = fmaf(2.f, d34, d12) + add[r];
+                    out.z = fmaf(4.f, s34, s12) + add[r];
+                    out.w = fmaf(8.f, d34, d12) + acc[5][m][r] + add[r];
+                    if (relu) {
+                        out.x = out.x < 0.f ? 0.f : out.x;
+                        out.y = out.y < 0.f ? 0.f : out.y;
+                        out.z = out.z < 0.f ? 0.f : out.z;
+                        out.w = out.w < 0.f ? 0.f : out.w;
+                    }
+                    float* target = y + static_cast<int64_t>(channel0 + r) * ldy + column + t;
+                    if (vector_ok && t >= owned_first && t + 3 < owned_end) {
+                        *reinterpret_cast<float4*>(target) = out;
+                    } else {
+                        if (t >= owned_first && t < owned_end) target[0] = out.x;
+                        if (t + 1 >= owned_first && t + 1 < owned_end) target[1] = out.y;
+                        if (t + 2 >= owned_first && t + 2 < owned_end) target[2] = out.z;
+                        if (t + 3 >= owned_first && t + 3 < owned_end) target[3] = out.w;
+                    }
+                }
+            }
+        }
+    };
+    if (part == 0) run(std::integral_constant<int, split>{});
+    else run(std::integral_constant<int, kStackMTiles - split>{});
+}
+
+}  // namespace emph
+
+using namespace emph;
+
+extern "C" {
+
+int32_t emph_conv_stack_max_layers(void) { return kStackMaxLayers; }
+
+// Spans of a packed axis for emph_conv1d_stack: every segment of `counts[i]`
+// positions at frame column `offsets[i]` is cut into the fewest spans a
+// workgroup can own - 256 positions for a whole segment, 252 for a span at one
+// end (a halo of 4 recomputed positions on the other side), 248 in between -
+// of even size, quads (4 positions) never split.  host_spans == NULL: returns
+// the number of spans.
+int32_t emph_conv_stack_spans(const int64_t* host_counts, const int64_t* host_offsets,
+                              int32_t n_segments, int32_t* host_spans) {
+    int32_t total = 0;
+    for (int32_t segment = 0; segment < n_segments; ++segment) {
+        const int64_t count = host_counts[segment];
+        if (count <= 0) continue;
+        const int64_t quads = (count + 3) / 4;
+        int64_t pieces = 1;
+        if (quads > 64) {
+            pieces = 2;
+            while (2 * 63 + (pieces - 2) * 62 < quads) ++pieces;
+        }
+        // even shares of the quads; what does not divide goes to the ends first
+        // (they may hold 63 quads), then to the spans in between
+        const int64_t base = quads / pieces;
+        int64_t spare = quads - base * pieces;
+        int64_t extra[3] = {0, 0, 0};         // first, last, in between (count)
+        if (pieces > 1) {
+            if (spare > 0 && base + 1 <= 63) extra[0] = 1, --spare;
+            if (spare > 0 && base + 1 <= 63) extra[1] = 1, --spare;
+            extra[2] = spare;
+        }
+        int64_t done = 0;
+        for (int64_t k = 0; k < pieces; ++k) {
+            int64_t share = base;
+            if (pieces == 1) share = quads;
+            else if (k == 0) share += extra[0];
+            else if (k == pieces - 1) share += extra[1];
+            else if (k <= extra[2]) share += 1;
+            if (k == pieces - 1) share = quads - done;
+            if (host_spans != nullptr) {
+                int32_t* row = host_spans + static_cast<int64_t>(total) * kSpanFields;
+                const int64_t first = 4 * done;
+                int64_t owned = 4 * share;
+                if (first + owned > count) owned = count - first;
+                row[0] = segment;
+                row[1] = static_cast<int32_t>(first);
+                row[2] = static_cast<int32_t>(host_offsets[segment]);
+                row[3] = static_cast<int32_t>(count);
+                row[4] = static_cast<int32_t>(owned);
+                row[5] = static_cast<int32_t>(first > 0 ? first - 4 : 0);
+                row[6] = row[7] = 0;
+            }
+            done += share;
+            ++total;
+        }
+    }
+    return total;
+}
+
+// `layers` (1 .. 4) consecutive Conv1d(80, 80, 3, 'same') layers in one launch.
+//   packs   float32: emph_conv_winograd4_pack of every layer, back to back
+//   biases  float32 [layers][80]
+//   relu_mask  bit l: layer l is followed by ReLU (else identity)
+//   spans   int32 [n_spans][8] from emph_conv_stack_spans (device copy)
+//   slot_map != NULL: the last layer leaves running sums in y = sums[slot][ldy]
+//   (emph_conv1d_winograd4_word_sums; the running sum restarts at every span's
+//   first own position and every 64 computed positions: `Plan.word_sum_tables`
+//   with the spans' restart columns)
+int emph_conv1d_stack(const float* x, int64_t ldx, float* y, int64_t ldy, const float* packs,
+                      const float* biases, int32_t layers, int32_t relu_mask,
+                      const int32_t* spans, int32_t n_spans, const int32_t* slot_map,
+                      void* stream) {
+    if (n_spans == 0) return EMPH_OK;
+    EMPH_REQUIRE(x && y && packs && biases && spans, EMPH_EINVAL,
+                 "emph_conv1d_stack: null pointer");
+    EMPH_REQUIRE(layers >= 1 && layers <= kStackMaxLayers, EMPH_ERANGE,
+                 "emph_conv1d_stack: %d layers (1 .. %d)", layers, kStackMaxLayers);
+    EMPH_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (ldx & 3) == 0, EMPH_EINVAL,
+                 "emph_conv1d_stack: the input must be 16-byte aligned with ldx a multiple of 4");
+    EMPH_REQUIRE(slot_map == nullptr ||
+                     ((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (ldy & 3) == 0 &&
+                      ldy >= kStackChannels && (reinterpret_cast<uintptr_t>(slot_map) & 15) == 0),
+                 EMPH_EINVAL, "emph_conv1d_stack: bad sums buffer or slot map");
+    const size_t lds = static_cast<size_t>(stack_lds_floats()) * sizeof(float);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (slot_map != nullptr) {
+        auto kernel = conv1d_stack_kernel<true>;
+        static LdsReservation reserved;
+        if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,
+                                     "emph_conv1d_stack"))
+            return status;
+        EMPH_LAUNCH(kernel, dim3(n_spans), dim3(kStackThreads), lds, s, x, ldx, y, ldy, packs,
+                    biases, layers, relu_mask, spans, slot_map);
+    } else {
+        auto kernel = conv1d_stack_kernel<false>;
+        static LdsReservation reserved;
+        if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,
+                                     "emph_conv1d_stack"))
+            return status;
+        EMPH_LAUNCH(kernel, dim3(n_spans), dim3(kStackThreads), lds, s, x, ldx, y, ldy, packs,
+                    biases, layers, relu_mask, spans, slot_map);
+    }
+    return check_launch("emph_conv1d_stack");
+}
+
+}  // extern "C"

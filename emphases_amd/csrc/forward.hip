@@ -30,7 +30,8 @@ int emph_prominence_forward(const emph_conv_model* model, const void* audio,
                             const int32_t* bounds, const int32_t* word_segment,
                             int64_t ld_frames, int64_t ld_words, float* workspace,
                             float* logits, float* scores,
-                            const emph_word_sum_tables* word_sums, void* stream) {
+                            const emph_word_sum_tables* word_sums,
+                            const int32_t* conv_spans, int32_t n_conv_spans, void* stream) {
     EMPH_REQUIRE(model != nullptr, EMPH_EINVAL, "emph_prominence_forward: model is null");
     const emph_conv_model& m = *model;
     EMPH_REQUIRE(audio && seg && workspace, EMPH_EINVAL,
@@ -77,10 +78,55 @@ int emph_prominence_forward(const emph_conv_model* model, const void* audio,
                                            activation, frame_tiles, n_frame_tiles, tile_n,
                                            stream);
     };
-    status = conv(features, current, m.input_pack, m.input_bias, m.features, EMPH_ACT_NONE);
-    if (status) return status;
     const int64_t pack_floats =
         quad ? emph_conv_winograd4_pack_size(c, c) : emph_conv_winograd_pack_size(c, c);
+    // The frame-rate layers as a few launches of several layers each
+    // (emph_conv1d_stack: activations resident in LDS from layer to layer) when the
+    // caller brought the span table and the model is the 80 -> 80 family with its
+    // packs and biases back to back (input layer first).
+    const bool stack = conv_spans != nullptr && quad && c == 80 && m.features == 80 &&
+                       m.encoder_packs == m.input_pack + pack_floats &&
+                       m.encoder_biases == m.input_bias + c &&
+                       (m.activation == EMPH_ACT_RELU || m.activation == EMPH_ACT_NONE);
+    if (stack) {
+        const int total = 1 + m.encoder_layers;
+        const int most = emph_conv_stack_max_layers();
+        const int groups = (total + most - 1) / most;
+        float* buffers[2] = {current, other};
+        const float* in = features;
+        int done = 0;
+        for (int group = 0; group < groups; ++group) {
+            // as even as possible, the larger groups first
+            const int size = (total - done + (groups - group) - 1) / (groups - group);
+            int relu = 0;
+            for (int l = 0; l < size; ++l)
+                if (done + l >= 1 && m.activation == EMPH_ACT_RELU) relu |= 1 << l;
+            // the closing group leaves running sums when the per-word sum is folded
+            const bool to_sums = group == groups - 1 && fold;
+            float* out = to_sums ? sums : buffers[group & 1];
+            status = emph_conv1d_stack(in, ld_frames, out, to_sums ? c : ld_frames,
+                                       m.input_pack + done * pack_floats,
+                                       m.input_bias + static_cast<int64_t>(done) * c, size, relu,
+                                       conv_spans, n_conv_spans,
+                                       to_sums ? word_sums->slot_map : nullptr, stream);
+            if (status) return status;
+            in = out;
+            done += size;
+        }
+        current = const_cast<float*>(in);        // (the encoder's output when not folded)
+        status = fold ? emph_word_sums(sums, c, word_sums->terms, word_sums->first,
+                                       word_sums->lengths, words, ld_words, c, ld_words,
+                                       m.reduction, stream)
+                      : emph_segment_reduce(current, ld_frames, bounds, words, ld_words, c, seg,
+                                            word_segment, ld_words, m.reduction, stream);
+        if (status) return status;
+        return emph_word_decoder(words, ld_words, word_tiles, n_word_tiles, c, m.decoder_packs,
+                                 m.decoder_biases, m.decoder_layers, m.decoder_kernel_size,
+                                 m.activation, m.out_weight, m.out_bias, m.decoder_kernel_size,
+                                 m.post, logits, scores, stream);
+    }
+    status = conv(features, current, m.input_pack, m.input_bias, m.features, EMPH_ACT_NONE);
+    if (status) return status;
     for (int layer = 0; layer < m.encoder_layers; ++layer) {
         if (fold && layer == m.encoder_layers - 1) {
             // the last frame-rate layer: running sums at the marked frames only

@@ -191,6 +191,24 @@ class Engine:
             config.downsample_method in ('sum', 'average') and
             len(self.frame_encoder) > 0 and config.channels % 4 == 0 and
             os.environ.get('EMPHASES_FOLD_WORD_SUMS', '1') != '0')
+        # the frame-rate layers as a few launches of several layers each
+        # (emph_conv1d_stack): the 80 -> 80, k = 3, identity / ReLU family
+        frame_stack = [self.input_layer] + list(self.frame_encoder) \
+            if config.architecture == 'convolution' else []
+        self.stack = bool(
+            self.quad and frame_stack and
+            config.downsample_location != 'input' and
+            all(layer.c_in == 80 and layer.c_out == 80 and
+                layer.kernel_size == 3 and layer.winograd4 is not None
+                for layer in frame_stack) and
+            os.environ.get('EMPHASES_CONV_STACK', '1') != '0')
+        if self.stack:
+            # one allocation, the input layer first: the layout
+            # emph_prominence_forward checks for
+            self._stack_packs = torch.cat(
+                [layer.winograd4 for layer in frame_stack])
+            self._stack_biases = torch.cat(
+                [layer.bias for layer in frame_stack])
         self.model = self._conv_model()
 
     def lane(self):
@@ -219,10 +237,18 @@ class Engine:
             return None
         encoder = self.frame_encoder
         pick = (lambda l: l.winograd4) if self.quad else (lambda l: l.winograd)
-        self._encoder_packs = torch.cat([pick(l) for l in encoder]) \
-            if encoder else torch.zeros(1, device=self.device)
-        self._encoder_biases = torch.cat([l.bias for l in encoder]) \
-            if encoder else torch.zeros(1, device=self.device)
+        input_pack, input_bias = pick(self.input_layer), self.input_layer.bias
+        if self.stack:
+            size = input_pack.numel()
+            input_pack = self._stack_packs[:size]
+            self._encoder_packs = self._stack_packs[size:]
+            input_bias = self._stack_biases[:config.channels]
+            self._encoder_biases = self._stack_biases[config.channels:]
+        else:
+            self._encoder_packs = torch.cat([pick(l) for l in encoder]) \
+                if encoder else torch.zeros(1, device=self.device)
+            self._encoder_biases = torch.cat([l.bias for l in encoder]) \
+                if encoder else torch.zeros(1, device=self.device)
         pointer = lambda t: None if t is None else t.data_ptr()  # noqa: E731
         return runtime.ConvModel(
             channels=config.channels, features=config.num_features,
@@ -237,8 +263,8 @@ class Engine:
             mel_count=pointer(self.mel_count),
             mel_offset=pointer(self.mel_offset),
             mel_values=pointer(self.mel_values),
-            input_pack=pointer(pick(self.input_layer)),
-            input_bias=pointer(self.input_layer.bias),
+            input_pack=pointer(input_pack),
+            input_bias=pointer(input_bias),
             encoder_packs=pointer(self._encoder_packs),
             encoder_biases=pointer(self._encoder_biases),
             decoder_packs=pointer(self.decoder_packs),
@@ -417,7 +443,9 @@ class Engine:
                         (runtime.AXIS_WORDS, self.word_block) + MANY_WORDS]
         requests = list(dict.fromkeys(requests))
         fold = self.fold and not nested and tile == 64
-        host, offsets = plan.pack_metadata(requests, word_sums=fold)
+        stack = self.stack and not nested and tile == 64
+        host, offsets = plan.pack_metadata(
+            requests, word_sums=fold, spans=stack)
         pinned = self._pinned(('meta', nested), host)
         device_buffer = pinned.to(self.device, non_blocking=True)
         views = {'_buffer': device_buffer, '_pinned': pinned, 'tile': tile,
@@ -425,7 +453,9 @@ class Engine:
         for name, (start, size) in offsets.items():
             views[name] = (device_buffer[start:start + size], size)
         if fold:
-            views['n_slots'] = plan.word_sum_tables()['n_slots']
+            views['n_slots'] = plan.word_sum_tables(
+                plan.sum_restarts(plan.conv_spans()) if stack else None)[
+                    'n_slots']
             views['word_sum_tables'] = runtime.WordSumTables(
                 *[views[('word_sums', name)][0].data_ptr() for name in (
                     'slot_map', 'terms', 'first', 'lengths')],
@@ -731,6 +761,62 @@ class Engine:
             add_layernorm(layer['norm2'])
         return x
 
+    def _frame_stack(self, features, ld_f, a, b, out, ld_w, plan, meta):
+        """Input layer + frame encoder as groups of up to four layers per
+        launch (`emph_conv1d_stack`: a workgroup owns a span of positions
+        through the layers of a group, activations resident in LDS), then
+        `emphases.downsample` into `out` - from running sums the last group
+        leaves behind when the per-word sum is folded, else by
+        `emph_segment_reduce`.  Same launches as emph_prominence_forward."""
+        config = self.config
+        channels = config.channels
+        spans, span_size = meta['conv_spans']
+        total = 1 + len(self.frame_encoder)
+        most = int(self.lib.emph_conv_stack_max_layers())
+        groups = -(-total // most)
+        fold = 'word_sum_tables' in meta
+        view = lambda name: meta[('word_sums', name)][0]  # noqa: E731
+        sums = self._buffer(
+            'word_sums', max(meta.get('n_slots', 0), 1), channels)
+        pack = self.input_layer.winograd4.numel()
+        relu_layers = config.activation == 'relu'
+        source, buffers, done = features, (a, b), 0
+        for group in range(groups):
+            size = -(-(total - done) // (groups - group))
+            relu = sum(1 << l for l in range(size)
+                       if done + l >= 1 and relu_layers)
+            to_sums = fold and group == groups - 1
+            target = sums if to_sums else buffers[group & 1]
+            flops = 2. * 80 * 80 * 3 * plan.total_frames * size
+            with self._timed('conv1d_stack_frames_80x80_k3', flops):
+                runtime.check(self.lib.emph_conv1d_stack(
+                    source.data_ptr(), ld_f, target.data_ptr(),
+                    channels if to_sums else ld_f,
+                    self._stack_packs[done * pack:].data_ptr(),
+                    self._stack_biases[done * channels:].data_ptr(), size,
+                    relu, spans.data_ptr(), span_size // 8,
+                    view('slot_map').data_ptr() if to_sums else None,
+                    runtime.stream()), 'emph_conv1d_stack')
+            source = target
+            done += size
+        if fold:
+            with self._timed('word_sums'):
+                runtime.check(self.lib.emph_word_sums(
+                    sums.data_ptr(), channels, view('terms').data_ptr(),
+                    view('first').data_ptr(), view('lengths').data_ptr(),
+                    out.data_ptr(), ld_w, channels, ld_w,
+                    runtime.REDUCTIONS[config.downsample_method],
+                    runtime.stream()), 'emph_word_sums')
+        else:
+            with self._timed('segment_reduce'):
+                runtime.check(self.lib.emph_segment_reduce(
+                    source.data_ptr(), ld_f, meta['bounds'][0].data_ptr(),
+                    out.data_ptr(), ld_w, channels,
+                    meta['table'][0].data_ptr(),
+                    meta['word_segment'][0].data_ptr(), ld_w,
+                    runtime.REDUCTIONS[config.downsample_method],
+                    runtime.stream()), 'emph_segment_reduce')
+
     def _word_sums(self, x, ld_f, out, ld_w, plan, meta):
         """The last frame-rate layer + `emphases.downsample` ('sum' /
         'average', `core.py:438-454`) without the layer's output ever being
@@ -823,6 +909,7 @@ class Engine:
             logits = self._buffer('logits', ld_w)
             scores = self._buffer('scores', ld_w)
             tables = meta.get('word_sum_tables')
+            spans, span_size = meta.get('conv_spans', (None, 0))
             floats = self.lib.emph_prominence_workspace_floats(
                 config.num_features, channels, ld_f, ld_w,
                 meta.get('n_slots', 0))
@@ -842,6 +929,8 @@ class Engine:
                 meta['word_segment'][0].data_ptr(), ld_f, ld_w,
                 workspace.data_ptr(), logits.data_ptr(), scores.data_ptr(),
                 None if tables is None else ctypes.byref(tables),
+                spans.data_ptr() if spans is not None else None,
+                span_size // 8 if spans is not None else 0,
                 runtime.stream()), 'emph_prominence_forward')
             return scores, logits
         if features is None:
@@ -887,36 +976,42 @@ class Engine:
         else:
             a = self._buffer('frames_a', channels, ld_f)
             b = self._buffer('frames_b', channels, ld_f)
-            # (the stage dump wants the input layer's own output)
-            positioned = self._conv(
-                self.input_layer, features, ld_f, a, ld_f, meta, frames, block,
-                None, position=config.architecture == 'transformer' and
-                stages is None)
-            if stages is not None:
-                stages['features'] = features.clone()
-                stages['input_layer'] = a.clone()
-            # (the stage dump wants the encoder's own output: the taps keep
-            # the unfolded reduce, which agrees to summation order)
-            fold = 'word_sum_tables' in meta and stages is None
-            encoded = self._stack_forward(
-                self.frame_encoder[:-1] if fold else self.frame_encoder, a, b,
-                ld_f, plan, meta, frames, block, 'frames',
-                positioned=positioned)
-            if stages is not None:
-                stages['encoder'] = encoded.clone()
-
-            check_bounds(plan, config.downsample_method)
-            if fold:
-                self._word_sums(encoded, ld_f, wa, ld_w, plan, meta)
+            if 'conv_spans' in meta and stages is None:
+                # the frame-rate layers a few at a time (emph_conv1d_stack),
+                # the last launch straight into the per-word sums when folded
+                check_bounds(plan, config.downsample_method)
+                self._frame_stack(features, ld_f, a, b, wa, ld_w, plan, meta)
             else:
-                with self._timed('segment_reduce'):
-                    runtime.check(self.lib.emph_segment_reduce(
-                        encoded.data_ptr(), ld_f,
-                        meta['bounds'][0].data_ptr(), wa.data_ptr(), ld_w,
-                        channels, table.data_ptr(),
-                        meta['word_segment'][0].data_ptr(), ld_w,
-                        runtime.REDUCTIONS[config.downsample_method],
-                        runtime.stream()), 'emph_segment_reduce')
+                # (the stage dump wants the input layer's own output)
+                positioned = self._conv(
+                    self.input_layer, features, ld_f, a, ld_f, meta, frames, block,
+                    None, position=config.architecture == 'transformer' and
+                    stages is None)
+                if stages is not None:
+                    stages['features'] = features.clone()
+                    stages['input_layer'] = a.clone()
+                # (the stage dump wants the encoder's own output: the taps keep
+                # the unfolded reduce, which agrees to summation order)
+                fold = 'word_sum_tables' in meta and stages is None
+                encoded = self._stack_forward(
+                    self.frame_encoder[:-1] if fold else self.frame_encoder, a, b,
+                    ld_f, plan, meta, frames, block, 'frames',
+                    positioned=positioned)
+                if stages is not None:
+                    stages['encoder'] = encoded.clone()
+
+                check_bounds(plan, config.downsample_method)
+                if fold:
+                    self._word_sums(encoded, ld_f, wa, ld_w, plan, meta)
+                else:
+                    with self._timed('segment_reduce'):
+                        runtime.check(self.lib.emph_segment_reduce(
+                            encoded.data_ptr(), ld_f,
+                            meta['bounds'][0].data_ptr(), wa.data_ptr(), ld_w,
+                            channels, table.data_ptr(),
+                            meta['word_segment'][0].data_ptr(), ld_w,
+                            runtime.REDUCTIONS[config.downsample_method],
+                            runtime.stream()), 'emph_segment_reduce')
         if stages is not None:
             stages['downsampled'] = wa.clone()
         if self.fused_words:

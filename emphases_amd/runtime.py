@@ -77,6 +77,11 @@ SIGNATURES = {
     'emph_conv1d_winograd4_word_sums': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _i32, _ptr, _i32,
         _ptr, _ptr]),
+    'emph_conv_stack_max_layers': (_i32, []),
+    'emph_conv_stack_spans': (_i32, [_ptr, _ptr, _i32, _ptr]),
+    'emph_conv1d_stack': (_c.c_int, [
+        _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _i32, _ptr,
+        _ptr]),
     'emph_word_sums': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _ptr]),
     'emph_conv_winograd4_split_pack': (_c.c_int, [_ptr, _i32, _i32, _ptr]),
@@ -102,7 +107,7 @@ SIGNATURES = {
         _i64, [_i32, _i32, _i64, _i64, _i32]),
     'emph_prominence_forward': (_c.c_int, [
         _ptr, _ptr, _i32, _ptr, _ptr, _i32, _ptr, _i32, _i32, _ptr, _i32, _ptr,
-        _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr]),
+        _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
     'emph_files_open': (_c.c_int, [_ptr, _ptr, _i32, _i32, _ptr]),
     'emph_files_close': (None, [_ptr]),
     'emph_files_error': (_c.c_char_p, [_ptr, _i32]),

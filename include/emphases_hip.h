@@ -361,6 +361,34 @@ int emph_conv1d_winograd4_word_sums(const float* x, int64_t ldx, float* sums,
                                     const int32_t* tiles, int32_t n_tiles,
                                     const int32_t* slot_map, void* stream);
 
+/* Up to emph_conv_stack_max_layers() (4) consecutive Conv1d(80, 80, 3, 'same')
+ * + activation layers of the frame encoder (emphases/model/core.py:24-31,
+ * 96-100; model/layers/convolution.py:25-37) in ONE launch: a workgroup owns
+ * a span of up to 252 positions of one segment through all the layers, the
+ * activations stay in LDS from layer to layer, the weights stream through an
+ * LDS ring, one recomputed quad of halo on each side that continues inside
+ * the segment.  Bit for bit the values of `layers` emph_conv1d_winograd4
+ * launches (same arithmetic per output).
+ *   packs      emph_conv_winograd4_pack of every layer, back to back
+ *   biases     float32 [layers][80]
+ *   relu_mask  bit l set: layer l is followed by ReLU (else identity)
+ *   spans      int32 [n_spans][8], emph_conv_stack_spans (device copy)
+ *   slot_map   NULL: y float32 [80][ldy] receives the last layer's output;
+ *              else the last layer leaves running sums in y = sums[slot][ldy]
+ *              like emph_conv1d_winograd4_word_sums, a running sum restarting
+ *              at a span's first own position and every 64 computed positions
+ * emph_conv_stack_spans cuts every segment (counts[i] positions at frame
+ * column offsets[i]) into the fewest spans of even size (host arithmetic;
+ * host_spans NULL: returns the number of spans). */
+int32_t emph_conv_stack_max_layers(void);
+int32_t emph_conv_stack_spans(const int64_t* host_counts,
+                              const int64_t* host_offsets, int32_t n_segments,
+                              int32_t* host_spans);
+int emph_conv1d_stack(const float* x, int64_t ldx, float* y, int64_t ldy,
+                      const float* packs, const float* biases, int32_t layers,
+                      int32_t relu_mask, const int32_t* spans, int32_t n_spans,
+                      const int32_t* slot_map, void* stream);
+
 /* EXPERIMENTAL (measured in DESIGN.md section 6, not used by the engine):
  * the F(4,3) layer as TWO independent launches ("halves"): half 0 computes the
  * output channels of the first ceil(m_tiles / 2) 16-channel tiles, half 1 the
@@ -735,8 +763,12 @@ int64_t emph_prominence_workspace_floats(int32_t features, int32_t channels,
  * block `tile_n` (32 or 64; 64 for conv_variant 1), `word_tiles` from
  * emph_word_decoder_tiles(...).  `word_sums` (conv_variant 1, reduction sum /
  * average; else NULL): the last encoder layer leaves running sums instead of
- * its output and emph_word_sums replaces emph_segment_reduce.  Enqueues on
- * `stream`; allocates nothing. */
+ * its output and emph_word_sums replaces emph_segment_reduce.  `conv_spans`
+ * (emph_conv_stack_spans, device copy; else NULL): the frame-rate layers run
+ * as groups of up to four layers per launch (emph_conv1d_stack) when the model
+ * is the 80 -> 80 family with `input_pack` / `encoder_packs` and `input_bias`
+ * / `encoder_biases` back to back in memory; `word_sums` must then follow the
+ * spans' restarts.  Enqueues on `stream`; allocates nothing. */
 int emph_prominence_forward(const emph_conv_model* model, const void* audio,
                             int32_t audio_format, const int64_t* seg,
                             const int32_t* frontend_tiles,
@@ -748,6 +780,7 @@ int emph_prominence_forward(const emph_conv_model* model, const void* audio,
                             int64_t ld_words, float* workspace, float* logits,
                             float* scores,
                             const emph_word_sum_tables* word_sums,
+                            const int32_t* conv_spans, int32_t n_conv_spans,
                             void* stream);
 
 #ifdef __cplusplus

@@ -217,6 +217,79 @@ def test_conv1d_winograd4(c_in, c_out, activation):
         None) == -2                         # c_in must be a multiple of 4
 
 
+@pytest.mark.parametrize('layers,relu_mask', [
+    (1, 0b1), (2, 0b10), (3, 0b110), (4, 0b1110), (4, 0b1111)])
+def test_conv1d_stack_equals_layer_by_layer(layers, relu_mask):
+    """emph_conv1d_stack (`layers` Conv1d(80, 80, 3) + identity / ReLU in ONE
+    launch, activations resident in LDS, one recomputed quad of halo per side)
+    == `layers` emph_conv1d_winograd4 launches, BIT FOR BIT, on ragged
+    segments around every span boundary the span table can produce: one span
+    (1 .. 256 positions), two spans (257, 504), three (505, 600), thirteen
+    (3000); NaN in all padding.  Also against torch conv1d (2e-5)."""
+    lib = runtime.library()
+    frames = [1000, 1, 2, 3, 4, 5, 37, 64, 65, 252, 253, 256, 257, 504, 505,
+              600, 3000, 130]
+    plan = ragged_plan(frames)
+    axis, tile = runtime.AXIS_FRAMES, 64
+    meta = Meta(plan, [(axis, tile)])
+    spans_host = plan.conv_spans()
+    assert spans_host[:, 4].sum() == sum(frames)
+    spans_dev = torch.from_numpy(spans_host).to(DEVICE)
+    x = random_packed(80, plan, axis, 31)
+    x[:, :batch.LEAD] = float('nan')
+    x[:, -batch.TAIL:] = float('nan')
+    for off, count in spans(plan, axis):
+        x[:, off + count:off + count + (-count) % 16] = float('nan')
+    weights = [synth.weights(40 + l, (80, 80, 3), 0.12) for l in range(layers)]
+    biases = [synth.weights(50 + l, (80,), 0.3) for l in range(layers)]
+    packs = torch.from_numpy(np.concatenate(
+        [runtime.conv_winograd4_pack(w) for w in weights])).to(DEVICE)
+    biases_dev = torch.from_numpy(np.concatenate(biases)).to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    x_dev = x.to(DEVICE)
+    # layer by layer
+    pack_size = packs.numel() // layers
+    current = x_dev
+    for l in range(layers):
+        out = torch.full((80, plan.ld_frames), 7.0, device=DEVICE)
+        runtime.check(lib.emph_conv1d_winograd4(
+            current.data_ptr(), plan.ld_frames, out.data_ptr(), plan.ld_frames,
+            packs[l * pack_size:].data_ptr(), biases_dev[80 * l:].data_ptr(),
+            80, 80, 1 if (relu_mask >> l) & 1 else 0, tiles.data_ptr(),
+            size // 4, None), 'emph_conv1d_winograd4')
+        current = out
+    want = current.cpu()
+    # one launch
+    y = torch.full((80, plan.ld_frames), 7.0, device=DEVICE)
+    runtime.check(lib.emph_conv1d_stack(
+        x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
+        packs.data_ptr(), biases_dev.data_ptr(), layers, relu_mask,
+        spans_dev.data_ptr(), len(spans_host), None, None),
+        'emph_conv1d_stack')
+    got = y.cpu()
+    reference = x.clone()
+    for off, count in spans(plan, axis):
+        assert torch.equal(got[:, off:off + count], want[:, off:off + count]), \
+            (count, float((got[:, off:off + count] -
+                           want[:, off:off + count]).abs().max()))
+        value = reference[None, :, off:off + count]
+        for l in range(layers):
+            value = torch.nn.functional.conv1d(
+                value, torch.from_numpy(weights[l]),
+                torch.from_numpy(biases[l]), padding=1)
+            if (relu_mask >> l) & 1:
+                value = torch.relu(value)
+        scale = max(1.0, float(value.abs().max()))
+        assert float((got[:, off:off + count] - value[0]).abs().max()) < \
+            2e-5 * scale * layers
+    # columns outside every segment are left untouched
+    assert float(got[:, :batch.LEAD].min()) == 7.0
+    assert lib.emph_conv1d_stack(
+        x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
+        packs.data_ptr(), biases_dev.data_ptr(), 5, 0, spans_dev.data_ptr(),
+        len(spans_host), None, None) != 0
+
+
 @pytest.mark.parametrize('c_in,c_out,activation,max_positions', [
     (80, 80, None, 5000), (80, 80, 'relu', 150), (64, 64, None, 131),
     (48, 33, None, 5000)])
