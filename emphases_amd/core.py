@@ -139,9 +139,10 @@ def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
         default: `penn` itself, if installed.
     Returns a list of float32 tensors [1, W_i] (CPU if `gpu is None`)."""
     session = get_session(checkpoint, gpu, config, conv_tile)
-    return session.run(
-        alignments, audios, sample_rate, batch_size,
-        on_device=gpu is not None, pitch_tracker=pitch_tracker)
+    with runtime.few_host_threads():
+        return session.run(
+            alignments, audios, sample_rate, batch_size,
+            on_device=gpu is not None, pitch_tracker=pitch_tracker)
 
 
 def from_alignment_and_audio(alignment, audio, sample_rate, checkpoint=None,
@@ -221,6 +222,14 @@ def files_to_scores(text_files, audio_files, session, batch_size=None,
     for file in text_files:
         if not str(file).endswith(('.TextGrid', '.json')):
             from_text_and_audio(None, None, None)
+    with runtime.few_host_threads():
+        _files_to_scores(text_files, audio_files, session, batch_size,
+                         utterances_per_batch, deliver, deliver_batch)
+
+
+def _files_to_scores(text_files, audio_files, session, batch_size,
+                     utterances_per_batch, deliver, deliver_batch):
+    from . import files
     in_flight = []
 
     def finish(jobs):

@@ -1,4 +1,4 @@
-// Up to FOUR consecutive Conv1d(80, 80, 3, 'same') + activation layers of the
+// Up to THREE consecutive Conv1d(80, 80, 3, 'same') + activation layers of the
 // frame encoder (emphases/model/core.py:24-31,96-100 over
 // model/layers/convolution.py:25-37) in ONE launch, Winograd F(4,3) on
 // v_mfma_f32_16x16x4_f32 like conv_w4.hip - the same arithmetic per output, so the
@@ -13,11 +13,18 @@
 // positions of one segment for all the layers of the launch:
 //
 //   * 256 computed positions = 4 MFMA column tiles of 16 quads = the span plus a
-//     halo of one quad on each side that continues inside the segment (a layer
-//     needs one position from each neighbour; four layers, four positions).  The
+//     halo of one quad on each side that continues inside the segment.  The
 //     halo is recomputed, 2.4 % more matrix work, instead of exchanged: a
 //     cross-workgroup hand-off per layer costs more than the layer's ramp
-//     (MI355X_MICROARCH.md, inter-workgroup visibility);
+//     (MI355X_MICROARCH.md, inter-workgroup visibility).  Why three layers and
+//     not four: in F(4,3) the stale column beside the computed region reaches
+//     only ONE output of the edge quad in the first layer (d0 enters v0, m0, y0
+//     alone; d5 only y3), every output of that quad in the second - two of them
+//     only through rounding, the mathematically cancelling terms - and through
+//     d0 / d5 of the NEXT quad the span's own first / last position in the
+//     fourth: 6.6e-7 off the layer-by-layer result (measured).  Three layers
+//     are exact with one quad of halo; four would need two (240 own positions:
+//     a 10 s utterance would no longer be four spans);
 //   * activations [80][260] floats (83.2 KB) are updated in place: accumulators
 //     live in registers, a barrier separates the last read of a layer from the
 //     first write of its output.  Index i of a row is position c0 - 1 + i, so the
@@ -39,6 +46,11 @@
 
 #include "common.h"
 
+// (tools/micro/stack_bench.hip defines STACK_STAMP for an in-kernel timeline)
+#ifndef STACK_STAMP
+#define STACK_STAMP(slot)
+#endif
+
 namespace emph {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -54,7 +66,7 @@ constexpr int kStackChunkFloats = kStackChunkSteps * kStackStepFloats;
 constexpr int kStackWidth = 256;                          // computed positions
 constexpr int kStackStride = 260;                         // floats per activation row
 constexpr int kStackThreads = 768;                        // 8 MFMA waves + 4 loader waves
-constexpr int kStackMaxLayers = 4;
+constexpr int kStackMaxLayers = 3;
 constexpr int kSpanFields = 8;
 
 __host__ __device__ constexpr int stack_lds_floats() {
@@ -99,38 +111,57 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
                 (const __attribute__((address_space(1))) void*)(source + 4 * (base + lane)),
                 (__attribute__((address_space(3))) void*)(target + 4 * base), 16, 0, 0);
     };
+    STACK_STAMP(0);
     if (loader) request(0);
 
     // ---- the layer-0 input of the computed positions, zeros outside the segment
     for (int index = threadIdx.x; index < layers * kStackChannels; index += kStackThreads)
         bias_lds[index] = biases[index];
-    for (int index = threadIdx.x; index < kStackChannels * 65; index += kStackThreads) {
-        const int c = index / 65;
-        const int q = index - c * 65;
-        const float* row = x + static_cast<int64_t>(c) * ldx + column;
-        float* target = act + c * kStackStride;
-        if (q < 64) {
+    {
+        // 80 rows x 64 quads: a thread REQUESTS its seven 16-byte runs first and
+        // writes them afterwards (one load in flight per thread took 7 us here:
+        // a global load is 1-2 us away on this chip)
+        constexpr int kQuads = kStackChannels * 64;
+        constexpr int kRounds = (kQuads + kStackThreads - 1) / kStackThreads;
+        float4 value[kRounds];
+#pragma unroll
+        for (int round = 0; round < kRounds; ++round) {
+            const int index = threadIdx.x + round * kStackThreads;
+            const int c = index >> 6, q = index & 63;
             const int p = c0 + 4 * q;
-            float4 value = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p + 3 < count) {
-                value = *reinterpret_cast<const float4*>(row + p);
-            } else {
-                if (p < count) value.x = row[p];
-                if (p + 1 < count) value.y = row[p + 1];
-                if (p + 2 < count) value.z = row[p + 2];
+            const float* row = x + static_cast<int64_t>(c) * ldx + column;
+            value[round] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (index < kQuads) {
+                if (p + 3 < count) {
+                    value[round] = *reinterpret_cast<const float4*>(row + p);
+                } else {
+                    if (p < count) value[round].x = row[p];
+                    if (p + 1 < count) value[round].y = row[p + 1];
+                    if (p + 2 < count) value[round].z = row[p + 2];
+                }
             }
-            target[4 * q + 1] = value.x;
-            *reinterpret_cast<f32x2*>(target + 4 * q + 2) = f32x2{value.y, value.z};
-            target[4 * q + 4] = value.w;
-        } else {
-            const int before = c0 - 1, after = c0 + kStackWidth;
-            target[0] = (before >= 0 && before < count) ? row[before] : 0.f;
-            target[kStackWidth + 1] = after < count ? row[after] : 0.f;
-            target[kStackWidth + 2] = after + 1 < count ? row[after + 1] : 0.f;
-            target[kStackWidth + 3] = 0.f;
         }
+        // the columns beside the computed positions
+        float side = 0.f;
+        const int side_row = threadIdx.x >> 2, side_kind = threadIdx.x & 3;
+        if (side_row < kStackChannels) {
+            const float* row = x + static_cast<int64_t>(side_row) * ldx + column;
+            const int p = side_kind == 0 ? c0 - 1 : c0 + kStackWidth + side_kind - 1;
+            if (side_kind < 3 && p >= 0 && p < count) side = row[p];
+        }
+#pragma unroll
+        for (int round = 0; round < kRounds; ++round) {
+            const int index = threadIdx.x + round * kStackThreads;
+            if (index >= kQuads) continue;
+            float* target = act + (index >> 6) * kStackStride + 4 * (index & 63);
+            target[1] = value[round].x;
+            *reinterpret_cast<f32x2*>(target + 2) = f32x2{value[round].y, value[round].z};
+            target[4] = value[round].w;
+        }
+        if (side_row < kStackChannels)
+            act[side_row * kStackStride + (side_kind == 0 ? 0 : kStackWidth + side_kind)] = side;
     }
-
+    STACK_STAMP(1);
     if (loader) {
         // chunk g has landed -> barrier (everyone is also done with chunk g - 1,
         // whose slot chunk g + 1 overwrites) -> request chunk g + 1; plus the one
@@ -138,6 +169,7 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
         // activations
         for (int g = 0; g < total_chunks; ++g) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+            STACK_STAMP(2 + 8 * (g / kStackChunks) + g % kStackChunks);
             __syncthreads();
             if (g + 1 < total_chunks) request(g + 1);
             // (the MFMA waves' barrier in front of a layer's in-place update: every
@@ -179,6 +211,7 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
                 // the chunk has landed (and, chunk 0: every wave has written its
                 // part of this layer's input)
                 __syncthreads();
+                STACK_STAMP(2 + 8 * layer + chunk);
                 if (chunk == 0) load_b(0);
                 const float* weights =
                     ring + ((layer * kStackChunks + chunk) & 1) * kStackChunkFloats +
@@ -215,6 +248,7 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
             const bool relu = (relu_mask >> layer) & 1;
             const bool last = layer == layers - 1;
             const float* bias_row = bias_lds + layer * kStackChannels;
+            STACK_STAMP(2 + 8 * layer + 5);
             if (!last) {
                 // every wave is done reading this layer's input: its output may
                 // take the rows' place (zeros outside the segment: 'same' padding)
@@ -249,6 +283,7 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
                         target[3] = o3;
                     }
                 }
+                STACK_STAMP(2 + 8 * layer + 6);
                 continue;
             }
             // ---- the launch's last layer: the span's own positions leave the chip
@@ -344,6 +379,7 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
                     }
                 }
             }
+            STACK_STAMP(2 + 8 * layer + 6);
         }
     };
     if (part == 0) run(std::integral_constant<int, split>{});

@@ -762,7 +762,7 @@ class Engine:
         return x
 
     def _frame_stack(self, features, ld_f, a, b, out, ld_w, plan, meta):
-        """Input layer + frame encoder as groups of up to four layers per
+        """Input layer + frame encoder as groups of up to three layers per
         launch (`emph_conv1d_stack`: a workgroup owns a span of positions
         through the layers of a group, activations resident in LDS), then
         `emphases.downsample` into `out` - from running sums the last group

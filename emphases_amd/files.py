@@ -28,7 +28,31 @@ from . import alignment as alignment_module
 from . import load
 from . import runtime
 
-THREADS = 16
+import os
+
+
+def _cpu_budget():
+    """CPUs this process may keep busy: the cgroup quota when there is one
+    (a container that shows 128 cores under a 16-CPU quota is THROTTLED -
+    frozen for the rest of the period - as soon as its threads together use
+    more than that), else the affinity mask."""
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as file:
+            quota, period = file.read().split()
+        if quota != 'max':
+            return max(1, int(float(quota) / float(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+# threads of the library's file pool per call: half the budget (two batches are
+# in flight, the Python thread and the HIP runtime's threads need CPUs too)
+THREADS = int(os.environ.get(
+    'EMPHASES_FILE_THREADS', max(2, min(16, _cpu_budget() // 2))))
 
 
 class FileAudio:
@@ -59,11 +83,11 @@ class FileAudio:
 class FileBatch:
     """`count` (alignment file, audio file) pairs opened by the library."""
 
-    def __init__(self, text_files, audio_files, threads=THREADS):
+    def __init__(self, text_files, audio_files, threads=None):
         self.text_files = [str(file) for file in text_files]
         self.audio_files = [str(file) for file in audio_files]
         self.count = len(self.text_files)
-        self.threads = int(threads)
+        self.threads = int(threads or THREADS)
         lib = runtime.library()
         self._lib = lib
         self._handle = ctypes.c_void_p()

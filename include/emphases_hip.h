@@ -361,7 +361,7 @@ int emph_conv1d_winograd4_word_sums(const float* x, int64_t ldx, float* sums,
                                     const int32_t* tiles, int32_t n_tiles,
                                     const int32_t* slot_map, void* stream);
 
-/* Up to emph_conv_stack_max_layers() (4) consecutive Conv1d(80, 80, 3, 'same')
+/* Up to emph_conv_stack_max_layers() (3) consecutive Conv1d(80, 80, 3, 'same')
  * + activation layers of the frame encoder (emphases/model/core.py:24-31,
  * 96-100; model/layers/convolution.py:25-37) in ONE launch: a workgroup owns
  * a span of up to 252 positions of one segment through all the layers, the
@@ -765,7 +765,7 @@ int64_t emph_prominence_workspace_floats(int32_t features, int32_t channels,
  * average; else NULL): the last encoder layer leaves running sums instead of
  * its output and emph_word_sums replaces emph_segment_reduce.  `conv_spans`
  * (emph_conv_stack_spans, device copy; else NULL): the frame-rate layers run
- * as groups of up to four layers per launch (emph_conv1d_stack) when the model
+ * as groups of up to three layers per launch (emph_conv1d_stack) when the model
  * is the 80 -> 80 family with `input_pack` / `encoder_packs` and `input_bias`
  * / `encoder_biases` back to back in memory; `word_sums` must then follow the
  * spans' restarts.  Enqueues on `stream`; allocates nothing. */

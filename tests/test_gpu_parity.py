@@ -473,7 +473,7 @@ def test_fused_forward_equals_step_by_step(cases, default_engine):
     library = runtime.library()
     assert library.emph_prominence_forward(
         None, 0, 0, 0, None, 0, None, 0, 32, None, 0, None, None, 0, 0, 0, None,
-        None, None, None) == -1
+        None, None, None, 0, None) == -1
 
 
 @pytest.mark.parametrize('method', ['sum', 'average'])

@@ -32,9 +32,17 @@ try:
         texts.append(text), waves.append(wave)
         prefixes.append(os.path.join(directory, f'o{index}'))
     emphases_amd.from_files_to_files(texts[:512], waves[:512], prefixes[:512], gpu=0)
-    start = time.perf_counter()
-    emphases_amd.from_files_to_files(texts, waves, prefixes, gpu=0)
-    print('plain call', time.perf_counter() - start, 's')
+    from emphases_amd import files
+    for threads in (4, 8, 16):
+        files.THREADS = threads
+        laps = []
+        for _ in range(3):
+            start = time.perf_counter()
+            emphases_amd.from_files_to_files(texts, waves, prefixes, gpu=0)
+            laps.append(time.perf_counter() - start)
+        print(f'{threads:2d} file threads: {min(laps) * 1e3:7.1f} ms '
+              f'= {count / min(laps):8.0f} files/s  (laps {laps})')
+    files.THREADS = 8
     profiler = cProfile.Profile()
     profiler.enable()
     emphases_amd.from_files_to_files(texts, waves, prefixes, gpu=0)
