@@ -112,62 +112,69 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
                 (__attribute__((address_space(3))) void*)(target + 4 * base), 16, 0, 0);
     };
     STACK_STAMP(0);
-    if (loader) request(0);
-
-    // ---- the layer-0 input of the computed positions, zeros outside the segment
-    for (int index = threadIdx.x; index < layers * kStackChannels; index += kStackThreads)
-        bias_lds[index] = biases[index];
-    {
-        // 80 rows x 64 quads: a thread REQUESTS its seven 16-byte runs first and
-        // writes them afterwards (one load in flight per thread took 7 us here:
-        // a global load is 1-2 us away on this chip)
-        constexpr int kQuads = kStackChannels * 64;
-        constexpr int kRounds = (kQuads + kStackThreads - 1) / kStackThreads;
-        float4 value[kRounds];
-#pragma unroll
-        for (int round = 0; round < kRounds; ++round) {
-            const int index = threadIdx.x + round * kStackThreads;
-            const int c = index >> 6, q = index & 63;
-            const int p = c0 + 4 * q;
-            const float* row = x + static_cast<int64_t>(c) * ldx + column;
-            value[round] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (index < kQuads) {
-                if (p + 3 < count) {
-                    value[round] = *reinterpret_cast<const float4*>(row + p);
-                } else {
-                    if (p < count) value[round].x = row[p];
-                    if (p + 1 < count) value[round].y = row[p + 1];
-                    if (p + 2 < count) value[round].z = row[p + 2];
-                }
-            }
-        }
-        // the columns beside the computed positions
-        float side = 0.f;
-        const int side_row = threadIdx.x >> 2, side_kind = threadIdx.x & 3;
-        if (side_row < kStackChannels) {
-            const float* row = x + static_cast<int64_t>(side_row) * ldx + column;
-            const int p = side_kind == 0 ? c0 - 1 : c0 + kStackWidth + side_kind - 1;
-            if (side_kind < 3 && p >= 0 && p < count) side = row[p];
-        }
-#pragma unroll
-        for (int round = 0; round < kRounds; ++round) {
-            const int index = threadIdx.x + round * kStackThreads;
-            if (index >= kQuads) continue;
-            float* target = act + (index >> 6) * kStackStride + 4 * (index & 63);
-            target[1] = value[round].x;
-            *reinterpret_cast<f32x2*>(target + 2) = f32x2{value[round].y, value[round].z};
-            target[4] = value[round].w;
-        }
-        if (side_row < kStackChannels)
-            act[side_row * kStackStride + (side_kind == 0 ? 0 : kStackWidth + side_kind)] = side;
-    }
-    STACK_STAMP(1);
     if (loader) {
+        request(0);
+        request(1);
+    }
+
+    // ---- the layer-0 input of the computed positions, zeros outside the segment.
+    // One 16-byte run per (row, quad), always ONE load from a readable address
+    // (clamped to the segment's last quad) and masked by position - so a thread's
+    // loads are all requested before the first is used (a global load is 1-2 us
+    // away on this chip) and their number is a constant.  The eight MFMA waves
+    // bring rows 0 .. 31, what the first two weight chunks multiply; the loader
+    // waves bring rows 32 .. 79 UNDER the K loop of those chunks (all CUs pulling
+    // their 82 KB at once is a 4 us burst at HBM speed: this hides 60 % of it).
+    const int last_quad = (count - 1) & ~3;
+    auto fetch = [&](int c, int q) {
+        const int p = c0 + 4 * q;
+        const float4 v = *reinterpret_cast<const float4*>(
+            x + static_cast<int64_t>(c) * ldx + column + min(p, last_quad));
+        return make_float4(p < count ? v.x : 0.f, p + 1 < count ? v.y : 0.f,
+                           p + 2 < count ? v.z : 0.f, p + 3 < count ? v.w : 0.f);
+    };
+    auto deposit = [&](int c, int q, const float4& v) {
+        float* target = act + c * kStackStride + 4 * q;
+        target[1] = v.x;
+        *reinterpret_cast<f32x2*>(target + 2) = f32x2{v.y, v.z};
+        target[4] = v.w;
+    };
+    constexpr int kEarlyRows = 32;
+    if (loader) {
+        constexpr int kLate = (kStackChannels - kEarlyRows) * 64 / 256;   // 12 per thread
+        static_assert(kLate == 12, "the s_waitcnt below counts these loads");
+        asm volatile("" ::: "memory");
+        float4 late[kLate];
+        const int mine = threadIdx.x - 512;
+#pragma unroll
+        for (int round = 0; round < kLate; ++round) {
+            const int index = mine + 256 * round;
+            late[round] = fetch(kEarlyRows + (index >> 6), index & 63);
+        }
+        STACK_STAMP(1);
         // chunk g has landed -> barrier (everyone is also done with chunk g - 1,
         // whose slot chunk g + 1 overwrites) -> request chunk g + 1; plus the one
         // barrier per layer between the last read and the first write of the
-        // activations
-        for (int g = 0; g < total_chunks; ++g) {
+        // activations.  Chunks 0 and 1 were both requested up front (both slots
+        // are free at the start) IN FRONT of the twelve row loads: vmcnt counts
+        // in order, so "chunk 0 landed" is vmcnt(rows + requests of chunk 1) and
+        // "chunk 1 landed" is vmcnt(rows), the rows still in flight under the K
+        // loop of both; the barriers are the bare instruction (__syncthreads()
+        // would wait for everything).
+        if (wave - 8 < 2) __builtin_amdgcn_s_waitcnt(0x4F74);    // vmcnt(12 + 8)
+        else __builtin_amdgcn_s_waitcnt(0x4F73);                 // vmcnt(12 + 7)
+        STACK_STAMP(2);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_waitcnt(0x0F7C);                      // vmcnt(12)
+        STACK_STAMP(3);
+        __builtin_amdgcn_s_barrier();
+        request(2);
+#pragma unroll
+        for (int round = 0; round < kLate; ++round) {
+            const int index = mine + 256 * round;
+            deposit(kEarlyRows + (index >> 6), index & 63, late[round]);
+        }
+        for (int g = 2; g < total_chunks; ++g) {
             __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
             STACK_STAMP(2 + 8 * (g / kStackChunks) + g % kStackChunks);
             __syncthreads();
@@ -178,6 +185,33 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
         }
         return;
     }
+    for (int index = threadIdx.x; index < layers * kStackChannels; index += 512)
+        bias_lds[index] = biases[index];
+    {
+        constexpr int kEarly = kEarlyRows * 64 / 512;                    // 4 per thread
+        float4 early[kEarly];
+#pragma unroll
+        for (int round = 0; round < kEarly; ++round) {
+            const int index = threadIdx.x + 512 * round;
+            early[round] = fetch(index >> 6, index & 63);
+        }
+        // the columns beside the computed positions, all 80 rows
+        float side = 0.f;
+        const int side_row = threadIdx.x >> 2, side_kind = threadIdx.x & 3;
+        if (side_row < kStackChannels) {
+            const float* row = x + static_cast<int64_t>(side_row) * ldx + column;
+            const int p = side_kind == 0 ? c0 - 1 : c0 + kStackWidth + side_kind - 1;
+            if (side_kind < 3 && p >= 0 && p < count) side = row[p];
+        }
+#pragma unroll
+        for (int round = 0; round < kEarly; ++round) {
+            const int index = threadIdx.x + 512 * round;
+            deposit(index >> 6, index & 63, early[round]);
+        }
+        if (side_row < kStackChannels)
+            act[side_row * kStackStride + (side_kind == 0 ? 0 : kStackWidth + side_kind)] = side;
+    }
+    STACK_STAMP(1);
 
     // ---- MFMA waves: column tile `tile` of 16 quads, m-tiles split 3 + 2 between
     // the two waves of a SIMD (conv_w4.hip)
@@ -212,7 +246,9 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
                 // part of this layer's input)
                 __syncthreads();
                 STACK_STAMP(2 + 8 * layer + chunk);
-                if (chunk == 0) load_b(0);
+                // (the launch's input rows 32 .. 79 arrive under chunks 0 and 1: what
+                // k-step 7 prefetched of row 32 may predate them - read it again)
+                if (chunk == 0 || (layer == 0 && chunk == 2)) load_b(chunk * kStackChunkSteps);
                 const float* weights =
                     ring + ((layer * kStackChunks + chunk) & 1) * kStackChunkFloats +
                     (m_begin << 6) + lane;
