@@ -489,14 +489,18 @@ def from_profiles(config, dominant):
                          else 'transformer_kernel_stats_1stream.csv')
     pattern = ROCPROF_NAMES.get(dominant)
     if stats and pattern:
+        # (every instantiation of the kernel: the fused conv launches are
+        # conv1d_stack_kernel<false> twice and <true> once per step)
+        calls, total = 0, 0.
         with open(stats) as file:
             for row in csv.DictReader(file):
                 if pattern in row['Name']:
-                    result['rocprof_avg_launch_us'] = \
-                        float(row['AverageNs']) * 1e-3
-                    result['rocprof_calls'] = int(row['Calls'])
-                    result['kernel_stats_file'] = os.path.relpath(stats, ROOT)
-                    break
+                    calls += int(row['Calls'])
+                    total += float(row['TotalDurationNs'])
+        if calls:
+            result['rocprof_avg_launch_us'] = total / calls * 1e-3
+            result['rocprof_calls'] = calls
+            result['kernel_stats_file'] = os.path.relpath(stats, ROOT)
     summary = profile_file('pmc_summary.json' if config == 'conv'
                            else 'transformer_pmc_summary.json')
     if summary:
@@ -565,8 +569,12 @@ def roofline(kernels, passes, ms_per_step, config):
         'share_of_step': None if not ms_per_step else
         seconds / passes / (ms_per_step * 1e-3),
         'algorithmic_flops_per_launch': flops / launches,
-        # Winograd F(2,3) executes 2/3, F(4,3) 1/2 of the direct form's MFMAs
+        # Winograd F(2,3) executes 2/3, F(4,3) 1/2 of the direct form's MFMAs:
+        # `achieved` / `frac` count the ALGORITHMIC (direct-form) flops SURVEY
+        # 8(d) prescribes, so they say how fast the layer is computed, not how
+        # busy the matrix pipe is - that is `frac_executed`
         'executed_mfma_flops_per_launch': flops / launches * executed,
+        'frac_executed': achieved * executed / PEAK_FP32_MFMA,
         # HBM bytes per launch by PMC: from the committed profile of this
         # command (see `from_profiles`), not collected in this run
         'traffic': committed.get('traffic'),
