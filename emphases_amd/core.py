@@ -229,35 +229,79 @@ def files_to_scores(text_files, audio_files, session, batch_size=None,
 
 def _files_to_scores(text_files, audio_files, session, batch_size,
                      utterances_per_batch, deliver, deliver_batch):
+    """Three things run side by side (two helper threads; what they call are
+    library or numpy routines that leave the interpreter lock alone):
+
+        opener   batch i + 1: open + parse + header walk (`files.FileBatch`),
+                 plan (`batch.plan_batch`) and the batch's metadata tables
+                 (`Engine.prepare`)
+        caller   batch i: samples -> pinned staging -> device, kernels
+                 (`Session.submit`), then the scores of batch i - 1
+        writer   batch i - 1: `<prefix>.TextGrid` + `<prefix>.pt`"""
+    import concurrent.futures
     from . import files
-    in_flight = []
+    engine = session.engine
 
-    def finish(jobs):
-        for pending, opened, chosen, indices in jobs:
-            scores = pending.result()
-            if deliver_batch is not None:
-                deliver_batch(opened, chosen, indices, scores)
-            else:
-                for local, index, item in zip(chosen, indices, scores):
-                    deliver(index, opened.alignment(local), item)
-
-    for first in range(0, len(text_files), utterances_per_batch):
-        last = min(first + utterances_per_batch, len(text_files))
+    def open_batch(first, last):
+        torch.set_num_threads(1)        # (this thread's OpenMP setting too)
         opened = files.FileBatch(
             text_files[first:last], audio_files[first:last])
         alignments = [opened.alignment(i) for i in range(last - first)]
         loaded = [opened.audio(i) for i in range(last - first)]
-        jobs = []
+        groups = []
         for rate in sorted({rate for _, rate in loaded}):
             chosen = [i for i, (_, r) in enumerate(loaded) if r == rate]
-            jobs.append((
-                session.submit(
-                    [alignments[i] for i in chosen],
-                    [loaded[i][0] for i in chosen], rate, batch_size),
-                opened, chosen, [first + i for i in chosen]))
+            picked = [alignments[i] for i in chosen]
+            audios = [loaded[i][0] for i in chosen]
+            plan = None
+            if rate == cfg.SAMPLE_RATE and all(
+                    a.dim() == 1 or a.shape[0] == 1 for a in audios):
+                plan = engine.prepare(batch.plan_batch(
+                    picked, [int(a.shape[-1]) for a in audios], batch_size))
+            groups.append((rate, chosen, picked, audios, plan))
+        return opened, groups
+
+    def write(opened, chosen, indices, scores):
+        torch.set_num_threads(1)
+        if deliver_batch is not None:
+            deliver_batch(opened, chosen, indices, scores)
+        else:
+            for local, index, item in zip(chosen, indices, scores):
+                deliver(index, opened.alignment(local), item)
+
+    starts = list(range(0, len(text_files), utterances_per_batch))
+    with concurrent.futures.ThreadPoolExecutor(2) as helpers:
+        writes, in_flight = [], []
+
+        def finish(jobs):
+            for pending, opened, chosen, indices in jobs:
+                scores = pending.result()
+                writes.append(helpers.submit(
+                    write, opened, chosen, indices, scores))
+            while len(writes) > 2:          # (errors surface; memory bounded)
+                writes.pop(0).result()
+
+        opening = helpers.submit(
+            open_batch, starts[0],
+            min(starts[0] + utterances_per_batch, len(text_files))) \
+            if starts else None
+        for position, first in enumerate(starts):
+            opened, groups = opening.result()
+            opening = None
+            if position + 1 < len(starts):
+                following = starts[position + 1]
+                opening = helpers.submit(
+                    open_batch, following,
+                    min(following + utterances_per_batch, len(text_files)))
+            jobs = [(session.submit(picked, audios, rate, batch_size,
+                                    plan=plan),
+                     opened, chosen, [first + i for i in chosen])
+                    for rate, chosen, picked, audios, plan in groups]
+            finish(in_flight)
+            in_flight = jobs
         finish(in_flight)
-        in_flight = jobs
-    finish(in_flight)
+        for pending_write in writes:
+            pending_write.result()
 
 
 def from_files_to_files(text_files, audio_files, output_prefixes=None,

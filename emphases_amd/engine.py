@@ -418,10 +418,17 @@ class Engine:
         np.copyto(view.numpy(), array)
         return view
 
-    def upload(self, plan, tile=None, nested=False):
-        """One H2D copy of all integer metadata; returns device views.
-        (`nested`: the layout of the word pieces of another plan.)"""
-        tile = tile or self.frame_tile(plan)
+    def prepare(self, plan):
+        """The host half of `upload` ahead of time: tile tables, span table,
+        word-sum tables and the packed metadata array, kept on the plan - what
+        a prefetch thread does for batch i + 1 while batch i is submitted
+        (`core.files_to_scores`).  Returns the plan."""
+        if self.config.downsample_location != 'input':
+            tile = self.frame_tile(plan)
+            plan.prepared = (tile,) + self._pack(plan, tile, False)
+        return plan
+
+    def _pack(self, plan, tile, nested):
         requests = [
             (runtime.AXIS_FRAMES, FRONTEND_BLOCK),
             (runtime.AXIS_FRAMES, tile),
@@ -446,6 +453,17 @@ class Engine:
         stack = self.stack and not nested and tile == 64
         host, offsets = plan.pack_metadata(
             requests, word_sums=fold, spans=stack)
+        return host, offsets, fold, stack
+
+    def upload(self, plan, tile=None, nested=False):
+        """One H2D copy of all integer metadata; returns device views.
+        (`nested`: the layout of the word pieces of another plan.)"""
+        tile = tile or self.frame_tile(plan)
+        prepared = getattr(plan, 'prepared', None)
+        if prepared is not None and prepared[0] == tile and not nested:
+            host, offsets, fold, stack = prepared[1:]
+        else:
+            host, offsets, fold, stack = self._pack(plan, tile, nested)
         pinned = self._pinned(('meta', nested), host)
         device_buffer = pinned.to(self.device, non_blocking=True)
         views = {'_buffer': device_buffer, '_pinned': pinned, 'tile': tile,

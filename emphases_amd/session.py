@@ -350,10 +350,14 @@ class Session:
         return list(packed.split(targets))
 
     def submit(self, alignments, audios, sample_rate=cfg.SAMPLE_RATE,
-               batch_size=None, on_device=False, pitch_tracker=None):
+               batch_size=None, on_device=False, pitch_tracker=None,
+               plan=None):
         """Enqueue a batch; returns a `Pending`.  The lane it takes is the one
         whose batch was submitted `depth` submissions ago: that batch's
-        results are extracted first if the caller has not done so."""
+        results are extracted first if the caller has not done so.  `plan`:
+        the batch's plan when the caller has it already (`batch.plan_batch` of
+        the same alignments and 16 kHz lengths, maybe `Engine.prepare`d on
+        another thread): no layout cache lookup, no planning here."""
         with self._lock:
             lane = self.lanes[self._cursor % len(self.lanes)]
             self._cursor += 1
@@ -363,7 +367,7 @@ class Session:
                 try:
                     return self._enqueue(
                         lane, list(alignments), list(audios), sample_rate,
-                        batch_size, on_device, pitch_tracker)
+                        batch_size, on_device, pitch_tracker, plan)
                 except BaseException:
                     # Copies and kernels may already be queued on the lane's
                     # stream with no `done` event behind them: drain it before
@@ -378,7 +382,7 @@ class Session:
                     raise
 
     def _enqueue(self, lane, alignments, audios, sample_rate, batch_size,
-                 on_device, pitch_tracker):
+                 on_device, pitch_tracker, ready=None):
         audios = [mono(audio) for audio in audios]
         resampling = int(sample_rate) != cfg.SAMPLE_RATE
         pcm = bool(audios) and all(
@@ -403,7 +407,9 @@ class Session:
             dtype_in, dtype = dtype, torch.float32
         layout = None
         key = layout_key(alignments, lengths, batch_size, dtype) \
-            if audios else None
+            if audios and ready is None else None
+        if ready is not None:
+            layout = _Layout(ready)
         if key is not None:
             layout = lane.layouts.get(key)
             if layout is not None:

@@ -12,14 +12,15 @@ FRAMES, WORDS, CHANNELS = 64000, 1882, 80
 KERNELS = {
     # kernel function substring -> (bench.py name, algorithmic bytes per launch)
     # the frame-rate layers as three launches per step (3 + 2 + 2 layers): each
-    # reads its input once; two write their output, the last one leaves the
-    # running sums of the per-word sum (2 rows of 80 floats per word); the mean
-    # over the three, plus the packs of 7 / 3 layers
-    'conv1d_stack_kernel': (
+    # reads its input once; the first two (<false>) write their output, the last
+    # one (<true>) leaves the running sums of the per-word sum (about two rows of
+    # 80 floats per word); plus the packs of the launch's layers
+    'conv1d_stack_kernel<false>': (
         'conv1d_stack_frames_80x80_k3',
-        CHANNELS * FRAMES * 4 + (2 * CHANNELS * FRAMES * 4 +
-                                 2 * WORDS * CHANNELS * 4) // 3 +
-        7 * 153600 // 3),
+        2 * CHANNELS * FRAMES * 4 + 5 * 153600 // 2),
+    'conv1d_stack_kernel<true>': (
+        'conv1d_stack_word_sums_80x80_k3',
+        CHANNELS * FRAMES * 4 + 2 * WORDS * CHANNELS * 4 + 2 * 153600),
     'word_sums_kernel': (
         'word_sums', 3 * WORDS * CHANNELS * 4 + CHANNELS * WORDS * 4),
     'conv1d_winograd4_kernel': (
