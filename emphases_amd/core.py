@@ -242,12 +242,15 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
     from . import files
     engine = session.engine
 
-    def open_batch(first, last):
+    def open_batch(first, last, turn):
         torch.set_num_threads(1)        # (this thread's OpenMP setting too)
         opened = files.FileBatch(
             text_files[first:last], audio_files[first:last])
         alignments = [opened.alignment(i) for i in range(last - first)]
         loaded = [opened.audio(i) for i in range(last - first)]
+        # the samples: straight into one of the session's pinned buffers
+        with torch.cuda.device(session.engine.device):
+            opened.read_all(session.file_buffer(turn, opened.audio_bytes()))
         groups = []
         for rate in sorted({rate for _, rate in loaded}):
             chosen = [i for i, (_, r) in enumerate(loaded) if r == rate]
@@ -283,7 +286,7 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
 
         opening = helpers.submit(
             open_batch, starts[0],
-            min(starts[0] + utterances_per_batch, len(text_files))) \
+            min(starts[0] + utterances_per_batch, len(text_files)), 0) \
             if starts else None
         for position, first in enumerate(starts):
             opened, groups = opening.result()
@@ -292,7 +295,8 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
                 following = starts[position + 1]
                 opening = helpers.submit(
                     open_batch, following,
-                    min(following + utterances_per_batch, len(text_files)))
+                    min(following + utterances_per_batch, len(text_files)),
+                    position + 1)
             jobs = [(session.submit(picked, audios, rate, batch_size,
                                     plan=plan),
                      opened, chosen, [first + i for i in chosen])

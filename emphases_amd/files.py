@@ -66,6 +66,7 @@ class FileAudio:
         self.shape = (int(samples),)
         self.dtype = dtype
         self.rate = int(rate)
+        self.staged = None      # byte offset in `batch.staging` once read
 
     def dim(self):
         return 1
@@ -110,6 +111,8 @@ class FileBatch:
             self._handle, self.times.ctypes.data, None, None, None, None,
             None, None, None, None), 'emph_files_alignments')
         self._labels = None
+        self._audios = [None] * self.count
+        self.staging = None
 
     def close(self):
         if self._handle:
@@ -209,13 +212,47 @@ class FileBatch:
         files, else what `load.wav(file, raw=True)` returns."""
         if self.status[index] & 2:
             return load.wav(self.audio_files[index], raw=True)   # raises
+        if self._audios[index] is not None:
+            return self._audios[index], self._audios[index].rate
         _, _, _, _, _, code, channels, rate, bits, _, nbytes, _ = \
-            self.sizes[index]
+            self.sizes[index].tolist()
         if channels == 1 and (code, bits) in ((1, 16), (3, 32)):
             dtype = torch.int16 if code == 1 else torch.float32
-            return FileAudio(self, index, nbytes // (bits // 8), dtype,
-                             rate), int(rate)
+            self._audios[index] = FileAudio(
+                self, index, nbytes // (bits // 8), dtype, rate)
+            return self._audios[index], int(rate)
         return load.wav(self.audio_files[index], raw=True)
+
+    def read_all(self, staging):
+        """Read the samples of every `FileAudio` of the batch back to back
+        into `staging` (a pinned uint8 tensor, on whatever thread): the
+        session then sends them to the device straight from there
+        (`Session` needs no copy of its own).  Returns the bytes used."""
+        members = [audio for audio in self._audios if audio is not None]
+        nbytes = [audio.shape[0] * (2 if audio.dtype == torch.int16 else 4)
+                  for audio in members]
+        where = np.concatenate([[0], np.cumsum(
+            [(n + 3) // 4 * 4 for n in nbytes])]).astype(np.int64)
+        if int(where[-1]) > staging.numel():
+            raise ValueError('staging buffer too small')
+        if members:
+            self.read([audio.index for audio in members], where[:-1], nbytes,
+                      staging.data_ptr())
+        for audio, offset in zip(members, where[:-1]):
+            audio.staged = int(offset)
+        self.staging = staging
+        return int(where[-1])
+
+    def audio_bytes(self):
+        """Bytes `read_all` needs (every file's samples, 4-byte aligned)."""
+        total = 0
+        for index in range(self.count):
+            audio = self.audio(index)[0] if not self.status[index] & 2 \
+                else None
+            if isinstance(audio, FileAudio):
+                total += (audio.shape[0] * (
+                    2 if audio.dtype == torch.int16 else 4) + 3) // 4 * 4
+        return total
 
     def read(self, indices, where, nbytes, destination):
         """Samples of files `indices` to host address `destination +

@@ -149,6 +149,27 @@ class _Lane:
         tensors among them take the copy path."""
         from . import runtime
         count = len(audios)
+        if all(not torch.is_tensor(audio) and audio.staged is not None
+               for audio in audios):
+            # already read into the batch's own pinned buffer (by the opener
+            # thread of core.files_to_scores): one DMA per run of files that
+            # sit back to back there
+            dtype = device_view.dtype
+            first = 0
+            for k in range(1, count + 1):
+                previous = audios[k - 1]
+                if k < count and audios[k].batch is previous.batch and \
+                        audios[k].staged == previous.staged + \
+                        lengths[k - 1] * item:
+                    continue
+                head = audios[first]
+                start, stop = int(offsets[first]), int(offsets[k])
+                source = head.batch.staging[
+                    head.staged:head.staged + (stop - start) * item]
+                device_view[start:stop].copy_(
+                    source.view(dtype), non_blocking=True)
+                first = k
+            return device_view
         base = host_view.data_ptr()
         pieces = max(1, min(4, count, int(offsets[-1]) * item // (8 << 20)))
         edges = np.linspace(0, count, pieces + 1).astype(int)
@@ -278,6 +299,7 @@ class Session:
         self._cursor = 0
         self._lock = threading.Lock()
         self._kernels = {}        # (rate, target) -> resampling kernel on the device
+        self._file_buffers = []   # pinned uint8 tensors for files.FileBatch.read_all
 
     def _resample(self, lane, audios, lengths, dtype, sample_rate,
                   target_rate=cfg.SAMPLE_RATE):
@@ -310,6 +332,21 @@ class Session:
             kernel.data_ptr(), orig, new, width, out.data_ptr(),
             runtime.stream()), 'emph_resample')
         return out, targets
+
+    def file_buffer(self, turn, nbytes):
+        """Pinned uint8 tensor number `turn % 3` of at least `nbytes` (three
+        rotate: one being read into, one in flight, one whose batch is being
+        finished); kept by the session, since pinning memory takes
+        milliseconds."""
+        while len(self._file_buffers) < 3:
+            self._file_buffers.append(None)
+        slot = turn % 3
+        buffer = self._file_buffers[slot]
+        if buffer is None or buffer.numel() < nbytes:
+            buffer = torch.empty(
+                max(nbytes, 1) * 5 // 4, dtype=torch.uint8).pin_memory()
+            self._file_buffers[slot] = buffer
+        return buffer
 
     def resample(self, audios, sample_rate, target_rate=cfg.SAMPLE_RATE,
                  on_device=False):

@@ -59,6 +59,10 @@ try:
     timed(session_module.Session, 'submit')
     timed(session_module.Pending, 'result')
     timed(session_module._Lane, 'stage')
+    from emphases_amd import batch as batch_module, engine as engine_module
+    timed(engine_module.Engine, 'prepare')
+    timed(engine_module.Engine, 'upload')
+    timed(engine_module.Engine, 'forward')
     def cpu_stat():
         try:
             return dict(line.split() for line in open('/sys/fs/cgroup/cpu.stat'))
