@@ -879,7 +879,7 @@ def side_longform(device):
     return result
 
 
-def side_files_api(device, count=2048):
+def side_files_api(device, count=4096):
     """The drop-in surface itself (`emphases/core.py:115-179`): `count`
     synthetic 10 s utterances as 16-bit PCM .wav + .TextGrid files in
     /dev/shm, `emphases_amd.from_files_to_files` over all of them (read,

@@ -203,12 +203,15 @@ def _tiles(counts, offsets, block):
     counts = np.asarray(counts, dtype=np.int64)
     per_segment = (counts + block - 1) // block
     total = int(per_segment.sum())
-    segment = np.repeat(np.arange(len(counts), dtype=np.int64), per_segment)
+    segment = np.repeat(np.arange(len(counts), dtype=np.int32), per_segment)
     first = np.arange(total, dtype=np.int64) - np.repeat(
         np.cumsum(per_segment) - per_segment, per_segment)
-    return np.stack(
-        [segment, first * block, np.asarray(offsets, dtype=np.int64)[segment],
-         counts[segment]], axis=1).astype(np.int32)
+    table = np.empty((total, 4), dtype=np.int32)
+    table[:, 0] = segment
+    table[:, 1] = first * block
+    table[:, 2] = np.asarray(offsets, dtype=np.int64)[segment]
+    table[:, 3] = counts[segment]
+    return table
 
 
 class Plan:
@@ -478,17 +481,17 @@ class Plan:
         for request in tile_requests:
             pieces.append(
                 (('tiles',) + tuple(request), self.tiles(*request).ravel()))
+        # one output array, every piece copied once, 16-byte aligned starts
         offsets = {}
         cursor = 0
-        chunks = []
         for name, array in pieces:
             offsets[name] = (cursor, array.size)
-            padded = _round_up(max(array.size, 1), 4)
-            chunk = np.zeros(padded, dtype=np.int32)
-            chunk[:array.size] = array
-            chunks.append(chunk)
-            cursor += padded
-        return np.concatenate(chunks), offsets
+            cursor += _round_up(max(array.size, 1), 4)
+        packed = np.zeros(cursor, dtype=np.int32)
+        for name, array in pieces:
+            start, size = offsets[name]
+            packed[start:start + size] = array
+        return packed, offsets
 
 
 class Pieces:

@@ -233,9 +233,9 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
     library or numpy routines that leave the interpreter lock alone):
 
         opener   batch i + 1: open + parse + header walk (`files.FileBatch`),
-                 plan (`batch.plan_batch`) and the batch's metadata tables
-                 (`Engine.prepare`)
-        caller   batch i: samples -> pinned staging -> device, kernels
+                 the samples into a pinned buffer of the session
+                 (`read_all`), the plan (`batch.plan_batch`)
+        caller   batch i: metadata tables (`Engine.prepare`), DMA + kernels
                  (`Session.submit`), then the scores of batch i - 1
         writer   batch i - 1: `<prefix>.TextGrid` + `<prefix>.pt`"""
     import concurrent.futures
@@ -246,8 +246,8 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
         torch.set_num_threads(1)        # (this thread's OpenMP setting too)
         opened = files.FileBatch(
             text_files[first:last], audio_files[first:last])
-        alignments = [opened.alignment(i) for i in range(last - first)]
-        loaded = [opened.audio(i) for i in range(last - first)]
+        alignments = opened.all_alignments()
+        loaded = opened.all_audios()
         # the samples: straight into one of the session's pinned buffers
         with torch.cuda.device(session.engine.device):
             opened.read_all(session.file_buffer(turn, opened.audio_bytes()))
@@ -259,8 +259,8 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
             plan = None
             if rate == cfg.SAMPLE_RATE and all(
                     a.dim() == 1 or a.shape[0] == 1 for a in audios):
-                plan = engine.prepare(batch.plan_batch(
-                    picked, [int(a.shape[-1]) for a in audios], batch_size))
+                plan = batch.plan_batch(
+                    picked, [int(a.shape[-1]) for a in audios], batch_size)
             groups.append((rate, chosen, picked, audios, plan))
         return opened, groups
 
@@ -297,8 +297,9 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
                     open_batch, following,
                     min(following + utterances_per_batch, len(text_files)),
                     position + 1)
-            jobs = [(session.submit(picked, audios, rate, batch_size,
-                                    plan=plan),
+            jobs = [(session.submit(
+                picked, audios, rate, batch_size,
+                plan=None if plan is None else engine.prepare(plan)),
                      opened, chosen, [first + i for i in chosen])
                     for rate, chosen, picked, audios, plan in groups]
             finish(in_flight)

@@ -223,6 +223,35 @@ class FileBatch:
             return self._audios[index], int(rate)
         return load.wav(self.audio_files[index], raw=True)
 
+    def all_alignments(self):
+        """`alignment(i)` for every file, without per-file numpy work."""
+        first = self.word_first.tolist()
+        bad = (self.status & 1).tolist()
+        times, lazy = self.times, alignment_module.Alignment.lazy
+        return [
+            self.alignment(i) if bad[i] else lazy(
+                times[first[i]:first[i + 1]],
+                lambda i=i: (self.words(i), self.tiers(i)))
+            for i in range(self.count)]
+
+    def all_audios(self):
+        """`audio(i)` for every file: `[(FileAudio | tensor, rate)]`."""
+        rows = self.sizes.tolist()
+        result = []
+        for index, row in enumerate(rows):
+            status, code, channels, rate, bits, nbytes = \
+                row[0], row[5], row[6], row[7], row[8], row[10]
+            if status & 2 or channels != 1 or \
+                    (code, bits) not in ((1, 16), (3, 32)):
+                result.append(self.audio(index))
+                continue
+            if self._audios[index] is None:
+                self._audios[index] = FileAudio(
+                    self, index, nbytes // (bits // 8),
+                    torch.int16 if code == 1 else torch.float32, rate)
+            result.append((self._audios[index], rate))
+        return result
+
     def read_all(self, staging):
         """Read the samples of every `FileAudio` of the batch back to back
         into `staging` (a pinned uint8 tensor, on whatever thread): the
@@ -245,14 +274,11 @@ class FileBatch:
 
     def audio_bytes(self):
         """Bytes `read_all` needs (every file's samples, 4-byte aligned)."""
-        total = 0
-        for index in range(self.count):
-            audio = self.audio(index)[0] if not self.status[index] & 2 \
-                else None
-            if isinstance(audio, FileAudio):
-                total += (audio.shape[0] * (
-                    2 if audio.dtype == torch.int16 else 4) + 3) // 4 * 4
-        return total
+        sizes = self.sizes
+        native = ((sizes[:, 0] & 2) == 0) & (sizes[:, 6] == 1) & (
+            ((sizes[:, 5] == 1) & (sizes[:, 8] == 16)) |
+            ((sizes[:, 5] == 3) & (sizes[:, 8] == 32)))
+        return int(((sizes[native, 10] + 3) // 4 * 4).sum())
 
     def read(self, indices, where, nbytes, destination):
         """Samples of files `indices` to host address `destination +

@@ -51,7 +51,7 @@ try:
             synth.word_frames(3000 + index, 1000)).save(text)
         texts.append(text), waves.append(wave)
         prefixes.append(os.path.join(directory, f'o{index}'))
-    emphases_amd.from_files_to_files(texts[:512], waves[:512], prefixes[:512], gpu=0)
+    emphases_amd.from_files_to_files(texts[:1024], waves[:1024], prefixes[:1024], gpu=0, utterances_per_batch=int(os.environ.get('PER_BATCH', 256)))
     from emphases_amd import session as session_module
     timed(files.FileBatch, '__init__')
     timed(files.FileBatch, 'read')
@@ -74,7 +74,7 @@ try:
           'process threads', len(os.listdir('/proc/self/task')))
     before = cpu_stat()
     start = time.perf_counter()
-    emphases_amd.from_files_to_files(texts, waves, prefixes, gpu=0)
+    emphases_amd.from_files_to_files(texts, waves, prefixes, gpu=0, utterances_per_batch=int(os.environ.get('PER_BATCH', 256)))
     total = time.perf_counter() - start
     after = cpu_stat()
     print('  cgroup:', {k: int(after[k]) - int(before[k]) for k in after
