@@ -259,7 +259,15 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
                     for (int j = 0; j < 6; ++j)
 #pragma unroll
                         for (int m = 0; m < COUNT; ++m)
+#ifdef STACK_FEWER_A_READS         // (micro-benchmark only: what the LDS reads between MFMAs cost)
+                            a[j][m] = (j & 1) ? a[j - 1][m]
+                                              : weights[(ks * 6 * kStackMTiles + j * kStackMTiles + m) << 6];
+#else
                             a[j][m] = weights[(ks * 6 * kStackMTiles + j * kStackMTiles + m) << 6];
+#endif
+#ifdef STACK_NO_TRANSFORM          // (micro-benchmark only: what the vector work costs)
+                    for (int j = 0; j < 6; ++j) v[j] = d[j];
+#else
                     // v = B^T d (conv_w4.hip: the same operations in the same order)
                     const float p = fmaf(-4.f, d[2], d[4]);
                     const float q = fmaf(-4.f, d[1], d[3]);
@@ -271,6 +279,7 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
                     v[3] = c + e;
                     v[4] = c - e;
                     v[5] = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+#endif
                     if (step + 1 < kStackSteps) load_b(step + 1);
 #pragma unroll
                     for (int j = 0; j < 6; ++j)
