@@ -564,7 +564,8 @@ int emph_add_position(float* x, int64_t ldx, const float* table,
  *              staged ONCE per workgroup in LDS (long segments: the frame axis);
  *              workgroups walk the (head, tile) space in XCD order, so that
  *              the tiles of a segment share one XCD's L2;
- *          512: the same with sixteen waves (keys / values staged once per 512
+ *          512 (EXPERIMENTAL: measured, not used by the engine, DESIGN.md
+ *          section 4): the same with sixteen waves (keys / values staged once per 512
  *              queries; one workgroup per CU: 1 % faster alone, 1 % slower
  *              with two batches in flight - the engine uses 256)
  *   key_counts int32 [n_seg] or NULL  src_key_padding_mask (transformer.py:

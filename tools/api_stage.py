@@ -1,5 +1,5 @@
 """Public-API call latency percentiles on the bench workload and the share of the host gather:
-python tools/api_stage.py   (EMPHASES_COPY_STREAM=0: plain memcpy in the gather; CALLS=n)"""
+python tools/api_stage.py   (CALLS=n; the gather's streaming stores are hard-wired since round 3)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
