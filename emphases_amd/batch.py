@@ -197,20 +197,21 @@ def _round_up(value, multiple):
     return (value + multiple - 1) // multiple * multiple
 
 
-def _tiles(counts, offsets, block):
+def _tiles(counts, offsets, block, least=0, most=1 << 62):
     """Tile table int32 [n, 4]: (segment, first position, segment's first
-    column, segment's positions) of every `block`-wide tile."""
-    counts = np.asarray(counts, dtype=np.int64)
-    per_segment = (counts + block - 1) // block
-    total = int(per_segment.sum())
-    segment = np.repeat(np.arange(len(counts), dtype=np.int32), per_segment)
-    first = np.arange(total, dtype=np.int64) - np.repeat(
-        np.cumsum(per_segment) - per_segment, per_segment)
-    table = np.empty((total, 4), dtype=np.int32)
-    table[:, 0] = segment
-    table[:, 1] = first * block
-    table[:, 2] = np.asarray(offsets, dtype=np.int64)[segment]
-    table[:, 3] = counts[segment]
+    column, segment's positions) of every `block`-wide tile of the segments
+    with `least <= count <= most` (`emph_plan_tiles`, host arithmetic in the
+    library; tests/plan_reference.py holds the numpy restatement)."""
+    lib = runtime.library()
+    counts = np.ascontiguousarray(counts, dtype=np.int64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    rows = lib.emph_plan_tiles(
+        counts.ctypes.data, offsets.ctypes.data, len(counts), block, least,
+        most, None)
+    table = np.empty((rows, 4), dtype=np.int32)
+    lib.emph_plan_tiles(
+        counts.ctypes.data, offsets.ctypes.data, len(counts), block, least,
+        most, table.ctypes.data)
     return table
 
 
@@ -322,9 +323,12 @@ class Plan:
         if least is not None:
             key = (axis, block, least, most)
             if key not in self._tiles:
-                rows = self.tiles(axis, block)
-                keep = (rows[:, 3] >= least) & (rows[:, 3] <= most)
-                self._tiles[key] = np.ascontiguousarray(rows[keep])
+                if axis == runtime.AXIS_FRAMES:
+                    self._tiles[key] = _tiles(
+                        self.frames, self.frame_off, block, least, most)
+                else:
+                    self._tiles[key] = _tiles(
+                        self.words, self.word_off, block, least, most)
             return self._tiles[key]
         key = (axis, block)
         if key not in self._tiles:
@@ -392,60 +396,44 @@ class Plan:
         column -> row of the sums buffer, -1), `terms` (signed rows: r adds,
         ~r subtracts; a word's terms part by part, plus before minus),
         `first` [ld_words + 1] (CSR over packed word columns), `lengths`
-        [ld_words] (e - s; -1 on alignment padding columns), and `n_slots`."""
+        [ld_words] (e - s; -1 on alignment padding columns), and `n_slots`.
+        Built by the library (`emph_plan_word_sums`: two passes over the
+        words; tests/plan_reference.py holds the numpy restatement)."""
         key = ('word_sums', None if restarts is None else restarts.tobytes())
         cached = self._tiles.get(key)
         if cached is not None:
             return cached
         if restarts is None:
             restarts = self.sum_restarts()
-        restarts = np.asarray(restarts, dtype=np.int64)
-        count = len(self.frames)
-        total = self.total_words
-        segment = np.repeat(np.arange(count, dtype=np.int64), self.words)
-        limit = self.frames[segment] if total else np.zeros(0, dtype=np.int64)
-        raw = self.segment_bounds.astype(np.int64)
-        start = np.clip(raw[0], 0, limit)
-        end = np.maximum(np.clip(raw[1], 0, limit), start)
-        column = self.frame_off[segment] if total else start
-        begin, stop = column + start, column + end
-        # the restarts strictly inside (begin, stop) cut the word
-        inner_lo = np.searchsorted(restarts, begin, side='right')
-        inner_hi = np.searchsorted(restarts, stop, side='left')
-        parts = np.where(end > start, inner_hi - inner_lo + 1, 0)
-        word = np.repeat(np.arange(total, dtype=np.int64), parts)
-        part_first = np.cumsum(parts) - parts
-        k = np.arange(int(parts.sum()), dtype=np.int64) - part_first[word]
-        cut = inner_lo[word] + k                    # index of the part's END restart
-        a = np.where(k == 0, begin[word],
-                     restarts[np.clip(cut - 1, 0, max(len(restarts) - 1, 0))])
-        b = np.where(k == parts[word] - 1, stop[word],
-                     restarts[np.clip(cut, 0, max(len(restarts) - 1, 0))])
-        at = np.searchsorted(restarts, a, side='left')
-        is_restart = (at < len(restarts)) & (
-            restarts[np.clip(at, 0, max(len(restarts) - 1, 0))] == a)
-        plus = b - 1
-        has_minus = ~is_restart
-        minus = a - 1
-        marked = np.unique(np.concatenate([plus, minus[has_minus]]))
-        slot_map = np.full(self.ld_frames, -1, dtype=np.int32)
-        slot_map[marked] = np.arange(len(marked), dtype=np.int32)
-        per_part = 1 + has_minus.astype(np.int64)
-        where = np.cumsum(per_part) - per_part
-        terms = np.zeros(int(per_part.sum()), dtype=np.int32)
-        terms[where] = slot_map[plus]
-        terms[where[has_minus] + 1] = ~slot_map[minus[has_minus]]
-        per_word = np.bincount(word, weights=per_part, minlength=total).astype(
-            np.int64) if total else np.zeros(0, dtype=np.int64)
-        per_column = np.zeros(self.ld_words + 1, dtype=np.int64)
-        lengths = np.full(self.ld_words, -1, dtype=np.int32)
-        if total:
-            per_column[self._columns + 1] = per_word
-            lengths[self._columns] = (end - start).astype(np.int32)
+        import ctypes
+        lib = runtime.library()
+        restarts = np.ascontiguousarray(restarts, dtype=np.int64)
+        frames = np.ascontiguousarray(self.frames, dtype=np.int64)
+        frame_off = np.ascontiguousarray(self.frame_off, dtype=np.int64)
+        words = np.ascontiguousarray(self.words, dtype=np.int64)
+        columns = np.ascontiguousarray(self._columns, dtype=np.int64)
+        bounds = np.ascontiguousarray(self.segment_bounds, dtype=np.int64)
+        slot_map = np.empty(self.ld_frames, dtype=np.int32)
+        first = np.empty(self.ld_words + 1, dtype=np.int32)
+        lengths = np.empty(self.ld_words, dtype=np.int32)
+        # (two terms per part; a word has 1 + restarts-inside-it parts)
+        terms = np.empty(4 * self.total_words + 2 * len(restarts) + 8,
+                         dtype=np.int32)
+        slots = ctypes.c_int32(0)
+        for _ in range(2):
+            count = lib.emph_plan_word_sums(
+                frames.ctypes.data, frame_off.ctypes.data, words.ctypes.data,
+                len(frames), columns.ctypes.data, bounds.ctypes.data,
+                self.total_words, restarts.ctypes.data, len(restarts),
+                self.ld_frames, self.ld_words, slot_map.ctypes.data,
+                first.ctypes.data, lengths.ctypes.data, terms.ctypes.data,
+                terms.size, ctypes.byref(slots))
+            if count >= 0:
+                break
+            terms = np.empty(-count, dtype=np.int32)
         tables = {
-            'slot_map': slot_map, 'terms': terms,
-            'first': np.cumsum(per_column).astype(np.int32),
-            'lengths': lengths, 'n_slots': int(len(marked))}
+            'slot_map': slot_map, 'terms': terms[:count].copy(),
+            'first': first, 'lengths': lengths, 'n_slots': int(slots.value)}
         self._tiles[key] = tables
         return tables
 

@@ -1054,3 +1054,116 @@ int emph_files_write(const emph_file_batch* batch, const int32_t* which,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Integer tables of a batch plan (emphases_amd/batch.py builds the same arrays
+// with numpy; at a few hundred utterances per batch their construction was the
+// largest piece of host time of a call that brings a layout never seen before)
+// ---------------------------------------------------------------------------
+
+extern "C" {
+
+// Tile table int32 [n][4] = (segment, first position, segment's first column,
+// segment's positions) of every `block`-wide tile of every segment whose count
+// lies in [least, most]; host_tiles == NULL: returns the number of rows.
+int64_t emph_plan_tiles(const int64_t* host_counts, const int64_t* host_offsets,
+                        int32_t n_segments, int32_t block, int64_t least, int64_t most,
+                        int32_t* host_tiles) {
+    int64_t rows = 0;
+    for (int32_t segment = 0; segment < n_segments; ++segment) {
+        const int64_t count = host_counts[segment];
+        if (count < least || count > most) continue;
+        for (int64_t first = 0; first < count; first += block) {
+            if (host_tiles != nullptr) {
+                int32_t* row = host_tiles + 4 * rows;
+                row[0] = segment;
+                row[1] = static_cast<int32_t>(first);
+                row[2] = static_cast<int32_t>(host_offsets[segment]);
+                row[3] = static_cast<int32_t>(count);
+            }
+            ++rows;
+        }
+    }
+    return rows;
+}
+
+// The tables of the folded per-word sum (batch.Plan.word_sum_tables):
+//   frames, frame_off  per segment; words per segment; word_columns[total_words]
+//   the packed word column of every word; bounds int64 [2][total_words]
+//   (chunk-relative, unclamped); restarts: sorted packed frame columns at which
+//   the running sum restarts (every segment's first column among them)
+// Outputs (host): slot_map int32 [ld_frames] (filled here, -1 elsewhere),
+//   first int32 [ld_words + 1], lengths int32 [ld_words] (-1 on padding columns),
+//   terms int32 [capacity]; returns the number of terms (or -(needed) when
+//   `capacity` is too small - two terms per part at most), *n_slots the rows of
+//   the running-sum buffer.
+int64_t emph_plan_word_sums(const int64_t* frames, const int64_t* frame_off,
+                            const int64_t* words, int32_t n_segments,
+                            const int64_t* word_columns, const int64_t* bounds,
+                            int64_t total_words, const int64_t* restarts, int64_t n_restarts,
+                            int64_t ld_frames, int64_t ld_words, int32_t* slot_map,
+                            int32_t* first, int32_t* lengths, int32_t* terms, int64_t capacity,
+                            int32_t* n_slots) {
+    for (int64_t i = 0; i < ld_frames; ++i) slot_map[i] = -1;
+    for (int64_t i = 0; i < ld_words; ++i) lengths[i] = -1;
+    for (int64_t i = 0; i <= ld_words; ++i) first[i] = 0;
+    // pass 1: the frames whose running sum somebody needs (0 marks, for now)
+    int64_t needed = 0;
+    auto walk = [&](auto&& emit) {
+        int64_t word = 0, cut = 0;
+        for (int32_t segment = 0; segment < n_segments; ++segment) {
+            const int64_t limit = frames[segment], column = frame_off[segment];
+            for (int64_t k = 0; k < words[segment]; ++k, ++word) {
+                int64_t start = bounds[word], end = bounds[total_words + word];
+                start = start < 0 ? 0 : (start > limit ? limit : start);
+                end = end < 0 ? 0 : (end > limit ? limit : end);
+                if (end < start) end = start;
+                emit(word, -1, static_cast<int32_t>(end - start), 0);
+                if (end <= start) continue;
+                const int64_t begin = column + start, stop = column + end;
+                // the first restart strictly behind `begin` (restarts are sorted;
+                // words of a segment mostly move forward, but need not)
+                while (cut < n_restarts && restarts[cut] <= begin) ++cut;
+                while (cut > 0 && restarts[cut - 1] > begin) --cut;
+                int64_t a = begin;
+                bool at_restart = cut > 0 && restarts[cut - 1] == begin;
+                int64_t next = cut;
+                for (;;) {
+                    const bool last = next >= n_restarts || restarts[next] >= stop;
+                    const int64_t b = last ? stop : restarts[next];
+                    emit(word, b - 1, 0, +1);
+                    if (!at_restart) emit(word, a - 1, 0, -1);
+                    if (last) break;
+                    a = b;
+                    at_restart = true;
+                    ++next;
+                }
+            }
+        }
+    };
+    walk([&](int64_t word, int64_t frame_column, int32_t length, int sign) {
+        if (sign == 0) {
+            lengths[word_columns[word]] = length;
+            return;
+        }
+        slot_map[frame_column] = 0;
+        first[word_columns[word] + 1] += 1;
+        ++needed;
+    });
+    int32_t slots = 0;
+    for (int64_t i = 0; i < ld_frames; ++i)
+        if (slot_map[i] == 0) slot_map[i] = slots++;
+    *n_slots = slots;
+    for (int64_t i = 0; i < ld_words; ++i) first[i + 1] += first[i];
+    if (needed > capacity) return -needed;
+    // pass 2: the terms, a word's parts in order, plus before minus
+    std::vector<int32_t> cursor(first, first + ld_words);
+    walk([&](int64_t word, int64_t frame_column, int32_t, int sign) {
+        if (sign == 0) return;
+        const int32_t slot = slot_map[frame_column];
+        terms[cursor[word_columns[word]]++] = sign > 0 ? slot : ~slot;
+    });
+    return needed;
+}
+
+}  // extern "C"

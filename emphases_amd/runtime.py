@@ -119,6 +119,10 @@ SIGNATURES = {
         _ptr, _ptr, _ptr, _ptr, _i32, _ptr, _i32]),
     'emph_files_write': (_c.c_int, [
         _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32]),
+    'emph_plan_tiles': (_i64, [_ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),
+    'emph_plan_word_sums': (_i64, [
+        _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64,
+        _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),
     'emph_gather_columns': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _i32, _ptr, _i32, _ptr]),
     'emph_word_decoder_block': (_i32, [_i32, _i32, _i32]),

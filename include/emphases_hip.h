@@ -172,6 +172,28 @@ int emph_files_write(const emph_file_batch* batch, const int32_t* which,
                      const char* const* prefixes, const float* scores,
                      const int64_t* first, int32_t count, int32_t threads);
 
+/* Integer tables of a batch plan built on the host (what emphases_amd/batch.py
+ * builds with numpy; host arithmetic on the segment lengths and word bounds
+ * of emphases.preprocess, emphases/core.py:345-418).
+ * emph_plan_tiles: the tile table int32 [rows][4] of an axis for `block`-wide
+ * tiles of the segments with least <= count <= most (host_tiles NULL: returns
+ * the number of rows).
+ * emph_plan_word_sums: the tables of the folded per-word sum for running sums
+ * that restart at the sorted frame columns `restarts` (see
+ * emph_conv1d_stack / emph_word_sums); returns the number of terms, or
+ * -(needed) when `capacity` is too small. */
+int64_t emph_plan_tiles(const int64_t* host_counts, const int64_t* host_offsets,
+                        int32_t n_segments, int32_t block, int64_t least,
+                        int64_t most, int32_t* host_tiles);
+int64_t emph_plan_word_sums(const int64_t* frames, const int64_t* frame_off,
+                            const int64_t* words, int32_t n_segments,
+                            const int64_t* word_columns, const int64_t* bounds,
+                            int64_t total_words, const int64_t* restarts,
+                            int64_t n_restarts, int64_t ld_frames,
+                            int64_t ld_words, int32_t* slot_map, int32_t* first,
+                            int32_t* lengths, int32_t* terms, int64_t capacity,
+                            int32_t* n_slots);
+
 /* ------------------------------------------------------------------------ */
 /* Front-end: framed log-mel (+ optional A-weighted loudness row)            */
 /* ------------------------------------------------------------------------ */

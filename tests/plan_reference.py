@@ -1,0 +1,78 @@
+"""numpy restatements of the plan tables the library builds on the host
+(`emph_plan_tiles`, `emph_plan_word_sums`): TEST INFRASTRUCTURE - the product
+(`emphases_amd/batch.py`) calls the library; tests/test_host.py holds the two
+against each other bit for bit."""
+import numpy as np
+
+
+def tiles(counts, offsets, block):
+    """Tile table int32 [n, 4]: (segment, first position, segment's first
+    column, segment's positions) of every `block`-wide tile."""
+    counts = np.asarray(counts, dtype=np.int64)
+    per_segment = (counts + block - 1) // block
+    total = int(per_segment.sum())
+    segment = np.repeat(np.arange(len(counts), dtype=np.int32), per_segment)
+    first = np.arange(total, dtype=np.int64) - np.repeat(
+        np.cumsum(per_segment) - per_segment, per_segment)
+    table = np.empty((total, 4), dtype=np.int32)
+    table[:, 0] = segment
+    table[:, 1] = first * block
+    table[:, 2] = np.asarray(offsets, dtype=np.int64)[segment]
+    table[:, 3] = counts[segment]
+    return table
+
+
+def word_sum_tables(plan, restarts):
+    """`Plan.word_sum_tables(restarts)` with numpy: every word [s, e) (clamped
+    to its chunk) is cut at the restarts strictly inside it into parts [a, b):
+    + running sum at frame b - 1, - running sum at frame a - 1 unless a is
+    itself a restart."""
+    self = plan
+    restarts = np.asarray(restarts, dtype=np.int64)
+    count = len(self.frames)
+    total = self.total_words
+    segment = np.repeat(np.arange(count, dtype=np.int64), self.words)
+    limit = self.frames[segment] if total else np.zeros(0, dtype=np.int64)
+    raw = self.segment_bounds.astype(np.int64)
+    start = np.clip(raw[0], 0, limit)
+    end = np.maximum(np.clip(raw[1], 0, limit), start)
+    column = self.frame_off[segment] if total else start
+    begin, stop = column + start, column + end
+    # the restarts strictly inside (begin, stop) cut the word
+    inner_lo = np.searchsorted(restarts, begin, side='right')
+    inner_hi = np.searchsorted(restarts, stop, side='left')
+    parts = np.where(end > start, inner_hi - inner_lo + 1, 0)
+    word = np.repeat(np.arange(total, dtype=np.int64), parts)
+    part_first = np.cumsum(parts) - parts
+    k = np.arange(int(parts.sum()), dtype=np.int64) - part_first[word]
+    cut = inner_lo[word] + k                    # index of the part's END restart
+    a = np.where(k == 0, begin[word],
+                 restarts[np.clip(cut - 1, 0, max(len(restarts) - 1, 0))])
+    b = np.where(k == parts[word] - 1, stop[word],
+                 restarts[np.clip(cut, 0, max(len(restarts) - 1, 0))])
+    at = np.searchsorted(restarts, a, side='left')
+    is_restart = (at < len(restarts)) & (
+        restarts[np.clip(at, 0, max(len(restarts) - 1, 0))] == a)
+    plus = b - 1
+    has_minus = ~is_restart
+    minus = a - 1
+    marked = np.unique(np.concatenate([plus, minus[has_minus]]))
+    slot_map = np.full(self.ld_frames, -1, dtype=np.int32)
+    slot_map[marked] = np.arange(len(marked), dtype=np.int32)
+    per_part = 1 + has_minus.astype(np.int64)
+    where = np.cumsum(per_part) - per_part
+    terms = np.zeros(int(per_part.sum()), dtype=np.int32)
+    terms[where] = slot_map[plus]
+    terms[where[has_minus] + 1] = ~slot_map[minus[has_minus]]
+    per_word = np.bincount(word, weights=per_part, minlength=total).astype(
+        np.int64) if total else np.zeros(0, dtype=np.int64)
+    per_column = np.zeros(self.ld_words + 1, dtype=np.int64)
+    lengths = np.full(self.ld_words, -1, dtype=np.int32)
+    if total:
+        per_column[self._columns + 1] = per_word
+        lengths[self._columns] = (end - start).astype(np.int32)
+    tables = {
+        'slot_map': slot_map, 'terms': terms,
+        'first': np.cumsum(per_column).astype(np.int32),
+        'lengths': lengths, 'n_slots': int(len(marked))}
+    return tables

@@ -968,3 +968,45 @@ def test_file_batch_reports_bad_files_like_the_python_readers(tmp_path):
     assert torch.is_tensor(audio) and audio.shape == (2, 200)
     with pytest.raises(ValueError):
         opened.audio(5)
+
+
+def test_plan_tables_of_the_library_match_numpy():
+    """emph_plan_tiles / emph_plan_word_sums (host arithmetic in the library,
+    what `batch.Plan` calls) against the numpy restatement in
+    tests/plan_reference.py, bit for bit, on ragged plans whose bounds stress
+    the tables: empty words, ends and starts beyond the chunk, overlapping
+    words, words over many restarts, one-frame segments; both restart schemes
+    (64-frame tiles, the conv stack's spans); filtered tile tables."""
+    import plan_reference
+    from emphases_amd import runtime
+    rng = np.random.default_rng(11)
+    frames = [1000, 37, 130, 64, 65, 1, 447, 256, 257, 3000, 505]
+    segments = []
+    for index, n in enumerate(frames):
+        starts = np.sort(rng.integers(0, n + 1, size=max(2, n // 9)))
+        ends = np.minimum(starts + rng.integers(0, 300, size=starts.size), n + 40)
+        ends[0] = starts[0]
+        starts[-1], ends[-1] = n + 3, n + 9
+        bounds = np.stack([starts, ends]).astype(np.int64)
+        segments.append(batch.Segment(index, 0, bounds.shape[1], 432, n * 160,
+                                      n, bounds))
+    plan = batch.Plan(segments, [0] * len(frames), [0] * len(frames))
+    for block in (8, 16, 64, 256):
+        assert np.array_equal(
+            plan.tiles(runtime.AXIS_FRAMES, block),
+            plan_reference.tiles(plan.frames, plan.frame_off, block))
+        whole = plan_reference.tiles(plan.words, plan.word_off, block)
+        assert np.array_equal(plan.tiles(runtime.AXIS_WORDS, block), whole)
+        keep = (whole[:, 3] >= 5) & (whole[:, 3] <= 60)
+        assert np.array_equal(
+            plan.tiles(runtime.AXIS_WORDS, block, 5, 60), whole[keep])
+    for restarts in (plan.sum_restarts(),
+                     plan.sum_restarts(plan.conv_spans())):
+        got = plan.word_sum_tables(restarts)
+        want = plan_reference.word_sum_tables(plan, restarts)
+        assert got['n_slots'] == want['n_slots']
+        for name in ('slot_map', 'terms', 'first', 'lengths'):
+            assert got[name].dtype == np.int32
+            assert np.array_equal(got[name], want[name]), name
+    empty = batch.Plan([], [], [])
+    assert empty.word_sum_tables()['n_slots'] == 0
