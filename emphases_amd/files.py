@@ -20,6 +20,7 @@ with the same results; a file that cannot be read raises what those readers
 raise.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -27,8 +28,6 @@ import torch
 from . import alignment as alignment_module
 from . import load
 from . import runtime
-
-import os
 
 
 def _cpu_budget():
