@@ -14,15 +14,16 @@
 //
 //   * 256 computed positions = 4 MFMA column tiles of 16 quads = the span plus a
 //     halo of one quad on each side that continues inside the segment.  The
-//     halo is recomputed, 2.4 % more matrix work, instead of exchanged: a
+//     halo is recomputed, at most 2.4 % more matrix work, instead of exchanged: a
 //     cross-workgroup hand-off per layer costs more than the layer's ramp
 //     (MI355X_MICROARCH.md, inter-workgroup visibility).  Why three layers and
-//     not four: in F(4,3) the stale column beside the computed region reaches
-//     only ONE output of the edge quad in the first layer (d0 enters v0, m0, y0
-//     alone; d5 only y3), every output of that quad in the second - two of them
-//     only through rounding, the mathematically cancelling terms - and through
-//     d0 / d5 of the NEXT quad the span's own first / last position in the
-//     fourth: 6.6e-7 off the layer-by-layer result (measured).  Three layers
+//     not four: the launch's first layer is exact everywhere (the columns beside
+//     the computed region are loaded with it); in the SECOND the stale column
+//     reaches only ONE output of the edge quad (in F(4,3) d0 enters v0, m0, y0
+//     alone; d5 only y3), in the third every output of that quad - two of them
+//     only through rounding, the mathematically cancelling terms - and in a
+//     fourth, through d0 / d5 of the NEXT quad, the span's own first / last
+//     position: 6.6e-7 off the layer-by-layer result (measured).  Three layers
 //     are exact with one quad of halo; four would need two (240 own positions:
 //     a 10 s utterance would no longer be four spans);
 //   * activations [80][260] floats (83.2 KB) are updated in place: accumulators
