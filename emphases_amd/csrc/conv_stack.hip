@@ -101,105 +101,183 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
 
     constexpr int kPackFloats = kStackSteps * kStackStepFloats;
     const int total_chunks = layers * kStackChunks;
-    auto request = [&](int g) {               // loader waves: chunk g -> ring[g & 1]
+    // chunk g -> ring[g & 1]: 1920 16-byte quads, i.e. 30 wave requests, dealt over
+    // waves first .. first + n - 1 (n = 4: 8 each, n = 8: 4 each)
+    auto request = [&](int g, int first, int n) {
         const int layer = g / kStackChunks;
         const float* source = packs + static_cast<int64_t>(layer) * kPackFloats +
                               (g - layer * kStackChunks) * kStackChunkFloats;
         float* target = ring + (g & 1) * kStackChunkFloats;
-        // 1920 16-byte quads per chunk: 30 wave requests, dealt over the four loaders
-        for (int base = (wave - 8) * 64; base < kStackChunkFloats / 4; base += 4 * 64)
+        // (every wave the same number of requests, the waits below count them: the
+        // last of some waves repeats the chunk's last 1 KB)
+        constexpr int kQuads = kStackChunkFloats / 4;
+        const int each = (kQuads / 64 + n - 1) / n;
+        for (int k = 0; k < each; ++k) {
+            const int from = min(((wave - first) + k * n) * 64, kQuads - 64);
             __builtin_amdgcn_global_load_lds(
-                (const __attribute__((address_space(1))) void*)(source + 4 * (base + lane)),
-                (__attribute__((address_space(3))) void*)(target + 4 * base), 16, 0, 0);
+                (const __attribute__((address_space(1))) void*)(source + 4 * (from + lane)),
+                (__attribute__((address_space(3))) void*)(target + 4 * from), 16, 0, 0);
+        }
     };
     STACK_STAMP(0);
-    if (loader) {
-        request(0);
-        request(1);
-    }
 
     // ---- the layer-0 input of the computed positions, zeros outside the segment.
     // One 16-byte run per (row, quad), always ONE load from a readable address
     // (clamped to the segment's last quad) and masked by position - so a thread's
     // loads are all requested before the first is used (a global load is 1-2 us
-    // away on this chip) and their number is a constant.  The eight MFMA waves
-    // bring rows 0 .. 31, what the first two weight chunks multiply; the loader
-    // waves bring rows 32 .. 79 UNDER the K loop of those chunks (all CUs pulling
-    // their 82 KB at once is a 4 us burst at HBM speed: this hides 60 % of it).
+    // away on this chip) and their number is a constant.  All CUs pulling their
+    // 82 KB + two weight chunks at once is a 4 us burst at HBM speed, and the K
+    // loop needs only the first weight chunk and the 16 rows it multiplies to
+    // start: the eight MFMA waves request exactly those, FIRST (requests are
+    // served roughly in the order the CUs issue them); the loader waves request
+    // chunk 1 and rows 16 .. 79 behind them and hand the rows over in the order
+    // the chunks need them - rows 16 .. 31 under chunk 0, the rest under chunk 1.
     const int last_quad = (count - 1) & ~3;
     auto fetch = [&](int c, int q) {
         const int p = c0 + 4 * q;
-        const float4 v = *reinterpret_cast<const float4*>(
+#ifdef STACK_NO_ROWS               // (micro-benchmark only: the weight stream alone)
+        return make_float4(float(p), 0.f, 0.f, 0.f);
+#endif
+        return *reinterpret_cast<const float4*>(
             x + static_cast<int64_t>(c) * ldx + column + min(p, last_quad));
+    };
+    auto masked = [&](int q, const float4& v) {
+        const int p = c0 + 4 * q;
         return make_float4(p < count ? v.x : 0.f, p + 1 < count ? v.y : 0.f,
                            p + 2 < count ? v.z : 0.f, p + 3 < count ? v.w : 0.f);
     };
-    auto deposit = [&](int c, int q, const float4& v) {
+    auto deposit = [&](int c, int q, const float4& raw) {
+        const float4 v = masked(q, raw);
         float* target = act + c * kStackStride + 4 * q;
         target[1] = v.x;
         *reinterpret_cast<f32x2*>(target + 2) = f32x2{v.y, v.z};
         target[4] = v.w;
     };
-    constexpr int kEarlyRows = 32;
+    constexpr int kEarlyRows = 16;
     if (loader) {
-        constexpr int kLate = (kStackChannels - kEarlyRows) * 64 / 256;   // 12 per thread
-        static_assert(kLate == 12, "the s_waitcnt below counts these loads");
-        asm volatile("" ::: "memory");
-        float4 late[kLate];
+        // The loader waves' row loads and LDS writes are inline asm with explicit
+        // s_waitcnt: hipcc waits for vmcnt(0) at the first use of ANY load result
+        // while an LDS-DMA is outstanding (two kinds of events on one counter) and
+        // in front of every LDS access it can see behind one, which would turn the
+        // staged hand-over below into "wait for everything".  Straight-line code
+        // with a register set per stage: a loop would carry the registers of loads
+        // in flight around its back edge, where hipcc is free to copy them.
+        // vmcnt counts in order, so a wait is a position in the wave's issue order:
+        //   chunk 1 (8 requests) | rows of chunk 1 (5 loads) | rows of chunk 2 |
+        //   chunk 2 | rows of chunk 3 | chunk 3 | rows of chunk 4 | chunk 4
+        // Stage c (under chunk c - 1 of layer 0): request chunk c of the weights,
+        // ask for the rows chunk c + 1 multiplies, hand over the rows of chunk c,
+        // see chunk c land.  The barriers pair with the MFMA waves' (one per chunk,
+        // plus one per layer between the last read and the first write of the
+        // activations); layer 0's are the bare instruction (__syncthreads() waits
+        // for every load).
+        constexpr int kStage = 16 * 64 / 256;                    // 4 loads: the rows of a chunk
+        static_assert(kStage == 4, "the s_waitcnt below count these loads");
+        f32x4 rows[kStackChunks - 1][kStage];
+        float side[kStackChunks - 1];
         const int mine = threadIdx.x - 512;
+        const int q = mine & 63;
+        const int p = c0 + 4 * q;
+        const float* source = x + static_cast<int64_t>(mine >> 6) * ldx + column + min(p, last_quad);
+        const uint32_t target = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+            (__attribute__((address_space(3))) float*)(act + (mine >> 6) * kStackStride + 4 * q)));
+        // the columns beside the computed positions: threads 0 .. 63, a (row, kind)
+        // each; the others repeat kind 3, the row's zero padding
+        const int side_kind = mine < 64 ? (mine & 3) : 3;
+        const int side_p = side_kind == 0 ? c0 - 1 : c0 + kStackWidth + side_kind - 1;
+        const bool side_real = side_kind < 3 && side_p >= 0 && side_p < count;
+        const float* side_source = x + static_cast<int64_t>((mine >> 2) & 15) * ldx + column +
+                                   (side_real ? side_p : 0);
+        const uint32_t side_target = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(
+            (__attribute__((address_space(3))) float*)(
+                act + ((mine >> 2) & 15) * kStackStride +
+                (side_kind == 0 ? 0 : kStackWidth + side_kind))));
+        auto ask = [&](int chunk) {                              // rows 16 chunk + 4 round + (mine >> 6)
 #pragma unroll
-        for (int round = 0; round < kLate; ++round) {
-            const int index = mine + 256 * round;
-            late[round] = fetch(kEarlyRows + (index >> 6), index & 63);
-        }
-        STACK_STAMP(1);
-        // chunk g has landed -> barrier (everyone is also done with chunk g - 1,
-        // whose slot chunk g + 1 overwrites) -> request chunk g + 1; plus the one
-        // barrier per layer between the last read and the first write of the
-        // activations.  Chunks 0 and 1 were both requested up front (both slots
-        // are free at the start) IN FRONT of the twelve row loads: vmcnt counts
-        // in order, so "chunk 0 landed" is vmcnt(rows + requests of chunk 1) and
-        // "chunk 1 landed" is vmcnt(rows), the rows still in flight under the K
-        // loop of both; the barriers are the bare instruction (__syncthreads()
-        // would wait for everything).
-        if (wave - 8 < 2) __builtin_amdgcn_s_waitcnt(0x4F74);    // vmcnt(12 + 8)
-        else __builtin_amdgcn_s_waitcnt(0x4F73);                 // vmcnt(12 + 7)
-        STACK_STAMP(2);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_waitcnt(0x0F7C);                      // vmcnt(12)
-        STACK_STAMP(3);
-        __builtin_amdgcn_s_barrier();
-        request(2);
+            for (int round = 0; round < kStage; ++round) {
+                const float* address = source + static_cast<int64_t>(16 * chunk + 4 * round) * ldx;
+                asm volatile("global_load_dwordx4 %0, %1, off"
+                             : "=v"(rows[chunk - 1][round]) : "v"(address) : "memory");
+            }
+            const float* address = side_source + static_cast<int64_t>(16 * chunk) * ldx;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(side[chunk - 1]) : "v"(address) : "memory");
+        };
+        auto hand_over = [&](int chunk) {
 #pragma unroll
-        for (int round = 0; round < kLate; ++round) {
-            const int index = mine + 256 * round;
-            deposit(kEarlyRows + (index >> 6), index & 63, late[round]);
-        }
-        for (int g = 2; g < total_chunks; ++g) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+            for (int round = 0; round < kStage; ++round) {
+                const f32x4 raw = rows[chunk - 1][round];
+                const float first = p < count ? raw[0] : 0.f;
+                const f32x2 middle = {p + 1 < count ? raw[1] : 0.f, p + 2 < count ? raw[2] : 0.f};
+                const float last = p + 3 < count ? raw[3] : 0.f;
+                const uint32_t address = target + (16 * chunk + 4 * round) * (kStackStride * 4);
+                asm volatile(
+                    "ds_write_b32 %0, %1 offset:4\n\t"
+                    "ds_write_b64 %0, %2 offset:8\n\t"
+                    "ds_write_b32 %0, %3 offset:16"
+                    :
+                    : "v"(address), "v"(first), "v"(middle), "v"(last)
+                    : "memory");
+            }
+            const float beside = side_real ? side[chunk - 1] : 0.f;
+            const uint32_t address = side_target + 16 * chunk * (kStackStride * 4);
+            asm volatile("ds_write_b32 %0, %1" : : "v"(address), "v"(beside) : "memory");
+        };
+#define EMPH_ROWS_HERE(COUNT, STAGE)                                                        \
+    asm volatile("s_waitcnt vmcnt(" #COUNT ")"                                              \
+                 : "+v"(rows[STAGE][0]), "+v"(rows[STAGE][1]), "+v"(rows[STAGE][2]),        \
+                   "+v"(rows[STAGE][3]), "+v"(side[STAGE])::"memory")
+        request(1, 8, 4);
+        ask(1);
+        __builtin_amdgcn_s_barrier();                            // chunk 0 starts
+        ask(2);
+        EMPH_ROWS_HERE(5, 0);                                    // (and chunk 1, in front of them)
+        hand_over(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                            // chunk 1 starts
+        request(2, 8, 4);
+        ask(3);
+        EMPH_ROWS_HERE(13, 1);
+        hand_over(2);
+        asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                            // chunk 2 starts
+        request(3, 8, 4);
+        ask(4);
+        EMPH_ROWS_HERE(13, 2);
+        hand_over(3);
+        asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                            // chunk 3 starts
+        request(4, 8, 4);
+        EMPH_ROWS_HERE(8, 3);
+        hand_over(4);
+#undef EMPH_ROWS_HERE
+        for (int g = 4; g < total_chunks; ++g) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             STACK_STAMP(2 + 8 * (g / kStackChunks) + g % kStackChunks);
             __syncthreads();
-            if (g + 1 < total_chunks) request(g + 1);
+            if (g + 1 < total_chunks) request(g + 1, 8, 4);
             // (the MFMA waves' barrier in front of a layer's in-place update: every
             // layer but the launch's last)
             if ((g + 1) % kStackChunks == 0 && g + 1 < total_chunks) __syncthreads();
         }
         return;
     }
-    for (int index = threadIdx.x; index < layers * kStackChannels; index += 512)
-        bias_lds[index] = biases[index];
+    request(0, 0, 8);
     {
-        constexpr int kEarly = kEarlyRows * 64 / 512;                    // 4 per thread
+        // (every load in front of the first LDS write: that write waits for the DMA)
+        static_assert(kStackMaxLayers * kStackChannels <= 512, "one bias per thread");
+        const bool has_bias = threadIdx.x < layers * kStackChannels;
+        const float bias_value = has_bias ? biases[threadIdx.x] : 0.f;
+        constexpr int kEarly = kEarlyRows * 64 / 512;                    // 2 per thread
         float4 early[kEarly];
 #pragma unroll
         for (int round = 0; round < kEarly; ++round) {
             const int index = threadIdx.x + 512 * round;
             early[round] = fetch(index >> 6, index & 63);
         }
-        // the columns beside the computed positions, all 80 rows
+        // the columns beside the computed positions, these sixteen rows
         float side = 0.f;
         const int side_row = threadIdx.x >> 2, side_kind = threadIdx.x & 3;
-        if (side_row < kStackChannels) {
+        if (side_row < kEarlyRows) {
             const float* row = x + static_cast<int64_t>(side_row) * ldx + column;
             const int p = side_kind == 0 ? c0 - 1 : c0 + kStackWidth + side_kind - 1;
             if (side_kind < 3 && p >= 0 && p < count) side = row[p];
@@ -209,8 +287,9 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
             const int index = threadIdx.x + 512 * round;
             deposit(index >> 6, index & 63, early[round]);
         }
-        if (side_row < kStackChannels)
+        if (side_row < kEarlyRows)
             act[side_row * kStackStride + (side_kind == 0 ? 0 : kStackWidth + side_kind)] = side;
+        if (has_bias) bias_lds[threadIdx.x] = bias_value;
     }
     STACK_STAMP(1);
 
@@ -247,9 +326,9 @@ __global__ __launch_bounds__(kStackThreads) void conv1d_stack_kernel(
                 // part of this layer's input)
                 __syncthreads();
                 STACK_STAMP(2 + 8 * layer + chunk);
-                // (the launch's input rows 32 .. 79 arrive under chunks 0 and 1: what
-                // k-step 7 prefetched of row 32 may predate them - read it again)
-                if (chunk == 0 || (layer == 0 && chunk == 2)) load_b(chunk * kStackChunkSteps);
+                // (the launch's input rows 16 c .. 16 c + 15 arrive under chunk c - 1,
+                // whose last k-step prefetched what may predate them - read it again)
+                if (chunk == 0 || layer == 0) load_b(chunk * kStackChunkSteps);
                 const float* weights =
                     ring + ((layer * kStackChunks + chunk) & 1) * kStackChunkFloats +
                     (m_begin << 6) + lane;
