@@ -1010,3 +1010,18 @@ def test_plan_tables_of_the_library_match_numpy():
             assert np.array_equal(got[name], want[name]), name
     empty = batch.Plan([], [], [])
     assert empty.word_sum_tables()['n_slots'] == 0
+
+
+def test_hand_scheduled_loads_are_not_touched_in_flight():
+    """conv_stack.hip's loader waves issue their row loads from inline asm and wait with
+    explicit s_waitcnt; hipcc does not know those registers are still being written.  The
+    checker replays the kernel's ISA and fails on any instruction that touches them early."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which('hipcc') is None:
+        pytest.skip('hipcc not on PATH')
+    done = subprocess.run([sys.executable, os.path.join(str(ROOT), 'tools', 'check_inflight.py')],
+                          capture_output=True, text=True, timeout=600)
+    assert done.returncode == 0, done.stdout + done.stderr
+    assert re.search(r'[1-9]\d* inline-asm loads checked, 0 problem', done.stdout), done.stdout
