@@ -12,11 +12,15 @@
 #ifdef STACK_STAMPS
 __device__ unsigned long long* g_stack_stamps = nullptr;
 // slot per (block, wave): realtime stamps (100 MHz)
+// (and, in the second half of the table, the shader clock's own counter: cycles per stamp
+// interval over its microseconds is the clock the kernel ran at)
 #define STACK_STAMP(slot)                                                                   \
     do {                                                                                    \
-        if (g_stack_stamps != nullptr && (threadIdx.x & 63) == 0)                           \
-            g_stack_stamps[(static_cast<size_t>(blockIdx.x) * 12 + (threadIdx.x >> 6)) * 32 + \
-                           (slot)] = __builtin_amdgcn_s_memrealtime();                     \
+        if (g_stack_stamps != nullptr && (threadIdx.x & 63) == 0) {                         \
+            const size_t at = (static_cast<size_t>(blockIdx.x) * 12 + (threadIdx.x >> 6)) * 32 + (slot); \
+            g_stack_stamps[at] = __builtin_amdgcn_s_memrealtime();                          \
+            g_stack_stamps[at + static_cast<size_t>(gridDim.x) * 12 * 32] = __builtin_amdgcn_s_memtime(); \
+        }                                                                                   \
     } while (0)
 #endif
 #include "../../emphases_amd/csrc/conv_w4.hip"
@@ -98,11 +102,11 @@ int main(int argc, char** argv) {
 #ifdef STACK_STAMPS
     unsigned long long* stamps;
     const size_t count = static_cast<size_t>(n_spans) * 12 * 32;
-    CHECK(hipMalloc(&stamps, count * 8)); CHECK(hipMemset(stamps, 0, count * 8));
+    CHECK(hipMalloc(&stamps, 2 * count * 8)); CHECK(hipMemset(stamps, 0, 2 * count * 8));
     CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_stack_stamps), &stamps, sizeof(stamps)));
     stack(); CHECK(hipDeviceSynchronize());
-    std::vector<unsigned long long> hs2(count);
-    CHECK(hipMemcpy(hs2.data(), stamps, count * 8, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> hs2(2 * count);
+    CHECK(hipMemcpy(hs2.data(), stamps, 2 * count * 8, hipMemcpyDeviceToHost));
     unsigned long long first = ~0ull;
     for (size_t i = 0; i < count; i += 32) if (hs2[i]) first = std::min(first, hs2[i]);
     // mean over blocks of wave 0 (MFMA) and wave 8 (loader) stamps, in us from the first stamp
@@ -118,6 +122,27 @@ int main(int argc, char** argv) {
         }
         printf("\n");
     }
+    // the clock between consecutive stamps of wave 0 (mean over blocks)
+    printf("GHz  0:");
+    int before = -1;
+    for (int slot = 0; slot < 32; ++slot) {
+        double cycles = 0, micros = 0;
+        bool have = false;
+        for (int b = 0; b < n_spans; ++b) {
+            const size_t at = (static_cast<size_t>(b) * 12) * 32;
+            if (!hs2[at + slot]) continue;
+            have = true;
+            if (before >= 0) {
+                micros += double(hs2[at + slot] - hs2[at + before]) / 100.;
+                cycles += double(hs2[count + at + slot] - hs2[count + at + before]);
+            }
+        }
+        if (have) {
+            if (before >= 0 && micros > 0) printf(" [%d] %.2f", slot, cycles / micros / 1e3);
+            before = slot;
+        }
+    }
+    printf("\n");
 #endif
     return 0;
 }
