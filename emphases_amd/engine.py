@@ -779,7 +779,8 @@ class Engine:
             add_layernorm(layer['norm2'])
         return x
 
-    def _frame_stack(self, features, ld_f, a, b, out, ld_w, plan, meta):
+    def _frame_stack(self, features, ld_f, a, b, out, ld_w, plan, meta,
+                     frames=True, words=True):
         """Input layer + frame encoder as groups of up to three layers per
         launch (`emph_conv1d_stack`: a workgroup owns a span of positions
         through the layers of a group, activations resident in LDS), then
@@ -799,7 +800,7 @@ class Engine:
         pack = self.input_layer.winograd4.numel()
         relu_layers = config.activation == 'relu'
         source, buffers, done = features, (a, b), 0
-        for group in range(groups):
+        for group in range(groups if frames else 0):
             size = -(-(total - done) // (groups - group))
             relu = sum(1 << l for l in range(size)
                        if done + l >= 1 and relu_layers)
@@ -817,6 +818,8 @@ class Engine:
                     runtime.stream()), 'emph_conv1d_stack')
             source = target
             done += size
+        if not words:
+            return
         if fold:
             with self._timed('word_sums'):
                 runtime.check(self.lib.emph_word_sums(
@@ -1032,6 +1035,15 @@ class Engine:
                             runtime.stream()), 'emph_segment_reduce')
         if stages is not None:
             stages['downsampled'] = wa.clone()
+        return self._word_stage(wa, plan, meta, logits, scores)
+
+    def _word_stage(self, wa, plan, meta, logits, scores):
+        """Word embeddings -> word decoder -> output layer -> postprocess."""
+        config = self.config
+        channels = config.channels
+        ld_w = plan.ld_words
+        words = runtime.AXIS_WORDS
+        table = meta['table'][0]
         if self.fused_words:
             tiles, size = meta[('tiles',) + self.decoder_tiles]
             with self._timed('word_decoder', 2. * channels * (
@@ -1064,6 +1076,37 @@ class Engine:
                 runtime.POSTPROCESS[config.loss], logits.data_ptr(),
                 scores.data_ptr(), runtime.stream()), 'emph_output_layer')
         return scores, logits
+
+    def splittable(self, plan, meta):
+        """Whether forward() is `forward_frames()` + `forward_words()` for this
+        configuration and layout: the default convolutional path (frame-rate
+        layers by emph_conv1d_stack, per-word sums folded, one-launch decoder)."""
+        return (self.config.downsample_location != 'input' and
+                'conv_spans' in meta and 'word_sum_tables' in meta and
+                self.fused_words and len(plan.segments) > 0)
+
+    def forward_frames(self, audio, plan, meta):
+        """The frame-rate half of forward(): features and the frame-rate layers,
+        up to the running sums the words are made of (left in the workspace)."""
+        ld_f = plan.ld_frames
+        channels = self.config.channels
+        check_bounds(plan, self.config.downsample_method)
+        features = self.features(audio, plan, meta)
+        a = self._buffer('frames_a', channels, ld_f)
+        b = self._buffer('frames_b', channels, ld_f)
+        self._frame_stack(features, ld_f, a, b, None, plan.ld_words, plan, meta,
+                          words=False)
+
+    def forward_words(self, plan, meta):
+        """The word-rate half: per-word sums -> decoder -> scores (same kernels,
+        same bits as forward())."""
+        ld_w = plan.ld_words
+        logits = self._buffer('logits', ld_w)
+        scores = self._buffer('scores', ld_w)
+        wa = self._buffer('words_a', self.config.channels, ld_w)
+        self._frame_stack(None, plan.ld_frames, None, None, wa, ld_w, plan, meta,
+                          frames=False)
+        return self._word_stage(wa, plan, meta, logits, scores)
 
     def capture(self, audio, plan, meta=None):
         """Capture forward() for this (audio buffer, plan) into a HIP graph.

@@ -476,6 +476,23 @@ def test_fused_forward_equals_step_by_step(cases, default_engine):
         None, None, None, 0, None) == -1
 
 
+def test_forward_in_two_halves(cases, default_engine):
+    """forward_frames() + forward_words() (the frame-rate and the word-rate half as
+    separate calls, what tools/split_lanes.py schedules on two graph branches) leave
+    the bits of forward()."""
+    audio, bounds, _ = case_inputs(cases, 'utt_10s')
+    plan, whole, whole_logits = run_case(default_engine, audio, bounds, 3000)
+    whole, whole_logits = whole.clone(), whole_logits.clone()
+    meta = default_engine.upload(plan)
+    assert default_engine.splittable(plan, meta)
+    default_engine.forward_frames(
+        torch.from_numpy(audio[0]).to(default_engine.device), plan, meta)
+    scores, logits = default_engine.forward_words(plan, meta)
+    columns = plan.word_columns()
+    assert torch.equal(whole[columns], scores[columns])
+    assert torch.equal(whole_logits[columns], logits[columns])
+
+
 @pytest.mark.parametrize('method', ['sum', 'average'])
 def test_folded_word_sums_against_segment_reduce(method):
     """The per-word sum folded into the last frame-rate layer
