@@ -575,6 +575,11 @@ def roofline(kernels, passes, ms_per_step, config):
         # busy the matrix pipe is - that is `frac_executed`
         'executed_mfma_flops_per_launch': flops / launches * executed,
         'frac_executed': achieved * executed / PEAK_FP32_MFMA,
+        'frac_is': 'algorithmic (direct-form) flops over the dense fp32 MFMA '
+                   'peak: F(4,3) executes %.3f of them, so a value above 1 is '
+                   'an algorithmic saving, not a faster matrix pipe - how busy '
+                   'the pipe is: frac_executed (PMC: profiles/'
+                   'r4_pmc_utilisation.md)' % executed,
         # HBM bytes per launch by PMC: from the committed profile of this
         # command (see `from_profiles`), not collected in this run
         'traffic': committed.get('traffic'),
