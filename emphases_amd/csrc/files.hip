@@ -291,37 +291,69 @@ void append_utf8(std::string* out, uint32_t code) {
     }
 }
 
-std::string utf16_to_utf8(const unsigned char* data, size_t bytes, bool big) {
-    std::string out;
-    out.reserve(bytes / 2);
+// (strict, like bytes.decode: an odd byte count, a lone surrogate -> false)
+bool utf16_to_utf8(const unsigned char* data, size_t bytes, bool big, std::string* out) {
+    if (bytes & 1) return false;
+    out->reserve(bytes / 2);
     auto unit = [&](size_t i) -> uint32_t {
         return big ? (data[i] << 8) | data[i + 1] : data[i] | (data[i + 1] << 8);
     };
     for (size_t i = 0; i + 1 < bytes; i += 2) {
         uint32_t code = unit(i);
-        if (code >= 0xD800 && code < 0xDC00 && i + 3 < bytes) {
+        if (code >= 0xDC00 && code < 0xE000) return false;
+        if (code >= 0xD800 && code < 0xDC00) {
+            if (i + 3 >= bytes) return false;
             const uint32_t low = unit(i + 2);
-            if (low >= 0xDC00 && low < 0xE000) {
-                code = 0x10000 + ((code - 0xD800) << 10) + (low - 0xDC00);
-                i += 2;
-            }
+            if (low < 0xDC00 || low >= 0xE000) return false;
+            code = 0x10000 + ((code - 0xD800) << 10) + (low - 0xDC00);
+            i += 2;
         }
-        append_utf8(&out, code);
+        append_utf8(out, code);
     }
-    return out;
+    return true;
+}
+
+// what bytes.decode('utf-8') accepts: no overlong forms, no surrogates, <= U+10FFFF
+bool valid_utf8(const unsigned char* d, size_t n) {
+    size_t i = 0;
+    while (i < n) {
+        const unsigned char c = d[i];
+        if (c < 0x80) {
+            ++i;
+            continue;
+        }
+        int extra;
+        uint32_t code, least;
+        if (c >= 0xC2 && c <= 0xDF) extra = 1, code = c & 0x1Fu, least = 0x80;
+        else if (c >= 0xE0 && c <= 0xEF) extra = 2, code = c & 0x0Fu, least = 0x800;
+        else if (c >= 0xF0 && c <= 0xF4) extra = 3, code = c & 0x07u, least = 0x10000;
+        else return false;
+        if (i + static_cast<size_t>(extra) >= n) return false;
+        for (int k = 1; k <= extra; ++k) {
+            if ((d[i + k] & 0xC0) != 0x80) return false;
+            code = (code << 6) | (d[i + k] & 0x3Fu);
+        }
+        if (code < least || code > 0x10FFFF || (code >= 0xD800 && code < 0xE000)) return false;
+        i += static_cast<size_t>(extra) + 1;
+    }
+    return true;
 }
 
 // alignment.decode: UTF-16 by BOM or by the zero bytes of the ASCII header,
-// UTF-8 with or without BOM
-std::string decode(const std::string& raw) {
+// UTF-8 with or without BOM; false where Python's decoder raises
+bool decode(const std::string& raw, std::string* text) {
     const unsigned char* d = reinterpret_cast<const unsigned char*>(raw.data());
     const size_t n = raw.size();
-    if (n >= 2 && d[0] == 0xFF && d[1] == 0xFE) return utf16_to_utf8(d + 2, n - 2, false);
-    if (n >= 2 && d[0] == 0xFE && d[1] == 0xFF) return utf16_to_utf8(d + 2, n - 2, true);
-    if (n >= 3 && d[0] == 0xEF && d[1] == 0xBB && d[2] == 0xBF) return raw.substr(3);
-    if (n >= 4 && d[1] == 0 && d[0] != 0) return utf16_to_utf8(d, n, false);
-    if (n >= 4 && d[0] == 0 && d[1] != 0) return utf16_to_utf8(d, n, true);
-    return raw;
+    if (n >= 2 && d[0] == 0xFF && d[1] == 0xFE) return utf16_to_utf8(d + 2, n - 2, false, text);
+    if (n >= 2 && d[0] == 0xFE && d[1] == 0xFF) return utf16_to_utf8(d + 2, n - 2, true, text);
+    if (n >= 3 && d[0] == 0xEF && d[1] == 0xBB && d[2] == 0xBF) {
+        *text = raw.substr(3);
+        return valid_utf8(d + 3, n - 3);
+    }
+    if (n >= 4 && d[1] == 0 && d[0] != 0) return utf16_to_utf8(d, n, false, text);
+    if (n >= 4 && d[0] == 0 && d[1] != 0) return utf16_to_utf8(d, n, true, text);
+    *text = raw;
+    return valid_utf8(d, n);
 }
 
 struct Value {
@@ -332,24 +364,32 @@ struct Value {
 
 bool is_word(unsigned char c) {
     return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') ||
-           c == '_' || c >= 0x80;
+           c == '_';
 }
 bool is_digit(unsigned char c) { return c >= '0' && c <= '9'; }
 
 // alignment._VALUE, as a scanner: "strings" (a quote inside is doubled), <flags>,
-// numbers that neither follow [\w.\[] nor run into [\w\]]
-void scan_values(const std::string& text, std::vector<Value>* values) {
+// numbers that neither follow [\w.\[] nor run into [\w\]].  Returns false where this
+// scanner cannot vouch for what the regex would do - a character beyond ASCII outside a
+// string (Python's \w and \d know Unicode) - and the file goes to the Python reader.
+bool scan_values(const std::string& text, std::vector<Value>* values) {
     const size_t n = text.size();
     size_t i = 0;
     while (i < n) {
         const unsigned char c = static_cast<unsigned char>(text[i]);
+        if (c >= 0x80) return false;
         if (c == '"') {
             std::string body;
             size_t j = i + 1;
             bool closed = false;
+            // the regex backtracks: a string that never closes ends at the FIRST
+            // quote of the last doubled pair it swallowed, if there was one
+            size_t last_pair = 0, body_at_pair = 0;
+            bool pair = false;
             while (j < n) {
                 if (text[j] == '"') {
                     if (j + 1 < n && text[j + 1] == '"') {
+                        pair = true, last_pair = j, body_at_pair = body.size();
                         body.push_back('"');
                         j += 2;
                         continue;
@@ -359,6 +399,11 @@ void scan_values(const std::string& text, std::vector<Value>* values) {
                 }
                 body.push_back(text[j]);
                 ++j;
+            }
+            if (!closed && pair) {
+                body.resize(body_at_pair);
+                j = last_pair;
+                closed = true;
             }
             if (closed) {
                 values->push_back({Value::kString, std::move(body), 0.});
@@ -371,6 +416,7 @@ void scan_values(const std::string& text, std::vector<Value>* values) {
         if (c == '<') {
             size_t j = i + 1;
             while (j < n && is_word(static_cast<unsigned char>(text[j]))) ++j;
+            if (j < n && static_cast<unsigned char>(text[j]) >= 0x80) return false;
             if (j > i + 1 && j < n && text[j] == '>') {
                 values->push_back({Value::kFlag, text.substr(i + 1, j - i - 1), 0.});
                 i = j + 1;
@@ -386,6 +432,7 @@ void scan_values(const std::string& text, std::vector<Value>* values) {
                 if (text[j] == '-' || text[j] == '+') ++j;
                 size_t digits = j;
                 while (j < n && is_digit(static_cast<unsigned char>(text[j]))) ++j;
+                const size_t whole = j;                  // end of \d+
                 bool mantissa = j > digits;
                 if (mantissa) {                          // \d+\.?\d*
                     if (j < n && text[j] == '.') {
@@ -408,17 +455,21 @@ void scan_values(const std::string& text, std::vector<Value>* values) {
                         while (k < n && is_digit(static_cast<unsigned char>(text[k]))) ++k;
                         if (k > exponent) j = k;
                     }
-                    // the regex backtracks over trailing digits to satisfy the
-                    // lookahead; a number that runs into a letter is no number at all
-                    // for the files this reads, so it is skipped whole
                     const unsigned char after = j < n ? static_cast<unsigned char>(text[j]) : ' ';
-                    if (!(j < n && (is_word(after) || after == ']'))) {
-                        Value value{Value::kNumber, std::string(), 0.};
-                        value.number = strtod(text.substr(i, j - i).c_str(), nullptr);
-                        values->push_back(std::move(value));
-                        i = j;
-                        continue;
+                    if (j < n && after >= 0x80) return false;
+                    if (j < n && (is_word(after) || after == ']')) {
+                        // the lookahead fails; the regex backtracks over the digits
+                        // (each shorter end runs into a digit) down to ONE end that
+                        // holds: the whole part in front of a '.'
+                        if (whole > digits && whole < j && text[whole] == '.') j = whole;
+                        else {
+                            i = j;
+                            continue;
+                        }
                     }
+                    Value value{Value::kNumber, std::string(), 0.};
+                    value.number = strtod(text.substr(i, j - i).c_str(), nullptr);
+                    values->push_back(std::move(value));
                     i = j;
                     continue;
                 }
@@ -426,6 +477,7 @@ void scan_values(const std::string& text, std::vector<Value>* values) {
         }
         ++i;
     }
+    return true;
 }
 
 struct Item {
@@ -443,10 +495,32 @@ struct Grid {
     bool has_phones = false;
 };
 
+// alignment._is_silence: `not text.strip()` (str.strip knows Unicode whitespace) or one of
+// the two silence labels
 bool is_silence(const std::string& text) {
     bool blank = true;
-    for (unsigned char c : text)
-        if (!(c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f))) blank = false;
+    const unsigned char* d = reinterpret_cast<const unsigned char*>(text.data());
+    const size_t n = text.size();
+    for (size_t i = 0; i < n && blank;) {
+        uint32_t code = d[i];
+        if (code < 0x80) {
+            ++i;
+        } else if (code < 0xE0 && i + 1 < n) {
+            code = ((code & 0x1F) << 6) | (d[i + 1] & 0x3F);
+            i += 2;
+        } else if (code < 0xF0 && i + 2 < n) {
+            code = ((code & 0x0F) << 12) | ((d[i + 1] & 0x3Fu) << 6) | (d[i + 2] & 0x3F);
+            i += 3;
+        } else {
+            code = 0x10000;                       // nothing beyond the BMP is whitespace
+            i += 4;
+        }
+        const bool space =
+            code == ' ' || (code >= 9 && code <= 13) || (code >= 0x1c && code <= 0x1f) ||
+            code == 0x85 || code == 0xA0 || code == 0x1680 || (code >= 0x2000 && code <= 0x200A) ||
+            code == 0x2028 || code == 0x2029 || code == 0x202F || code == 0x205F || code == 0x3000;
+        if (!space) blank = false;
+    }
     return blank || text == "sp" || text == kSilence;
 }
 
@@ -459,7 +533,10 @@ std::string lower(const std::string& text) {
 
 bool parse_grid(const std::string& text, Grid* grid, std::string* error) {
     std::vector<Value> values;
-    scan_values(text, &values);
+    if (!scan_values(text, &values)) {
+        *error = "TextGrid: text beyond ASCII outside a string";
+        return false;
+    }
     size_t at = 0;
     bool short_of = false;
     auto take = [&](Value::Kind kind, const char* name) -> const Value* {
@@ -495,7 +572,18 @@ bool parse_grid(const std::string& text, Grid* grid, std::string* error) {
     std::vector<Tier> tiers;              // interval tiers only
     if (v->text == "exists") {
         if (!(v = take(Value::kNumber, "float"))) return fail();
-        const int count = static_cast<int>(v->number);
+        // (int(float) of Python: nan / inf raise, anything else truncates - a count no
+        // int holds runs out of values, which the loop would only find out by walking)
+        auto whole = [&](double number, int* out) {
+            if (!(number > -2147483648. && number < 2147483647.)) {
+                *error = "TextGrid: a count out of range";
+                return false;
+            }
+            *out = static_cast<int>(number);
+            return true;
+        };
+        int count = 0;
+        if (!whole(v->number, &count)) return false;
         for (int t = 0; t < count; ++t) {
             const Value* kind = take(Value::kString, "str");
             if (!kind) return fail();
@@ -504,7 +592,8 @@ bool parse_grid(const std::string& text, Grid* grid, std::string* error) {
             if (!take(Value::kNumber, "float") || !take(Value::kNumber, "float")) return fail();
             const Value* size = take(Value::kNumber, "float");
             if (!size) return fail();
-            const int items = static_cast<int>(size->number);
+            int items = 0;
+            if (!whole(size->number, &items)) return false;
             const bool interval = kind->text == "IntervalTier";
             Tier tier;
             tier.name = name->text;
@@ -590,6 +679,12 @@ bool parse_grid(const std::string& text, Grid* grid, std::string* error) {
         grid->words.push_back(std::move(words[i]));
     }
     for (Item& phone : grid->phones) phone.word = moved[phone.word];
+    // (the two tier names travel to the host side as one line each)
+    if (grid->word_tier.find('\n') != std::string::npos ||
+        grid->phone_tier.find('\n') != std::string::npos) {
+        *error = "TextGrid: a line break in a tier name";
+        return false;
+    }
     return true;
 }
 
@@ -865,8 +960,13 @@ int emph_files_open(const char* const* text_paths, const char* const* audio_path
         file.text_path = text_paths[i];
         file.audio_path = audio_paths[i];
         std::string raw, error;
-        if (!read_whole(text_paths[i], &raw, &error) ||
-            !parse_grid(decode(raw), &file.grid, &error)) {
+        std::string text;
+        bool parsed = read_whole(text_paths[i], &raw, &error);
+        if (parsed && !decode(raw, &text)) {
+            error = "TextGrid: not valid UTF-8 / UTF-16";
+            parsed = false;
+        }
+        if (!parsed || !parse_grid(text, &file.grid, &error)) {
             file.status |= 1;
             file.error = error;
         }
