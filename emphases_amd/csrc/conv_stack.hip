@@ -575,7 +575,8 @@ int32_t emph_conv_stack_spans(const int64_t* host_counts, const int64_t* host_of
     return total;
 }
 
-// `layers` (1 .. 4) consecutive Conv1d(80, 80, 3, 'same') layers in one launch.
+// `layers` (1 .. emph_conv_stack_max_layers()) consecutive Conv1d(80, 80, 3, 'same') layers in
+// one launch.
 //   packs   float32: emph_conv_winograd4_pack of every layer, back to back
 //   biases  float32 [layers][80]
 //   relu_mask  bit l: layer l is followed by ReLU (else identity)

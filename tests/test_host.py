@@ -1062,3 +1062,33 @@ def test_file_readers_differential_fuzz(tmp_path):
     for index, text in enumerate(texts):
         assert fuzz_files.python_alignment(text) == \
             fuzz_files.library_alignment(opened, index), text.name
+
+
+def test_conv_span_table_invariants():
+    """emph_conv_stack_spans for every segment length up to 2100 and a few long
+    ones: the spans of a segment tile it without gap or overlap from quad
+    boundaries, each fits the 256 computed positions of a workgroup together
+    with the quad of halo it needs on every side that continues inside the
+    segment, and there are as few of them as those capacities allow."""
+    counts = np.array(list(range(1, 2101)) + [2999, 3000, 3001, 30000, 30001],
+                      dtype=np.int64)
+    plan = batch.Plan([], [], [])
+    plan.frames = counts
+    plan.frame_off = np.concatenate([[16], 16 + np.cumsum(counts + 24)[:-1]])
+    plan._tiles = {}
+    spans = plan.conv_spans()
+    assert spans.dtype == np.int32 and spans.shape[1] == 8
+    for segment, count in enumerate(counts.tolist()):
+        rows = spans[spans[:, 0] == segment]
+        assert (rows[:, 2] == plan.frame_off[segment]).all()
+        assert (rows[:, 3] == count).all() and not rows[:, 6:].any()
+        first, owned, computed = rows[:, 1], rows[:, 4], rows[:, 5]
+        assert first[0] == 0 and (first[1:] == first[:-1] + owned[:-1]).all()
+        assert owned.sum() == count and (owned > 0).all()
+        assert not (first % 4).any() and not (computed % 4).any()
+        assert (computed == np.maximum(first - 4, 0)).all()
+        end = first + owned
+        need = np.where(end < count, end + 4, end)      # a quad of halo inside
+        assert (need <= computed + 256).all(), count
+        pieces = 1 if count <= 256 else max(2, 2 + -(-(count - 504) // 248))
+        assert len(rows) == pieces, (count, len(rows), pieces)
