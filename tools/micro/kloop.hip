@@ -174,10 +174,19 @@ int main(int argc, char** argv) {
     std::sort(laps.begin(), laps.end());
     std::vector<unsigned long long> h(256 * 16);
     CHECK(hipMemcpy(h.data(), clocks, h.size() * 8, hipMemcpyDeviceToHost));
-    double cycles = 0; int n = 0;
-    for (int b = 0; b < 256; ++b) for (int w = 0; w < (threads >= 512 ? 8 : 4); ++w) cycles += h[b * 16 + w], ++n;
+    // the workgroup's LONGEST wave (waves of a SIMD do not progress evenly without a barrier:
+    // the mean over the waves is not the loop's duration), mean over the workgroups
+    double cycles = 0, mean = 0;
+    const int waves = threads >= 512 ? 8 : 4;
+    for (int b = 0; b < 256; ++b) {
+        unsigned long long longest = 0;
+        for (int w = 0; w < waves; ++w) longest = std::max(longest, h[b * 16 + w]), mean += h[b * 16 + w];
+        cycles += longest;
+    }
+    cycles /= 256, mean /= 256 * waves;
     // per chunk and SIMD: 120 MFMAs of 32 cycles = 3840 cycles of matrix pipe
-    printf("%d chunks: kernel %.1f us = %.3f us per chunk; loop %.0f s_memtime ticks per chunk (x%d waves)\n", chunks,
-           laps[3], laps[3] / chunks, cycles / n / chunks, n / 256);
+    printf("%d chunks: kernel %.1f us = %.3f us per chunk; %.0f cycles per chunk in the longest wave (mean of the "
+           "waves %.0f) = %.2f GHz; matrix pipe %.0f %% of them\n", chunks, laps[3], laps[3] / chunks, cycles / chunks,
+           mean / chunks, cycles / (laps[3] * 1e3), 100. * 3840 * chunks / cycles);
     return 0;
 }
