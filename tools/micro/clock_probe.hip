@@ -68,7 +68,7 @@ void run(const char* name, size_t lds_bytes, int rounds, const float* seed, floa
     }
     longest /= 256;
     const double mfmas = 2. * rounds * 8;                // per SIMD
-    printf("%-44s %8.1f us  %5.2f GHz  %5.1f cycles per MFMA  %6.1f TFLOP/s\n", name, laps[2] * 1e3,
+    printf("%-44s %8.1f us  %5.0f MHz  %5.1f cycles per MFMA  %6.1f TFLOP/s\n", name, laps[2] * 1e3,
            longest / (laps[2] * 1e3), longest / mfmas, 256. * 4 * mfmas * 2048 / (laps[2] * 1e-3) / 1e12);
 }
 
