@@ -18,7 +18,10 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kStride = 260, kChannels = 80, kMTiles = 5, kChunkSteps = 4;
+#ifndef KLOOP_CHUNK_STEPS
+#define KLOOP_CHUNK_STEPS 4
+#endif
+constexpr int kStride = 260, kChannels = 80, kMTiles = 5, kChunkSteps = KLOOP_CHUNK_STEPS;
 constexpr int kStepFloats = 6 * kMTiles * 64;
 constexpr int kChunkFloats = kChunkSteps * kStepFloats;
 
@@ -53,7 +56,7 @@ __device__ __forceinline__ void loop(const float* act, const float* ring, int ch
 #ifdef BARRIER
         __syncthreads();
 #endif
-        const int within = chunk % 5;
+        const int within = chunk % (20 / kChunkSteps);
         if (within == 0) load_b(0);
         const float* weights = ring + (chunk & 1) * kChunkFloats + (m_begin << 6) + lane;
 #pragma unroll
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(768) void kloop_kernel(const float* seed, int chunk
 #endif
 }
 
+#ifndef KLOOP_NO_MAIN
 int main(int argc, char** argv) {
     const int chunks = argc > 1 ? atoi(argv[1]) : 150;
 #ifdef ONE_WAVE
@@ -190,3 +194,4 @@ int main(int argc, char** argv) {
            mean / chunks, cycles / (laps[3] * 1e3), 100. * 3840 * chunks / cycles);
     return 0;
 }
+#endif
