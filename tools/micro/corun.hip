@@ -8,7 +8,6 @@
 #define BARRIER
 #include "kloop.hip"
 #include <math.h>
-#define EMPH_STAMP(slot)
 #include "../../emphases_amd/csrc/frontend.hip"
 
 int main(int argc, char** argv) {
