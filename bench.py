@@ -1191,6 +1191,16 @@ def spawn_workers(args):
 ###############################################################################
 
 
+LINE_OUT = None
+
+
+def emit(result):
+    """The run's one line, on the process's original stdout."""
+    out = LINE_OUT or sys.stdout
+    out.write(json.dumps(result) + '\n')
+    out.flush()
+
+
 def main():
     args = parse_args()
     if args.cpu_worker is not None:
@@ -1198,6 +1208,13 @@ def main():
         return
     if 'RANK' not in os.environ and args.gpus > 1:
         spawn_workers(args)             # (does not return)
+    # The contract is ONE JSON line on stdout.  Libraries write there too (gloo
+    # announces its peers on stdout, RCCL can be told to log): keep the real
+    # stdout for the line and send everything else, from any layer, to stderr.
+    global LINE_OUT
+    LINE_OUT = os.fdopen(os.dup(1), 'w')
+    sys.stdout.flush()
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
@@ -1269,7 +1286,7 @@ def run_sharded(args, rank, world, device, host):
         'job': line}
     if host is not None:
         result['cpu_baseline'] = host
-    print(json.dumps(result), flush=True)
+    emit(result)
 
 
 def run_batch(args, rank, world, device, host):
@@ -1420,7 +1437,7 @@ def run_batch(args, rank, world, device, host):
                     side_transformer, device, audios, alignments, args)
                 result['configs_4_longform'] = guarded(side_longform, device)
                 result['configs_3_corpus'] = guarded(side_corpus, device)
-        print(json.dumps(result), flush=True)
+        emit(result)
 
 
 if __name__ == '__main__':
