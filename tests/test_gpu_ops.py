@@ -218,7 +218,7 @@ def test_conv1d_winograd4(c_in, c_out, activation):
 
 
 @pytest.mark.parametrize('layers,relu_mask', [
-    (1, 0b1), (2, 0b10), (3, 0b110), (3, 0b111), (3, 0)])
+    (1, 0b1), (2, 0b10), (3, 0b110), (3, 0b111), (3, 0), (3, -0b110), (2, -0b01)])
 def test_conv1d_stack_equals_layer_by_layer(layers, relu_mask):
     """emph_conv1d_stack (`layers` Conv1d(80, 80, 3) + identity / ReLU in ONE
     launch, activations resident in LDS, one recomputed quad of halo per side)
@@ -229,6 +229,11 @@ def test_conv1d_stack_equals_layer_by_layer(layers, relu_mask):
     lib = runtime.library()
     frames = [1000, 1, 2, 3, 4, 5, 37, 64, 65, 252, 253, 256, 257, 504, 505,
               600, 3000, 130]
+    if relu_mask < 0:
+        # (a negative mask: the same layers on forty random lengths)
+        relu_mask = -relu_mask
+        rng = np.random.default_rng(1000 + layers)
+        frames = [int(n) for n in rng.integers(1, 3001, size=40)]
     plan = ragged_plan(frames)
     axis, tile = runtime.AXIS_FRAMES, 64
     meta = Meta(plan, [(axis, tile)])
