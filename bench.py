@@ -63,7 +63,7 @@ PEAK_HBM = 8.0e12             # B/s, same guide
 # compulsory traffic and algorithmic flops of the conv path
 BYTES_PER_FRAME = 641.
 FLOPS_PER_FRAME, FLOPS_PER_WORD = 0.2968e6, 0.2309e6
-PROFILE_TAGS = ('r4', 'r3', 'r2', 'r1')
+PROFILE_TAGS = ('r5', 'r4', 'r3', 'r2', 'r1')
 # kernel name in `Engine.timers` -> substring of the rocprofv3 kernel name
 ROCPROF_NAMES = {
     'conv1d_winograd4_frames_80x80_k3': 'conv1d_winograd4_kernel',
@@ -407,6 +407,12 @@ class Runner:
         engine.timers = []
         for _ in range(passes):
             engine.forward(self.packed, self.plan, self.meta)
+        # the dispatch alone: the same events around an empty kernel
+        from emphases_amd import runtime
+        for _ in range(4 * passes):
+            with engine._timed('launch_probe'):
+                runtime.check(engine.lib.emph_launch_probe(runtime.stream()),
+                              'emph_launch_probe')
         torch.cuda.synchronize()
         kernels = {}
         for name, flops, begin, end in engine.timers:
@@ -501,6 +507,13 @@ def from_profiles(config, dominant):
             result['rocprof_avg_launch_us'] = total / calls * 1e-3
             result['rocprof_calls'] = calls
             result['kernel_stats_file'] = os.path.relpath(stats, ROOT)
+        # the empty kernel of `emph_launch_probe` in the same trace: what an event
+        # pair around it measures beyond this is the dispatch
+        with open(stats) as file:
+            for row in csv.DictReader(file):
+                if 'launch_probe_kernel' in row['Name']:
+                    result['rocprof_probe_kernel_us'] = \
+                        float(row['AverageNs']) * 1e-3
     summary = profile_file('pmc_summary.json' if config == 'conv'
                            else 'transformer_pmc_summary.json')
     if summary:
@@ -515,6 +528,7 @@ def from_profiles(config, dominant):
         with open(utilisation) as file:
             entry = json.load(file).get(dominant, {})
         result['mfma_pipe_busy'] = entry.get('mfma_pipe_busy')
+        result['sq_insts_mfma_per_launch'] = entry.get('sq_insts_mfma_per_launch')
         result['mfma_pipe_busy_file'] = os.path.relpath(utilisation, ROOT)
     return result
 
@@ -548,47 +562,117 @@ def rocprof_kernels(config):
     return result
 
 
-def roofline(kernels, passes, ms_per_step, config):
+# flops of one wave-level matrix instruction of each kernel's K loop
+MFMA_FLOPS = {'conv1d_stack_frames_80x80_k3': 2 * 16 * 16 * 4,      # v_mfma_f32_16x16x4_f32
+              'conv1d_winograd4_frames_80x80_k3': 2 * 16 * 16 * 4,
+              'attention_frames': 2 * 16 * 16 * 4}
+
+
+def executed_matrix_flops(dominant, launches_per_step, committed, spans=None,
+                          layers=None):
+    """Matrix flops ONE launch of the dominant kernel executes: the committed
+    PMC pass's SQ_INSTS_MFMA per launch (`profiles/*_pmc_utilisation.json`, the
+    same command as this run) times the flops of the instruction; for the fused
+    conv stack cross-checked against the count the span table implies (a
+    workgroup per span, 20 k-steps x 30 MFMAs on each of 4 SIMDs per layer)."""
+    per = MFMA_FLOPS.get(dominant)
+    counted = committed.get('sq_insts_mfma_per_launch')
+    result = {}
+    if spans and layers and 'stack' in dominant:
+        result['mfma_instructions_per_launch_from_spans'] = \
+            spans * layers * 20 * 30 * 4 / launches_per_step
+    implied = result.get('mfma_instructions_per_launch_from_spans')
+    if per and counted and (not implied or abs(counted / implied - 1.) < .02):
+        result['mfma_instructions_per_launch'] = counted
+        result['mfma_instructions_source'] = committed.get('mfma_pipe_busy_file')
+        result['flops'] = counted * per
+        if implied:
+            result['pmc_vs_span_table'] = counted / implied
+    elif per and result:
+        # (the committed PMC pass is of the headline batch, this is another job)
+        result['flops'] = result['mfma_instructions_per_launch_from_spans'] * per
+        result['mfma_instructions_source'] = 'span table (no committed PMC pass)'
+    return result
+
+
+def roofline(kernels, passes, ms_per_step, config, spans=None, layers=None):
+    """`frac` = matrix flops the dominant kernel EXECUTES (its MFMA
+    instructions, counted by PMC) per second of kernel time, over the dense
+    fp32 MFMA peak: a fraction of the pipe, at most 1.  The direct-form figure
+    SURVEY 8(d) counts (F(4,3) executes about half of it) is
+    `frac_algorithmic`, which says how fast the layer is computed and can
+    exceed 1."""
+    probe = kernels.pop('launch_probe', None)
     dominant = max(kernels, key=lambda name: kernels[name][1])
     launches, seconds, flops = kernels[dominant]
-    achieved = flops / seconds / 1e12
     committed = from_profiles(config, dominant)
-    # Winograd F(4,3) executes half the direct form's MFMAs (the fused stack
-    # recomputes one quad of halo per side: 256 computed per 250 owned)
-    executed = .5 * 256 / 250 if 'stack' in dominant else \
-        .5 if 'winograd4' in dominant else \
-        2. / 3. if 'winograd' in dominant else 1.
+    launches_per_step = launches / passes
+    # HIP events around a launch bracket the command processor's dispatch as
+    # well as the kernel.  The same events around an EMPTY kernel
+    # (emph_launch_probe) measure dispatch + that kernel; what the empty kernel
+    # itself takes is in the committed rocprofv3 trace of this command - the
+    # difference is the dispatch, which comes off the live duration.
+    raw_us = seconds / launches * 1e6
+    probe_us = probe[1] / probe[0] * 1e6 if probe else None
+    empty_us = committed.get('rocprof_probe_kernel_us')
+    dispatch_us = probe_us - empty_us \
+        if probe_us is not None and empty_us is not None else 0.
+    kernel_us = raw_us - dispatch_us
+    executed = executed_matrix_flops(
+        dominant, launches_per_step, committed, spans, layers)
+    executed_flops = executed.get('flops')
+    if executed_flops is None:         # (a kernel without a Winograd saving)
+        executed_flops = flops / launches
+    achieved = executed_flops / (kernel_us * 1e-6) / 1e12
+    algorithmic = flops / launches / (kernel_us * 1e-6) / 1e12
     result = {
         'bound': 'mfma', 'kernel': dominant,
         'achieved': achieved, 'peak': PEAK_FP32_MFMA,
         'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA,
-        'avg_launch_us': seconds / launches * 1e6,
+        'frac_is': 'EXECUTED matrix flops (MFMA instructions by PMC x flops '
+                   'per instruction) per second of kernel time over the dense '
+                   'fp32 MFMA peak; the vector work of the kernel (Winograd '
+                   'transforms) runs on the same multipliers and is not '
+                   'counted (profiles/r5_coexec.txt)',
+        'avg_launch_us': kernel_us,
         'avg_launch_us_is': 'HIP events around each launch on the launch '
-                            'stream, this run (includes the dispatch gap)',
-        'launches_per_step': launches / passes,
+                            'stream, this run, minus the dispatch (the same '
+                            'events around an empty kernel, less that '
+                            'kernel\'s own duration in the committed '
+                            'rocprofv3 trace)' if dispatch_us else
+                            'HIP events around each launch on the launch '
+                            'stream, this run (includes the dispatch: no '
+                            'committed trace of the empty kernel yet)',
+        'avg_launch_us_raw': raw_us,
+        'launch_probe_us': probe_us,
+        'launch_probe_kernel_us_rocprof': empty_us,
+        'dispatch_us': dispatch_us,
+        'launches_per_step': launches_per_step,
         'share_of_step': None if not ms_per_step else
-        seconds / passes / (ms_per_step * 1e-3),
+        kernel_us * 1e-6 * launches_per_step / (ms_per_step * 1e-3),
+        'executed_mfma_flops_per_launch': executed_flops,
+        'executed': executed,
         'algorithmic_flops_per_launch': flops / launches,
-        # Winograd F(2,3) executes 2/3, F(4,3) 1/2 of the direct form's MFMAs:
-        # `achieved` / `frac` count the ALGORITHMIC (direct-form) flops SURVEY
-        # 8(d) prescribes, so they say how fast the layer is computed, not how
-        # busy the matrix pipe is - that is `frac_executed`
-        'executed_mfma_flops_per_launch': flops / launches * executed,
-        'frac_executed': achieved * executed / PEAK_FP32_MFMA,
-        'frac_is': 'algorithmic (direct-form) flops over the dense fp32 MFMA '
-                   'peak: F(4,3) executes %.3f of them, so a value above 1 is '
-                   'an algorithmic saving, not a faster matrix pipe - how busy '
-                   'the pipe is: frac_executed (PMC: profiles/'
-                   'r4_pmc_utilisation.md)' % executed,
+        'achieved_algorithmic': algorithmic,
+        'frac_algorithmic': algorithmic / PEAK_FP32_MFMA,
+        'frac_algorithmic_is': 'direct-form flops (SURVEY 8d: 2 x 80 x 240 per '
+                               'frame and layer) over the same peak: above 1 '
+                               'is Winograd\'s saving, not a faster pipe',
         # HBM bytes per launch by PMC: from the committed profile of this
         # command (see `from_profiles`), not collected in this run
         'traffic': committed.get('traffic'),
         'traffic_source': committed.get('pmc_file')}
+    if committed.get('mfma_pipe_busy') is not None:
+        result['frac_pmc_pipe_busy'] = committed['mfma_pipe_busy']
+        result['frac_pmc_pipe_busy_is'] = (
+            'SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of the '
+            'committed PMC pass: the same quantity in cycles, independent of '
+            'the clock')
     if committed.get('rocprof_avg_launch_us'):
         average = committed['rocprof_avg_launch_us']
         result['rocprof_avg_launch_us'] = average
         result['frac_at_rocprof_avg'] = \
-            flops / launches / (average * 1e-6) / 1e12 / PEAK_FP32_MFMA
+            executed_flops / (average * 1e-6) / 1e12 / PEAK_FP32_MFMA
     return result, committed
 
 
@@ -1133,6 +1217,8 @@ def sharded_job(workload, args, rank, world, device, steps, warmup, regions,
         torch.cuda.synchronize()
         compute_ms = (time.perf_counter() - start) / steps * 1e3
         kernels, passes = runner.kernel_times(kernel_passes)
+        if 'conv_spans' in runner.meta:
+            kernels['_stack_spans'] = runner.meta['conv_spans'][1] // 8
     compute = torch.tensor([compute_ms or 0.], dtype=torch.float64,
                            device=wire)
     every = torch.zeros(world, dtype=torch.float64, device=wire)
@@ -1228,8 +1314,11 @@ def main():
 
     # The host baseline first: its child processes are started before this
     # process has touched the GPU, and nothing else competes for the cores.
+    # Rank 0 runs it at EVERY world size and workload (an N > 1 or
+    # strong-scaling line without it reads as unmeasured); the other ranks wait
+    # for rank 0 inside init_process_group, idle.
     host = None
-    if world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         host = guarded(cpu_baseline)
 
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -1262,7 +1351,9 @@ def run_sharded(args, rank, world, device, host):
         args.regions)
     if rank != 0:
         return
-    roof, committed = roofline(kernels, passes, None, 'conv')
+    roof, committed = roofline(
+        kernels, passes, None, 'conv', spans=kernels.pop('_stack_spans', None),
+        layers=1 + cfg.DEFAULT.layers)
     unit = 'utterances/s'
     result = {
         'metric': 'utterances/s (mixed 2-30 s @16 kHz) whole-node'
@@ -1343,6 +1434,9 @@ def run_batch(args, rank, world, device, host):
     kernels, passes = runner.kernel_times(20)
     checksum = float(scores[columns].sum().item())
     meta_tile, lanes = runner.meta['tile'], len(runner.lanes)
+    stack_spans = runner.meta['conv_spans'][1] // 8 \
+        if 'conv_spans' in runner.meta else None
+    frame_layers = 1 + config.layers        # input layer + encoder layers
     del runner
     torch.cuda.empty_cache()
 
@@ -1363,7 +1457,8 @@ def run_batch(args, rank, world, device, host):
 
     if rank == 0:
         roof, committed = roofline(
-            kernels, passes, line['ms_per_step'], args.config)
+            kernels, passes, line['ms_per_step'], args.config,
+            spans=stack_spans, layers=frame_layers)
         total_utterances = UTTERANCES * world
         result = {
             'metric': 'utterances/s (10 s @16 kHz) whole-node',

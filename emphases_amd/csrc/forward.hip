@@ -12,7 +12,16 @@
 
 using namespace emph;
 
+namespace emph {
+__global__ __launch_bounds__(64) void launch_probe_kernel() {}
+}  // namespace emph
+
 extern "C" {
+
+int emph_launch_probe(void* stream) {
+    EMPH_LAUNCH(launch_probe_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream));
+    return check_launch("emph_launch_probe");
+}
 
 int64_t emph_prominence_workspace_floats(int32_t features, int32_t channels,
                                          int64_t ld_frames, int64_t ld_words,

@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -41,6 +41,7 @@ _ptr, _i32, _i64, _f32 = _c.c_void_p, _c.c_int32, _c.c_int64, _c.c_float
 SIGNATURES = {
     'emph_abi_version': (_c.c_int, []),
     'emph_last_error': (_c.c_char_p, []),
+    'emph_launch_probe': (_c.c_int, [_ptr]),
     'emph_frontend_table_size': (_i64, []),
     'emph_frontend_table_fill': (_c.c_int, [_ptr]),
     'emph_frontend_block': (_i32, []),

@@ -65,10 +65,13 @@ def parameter_shapes(config=cfg.DEFAULT):
     return shapes
 
 
-def random_state(config=cfg.DEFAULT, seed=0):
+def random_state(config=cfg.DEFAULT, seed=0, output_gain=1.0):
     """Seeded parameters (uniform, variance-preserving fan-in scale) for configurations that have
     no trained checkpoint — the reference ships none for the transformer or
-    any hparam-search variant."""
+    any hparam-search variant.  `output_gain` scales the
+    output layer (a power of two scales the logits exactly): the variant
+    goldens use it to keep |logit| within a few units, where a sigmoid still
+    shows a difference (`tests/golden/generate.py`)."""
     state = collections.OrderedDict()
     for index, (name, shape) in enumerate(parameter_shapes(config).items()):
         stream = seed * 1000 + index
@@ -79,6 +82,9 @@ def random_state(config=cfg.DEFAULT, seed=0):
         else:
             fan_in = int(np.prod(shape[1:]))
             state[name] = synth.weights(stream, shape, math.sqrt(6.0 / fan_in))
+    if output_gain != 1.0:
+        for name in ('output_layer.weight', 'output_layer.bias'):
+            state[name] = (state[name] * np.float32(output_gain)).astype(np.float32)
     return state
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 24
+#define EMPH_ABI_VERSION 25
 
 /* Segment-table fields */
 enum {
@@ -805,6 +805,19 @@ int emph_prominence_forward(const emph_conv_model* model, const void* audio,
                             const emph_word_sum_tables* word_sums,
                             const int32_t* conv_spans, int32_t n_conv_spans,
                             void* stream);
+
+/* ------------------------------------------------------------------------ */
+/* Measurement                                                               */
+/* ------------------------------------------------------------------------ */
+
+/* Enqueues one empty kernel (one wave, no memory access) on `stream`.  A pair
+ * of HIP events around a launch brackets the command processor's dispatch of
+ * the kernel as well as the kernel; the same pair around this launch is that
+ * overhead alone, which `bench.py` subtracts from its live per-kernel
+ * durations so that they can be held against rocprofv3's (which timestamps
+ * the kernel itself).  No reference counterpart: the reference measures
+ * nothing per kernel. */
+int emph_launch_probe(void* stream);
 
 #ifdef __cplusplus
 }

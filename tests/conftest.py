@@ -65,3 +65,12 @@ def variant_config(name):
         else:
             overrides[key] = value
     return cfg.Config(**overrides), overrides
+
+
+def variant_state(archive, name, config):
+    """The seeded weights a variant's goldens were captured with: seed 7 and
+    the output-layer gain `tests/golden/generate.py` chose for it (a power of
+    two that keeps |logit| in (2, 4], so that the scores are not saturated)."""
+    from emphases_amd import weights
+    return weights.random_state(
+        config, seed=7, output_gain=float(archive[f'{name}/output_gain']))

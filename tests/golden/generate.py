@@ -18,6 +18,7 @@ Outputs (committed; data only, no reference source):
 The GPU box never runs this script; it only reads the .npz files.
 """
 import hashlib
+import math
 import os
 import sys
 
@@ -346,8 +347,18 @@ def capture_variants(out):
     for overrides in variant_list():
         config = acfg.Config(**overrides)
         name = variant_name(overrides)
+        # Seeded weights put |logit| in the hundreds for several variants, where
+        # the sigmoid saturates and a score comparison shows nothing: the
+        # reference runs once to find the scale, then the output layer is
+        # scaled by a power of two (exact in float32) that brings the largest
+        # |logit| into (2, 4], and THAT state is the variant's
         configure_reference(config)
-        state = weights.random_state(config, seed=7)
+        probe = run_fp32(reference_model(weights.random_state(config, seed=7)),
+                         alignment, audio_t)
+        largest = float(np.abs(probe[0]['logits']).max())
+        gain = float(2.0 ** math.floor(math.log2(4.0 / largest)))
+        out[f'{name}/output_gain'] = np.float32(gain)
+        state = weights.random_state(config, seed=7, output_gain=gain)
         model = reference_model(state)
         expected = {
             k: tuple(v.shape) for k, v in model.state_dict().items()
@@ -370,9 +381,9 @@ def capture_variants(out):
                 dict(cfg_dict)).numpy()
             delta = float(np.abs(mine - stages[0]['logits']).max())
             scale = float(np.abs(stages[0]['logits']).max())
-            assert delta < 5e-5 + 2e-6 * scale, (name, delta, scale)
+            assert delta < 5e-6 * max(1., scale), (name, delta, scale)
         names.append(name)
-        print(f'variant {name:60s} |oracle-ref|logit={delta:.2e} '
+        print(f'variant {name:60s} gain 2^{int(math.log2(gain)):+d} |oracle-ref|logit={delta:.2e} '
               f'range=[{stages[0]["logits"].min():.3f}, '
               f'{stages[0]["logits"].max():.3f}]')
     configure_reference(acfg.DEFAULT)

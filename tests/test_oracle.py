@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import case_inputs, case_names, seconds, variant_config
+from conftest import case_inputs, case_names, seconds, variant_config, \
+    variant_state
 from emphases_amd import synth, weights
 from oracle import librosa_mel
 from oracle import prominence as oracle
@@ -117,13 +118,17 @@ def test_variant_matrix_matches_reference(variants):
     for name in variants['names']:
         config, overrides = variant_config(name)
         state = {k: torch.from_numpy(v) for k, v in
-                 weights.random_state(config, seed=7).items()}
+                 variant_state(variants, name, config).items()}
         feats = oracle.features(
             padded[:, :audio.shape[1]], overrides, synth.pitch_tracks)[0]
         logits = oracle.forward(feats, bounds, state, overrides).numpy()
         want = variants[f'{name}/logits']
-        scale = max(1.0, float(np.abs(want).max()))
-        assert np.abs(logits - want).max() < 2e-5 * scale, name
+        scale = float(np.abs(want).max())
+        assert 2. < scale <= 4., (name, scale)        # (the goldens' output gain)
+        assert np.abs(logits - want).max() < 5e-6 * scale, name
+        scores = oracle.postprocess(torch.from_numpy(logits), config.loss)
+        assert np.abs(scores.numpy() -
+                      variants[f'{name}/scores']).max() < 2e-6, name
         if config.loudness_feature or config.pitch_feature or \
                 config.periodicity_feature:
             np.testing.assert_allclose(

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: the micro-benchmarks behind DESIGN §6 "What the conv K loop costs".
 # usage: tools/kloop_run.sh <tag>   -> gpurun_out/<tag>_kloop.txt   (binaries: see the .hip headers)
-tag=${1:-r4}
+tag=${1:-r5}
 repo=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$repo/gpurun_out/${tag}_kloop.txt
 bin=$repo/tools/micro/bin

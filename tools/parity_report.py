@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 import emphases_amd  # noqa: E402
 from emphases_amd import batch, engine as engine_module, synth, weights  # noqa: E402
-from conftest import variant_config  # noqa: E402
+from conftest import variant_config, variant_state  # noqa: E402
 
 
 def run(engine, audio, bounds, batch_size):
@@ -57,13 +57,13 @@ def main():
     audio = synth.pcm_to_float(variants['audio_pcm'])
     bounds = variants['bounds_frames'].astype(np.int64)
     print(f'\nvariant matrix, {len(variants["names"])} configurations with SEEDED RANDOM weights: '
-          'their logits are large (scale = max |logit| of the reference), so the\nsame relative '
-          'error is a larger absolute one, on the logits and, where a logit is near 0, on the score')
+          'the output layer of each carries a power-of-two gain\nthat keeps the largest |logit| '
+          '(= scale) in (2, 4], so that no score is saturated')
     print(f'{"variant":74s} {"scale":>8s} {"max |score - ref|":>18s} {"max |logit - ref| / scale":>26s}')
     worst = 0.
     for name in variants['names']:
         config, _ = variant_config(name)
-        engine = engine_module.Engine(config, weights.random_state(config, seed=7), 0)
+        engine = engine_module.Engine(config, variant_state(variants, name, config), 0)
         scores, logits = run(engine, audio, bounds, None)
         want = variants[f'{name}/logits']
         scale = max(1.0, float(np.abs(want).max()))

@@ -2,7 +2,7 @@
 # Runs on the GPU box: matrix-pipe / vector / LDS utilisation counters of the round's
 # kernels (one rocprofv3 --pmc pass each; counters of a pass must fit together).
 # usage: tools/pmc_round.sh <tag>   -> gpurun_out/<tag>_pmc_utilisation.txt
-tag=${1:-r4}
+tag=${1:-r5}
 repo=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$repo/gpurun_out/${tag}_pmc_utilisation.txt
 mkdir -p $repo/gpurun_out
@@ -22,3 +22,4 @@ $repo/tools/pmc_kernel.sh frontend_kernel SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -- $
 echo "== attention_group_kernel: matrix pipe" >> $out
 $repo/tools/pmc_kernel.sh attention_group_kernel SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES -- $tr >> $out 2>&1
 cat $out
+python3 $repo/tools/pmc_utilisation_json.py $repo/gpurun_out $tag > /dev/null

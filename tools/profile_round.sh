@@ -2,7 +2,7 @@
 # Runs on the GPU box (through gpurun): the round's bench line, the rocprofv3
 # kernel statistics of the same workload and the two HBM PMC passes.
 # usage: tools/profile_round.sh <tag>      -> gpurun_out/<tag>_*
-tag=${1:-r4}
+tag=${1:-r5}
 repo=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$repo/gpurun_out
 mkdir -p $out
