@@ -84,6 +84,10 @@ def parse_args():
                              'median region is reported')
     parser.add_argument('--config', default='conv',
                         choices=['conv', 'transformer'])
+    parser.add_argument('--precision', default='f32',
+                        choices=['f32', 'bf16x3', 'bf16x6'],
+                        help='--config transformer only: the opt-in '
+                             'split-bf16 attention (engine.Engine)')
     parser.add_argument('--workload', default='batch',
                         choices=['batch', 'corpus', 'longform'],
                         help='batch: BASELINE configs[1] per GPU (weak '
@@ -356,12 +360,14 @@ class Runner:
     one resident batch; `step()` enqueues one pass on the next lane."""
 
     def __init__(self, config, state, device, audios, alignments, streams=2,
-                 tile=None, winograd=True, graph=True, plan=None, packed=None):
+                 tile=None, winograd=True, graph=True, plan=None, packed=None,
+                 precision='f32'):
         """`audios` + `alignments` (configs[1]: one chunk per utterance), or a
         ready `plan` with its `packed` device audio (the sharded workloads)."""
         self.device = device
         self.engine = emphases_amd.engine.Engine(
-            config, state, device, conv_tile=tile, winograd=winograd)
+            config, state, device, conv_tile=tile, winograd=winograd,
+            precision=precision)
         if plan is None:
             plan = build_plan(audios, alignments)
             packed = torch.cat(
@@ -373,7 +379,8 @@ class Runner:
         for index in range(max(1, streams)):
             engine = self.engine if index == 0 else \
                 emphases_amd.engine.Engine(
-                    config, state, device, conv_tile=tile, winograd=winograd)
+                    config, state, device, conv_tile=tile, winograd=winograd,
+                    precision=precision)
             stream = torch.cuda.Stream(device=device) if streams > 1 \
                 else torch.cuda.current_stream()
             with torch.cuda.stream(stream):
@@ -595,7 +602,14 @@ def executed_matrix_flops(dominant, launches_per_step, committed, spans=None,
     return result
 
 
-def roofline(kernels, passes, ms_per_step, config, spans=None, layers=None):
+PEAK_BF16_MFMA = 2500.        # TFLOP/s dense, same guide
+# 32 x 32 tiles of the split attention: 7 x terms v_mfma_f32_32x32x16_bf16 (the head
+# dimension padded 40 -> 48, the value rows 41 -> 64) per 2 x 2 x 32 x 32 x 40 flops
+SPLIT_EXECUTED = {'bf16x3': 7 * 3 * 32768 / 163840., 'bf16x6': 7 * 6 * 32768 / 163840.}
+
+
+def roofline(kernels, passes, ms_per_step, config, spans=None, layers=None,
+             precision='f32'):
     """`frac` = matrix flops the dominant kernel EXECUTES (its MFMA
     instructions, counted by PMC) per second of kernel time, over the dense
     fp32 MFMA peak: a fraction of the pipe, at most 1.  The direct-form figure
@@ -621,14 +635,26 @@ def roofline(kernels, passes, ms_per_step, config, spans=None, layers=None):
     executed = executed_matrix_flops(
         dominant, launches_per_step, committed, spans, layers)
     executed_flops = executed.get('flops')
+    peak = PEAK_FP32_MFMA
+    if precision != 'f32' and dominant.startswith('attention'):
+        # the split kernel's bf16 instructions, against the bf16 peak (the time
+        # includes the emph_split_kv launch that prepares the pieces)
+        executed = {'flops': flops / launches * SPLIT_EXECUTED[precision],
+                    'mfma_instructions_source':
+                        'algorithmic flops x 7 x terms x 32768 / 163840 '
+                        '(32 x 32 tiles, head dimension 40 -> 48, value rows '
+                        '41 -> 64; tile edges not counted)'}
+        executed_flops = executed['flops']
+        peak = PEAK_BF16_MFMA
+        committed = dict(committed, mfma_pipe_busy=None)
     if executed_flops is None:         # (a kernel without a Winograd saving)
         executed_flops = flops / launches
     achieved = executed_flops / (kernel_us * 1e-6) / 1e12
     algorithmic = flops / launches / (kernel_us * 1e-6) / 1e12
     result = {
         'bound': 'mfma', 'kernel': dominant,
-        'achieved': achieved, 'peak': PEAK_FP32_MFMA,
-        'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA,
+        'achieved': achieved, 'peak': peak,
+        'unit': 'TFLOP/s', 'frac': achieved / peak,
         'frac_is': 'EXECUTED matrix flops (MFMA instructions by PMC x flops '
                    'per instruction) per second of kernel time over the dense '
                    'fp32 MFMA peak; the vector work of the kernel (Winograd '
@@ -671,8 +697,9 @@ def roofline(kernels, passes, ms_per_step, config, spans=None, layers=None):
     if committed.get('rocprof_avg_launch_us'):
         average = committed['rocprof_avg_launch_us']
         result['rocprof_avg_launch_us'] = average
-        result['frac_at_rocprof_avg'] = \
-            executed_flops / (average * 1e-6) / 1e12 / PEAK_FP32_MFMA
+        if precision == 'f32':
+            result['frac_at_rocprof_avg'] = \
+                executed_flops / (average * 1e-6) / 1e12 / PEAK_FP32_MFMA
     return result, committed
 
 
@@ -787,18 +814,29 @@ def end_to_end_api(audios, alignments, rounds=200):
     return result
 
 
-def side_transformer(device, audios, alignments, args):
+def side_transformer(device, audios, alignments, args, precision='f32',
+                     baseline=None):
     """BASELINE configs[2]: the same 64 x 10 s batch, Transformer config
-    (seeded weights), same protocol as the headline."""
+    (seeded weights), same protocol as the headline.  `precision` 'bf16x3' /
+    'bf16x6': the opt-in split-bf16 attention (never the headline), with its
+    worst score difference to the f32 run's scores (`baseline`)."""
     config = cfg.Config(architecture='transformer')
     state = emphases_amd.weights.random_state(config, seed=0)
-    runner = Runner(config, state, device, audios, alignments, streams=2)
+    runner = Runner(config, state, device, audios, alignments, streams=2,
+                    precision=precision)
     steps = max(10, min(args.steps, 40))
-    laps, ramp, _ = timed_regions(runner, steps, 5, 5, 1)
+    laps, ramp, scores = timed_regions(runner, steps, 5, 5, 1)
     line = summary(laps, steps)
+    line['precision'] = precision
+    kept = scores[runner.columns].clone()
+    if baseline is not None:
+        line['max_abs_dscore_vs_f32'] = float((kept - baseline).abs().max())
+        line['words_compared'] = int(kept.numel())
+    line['_scores'] = kept
     kernels, passes = runner.kernel_times(5)
     roof, committed = roofline(
-        kernels, passes, line['ms_per_step'], 'transformer')
+        kernels, passes, line['ms_per_step'], 'transformer',
+        precision=precision)
     line.update({
         'workload': '64 synthetic 10 s 16 kHz utterances, Transformer config '
                     '(6 post-LN layers, 2 heads, 80 channels; seeded '
@@ -1389,7 +1427,8 @@ def run_batch(args, rank, world, device, host):
     audios, alignments, bounds = workload(rank)
     runner = Runner(config, state, device, audios, alignments,
                     streams=args.streams, tile=args.tile,
-                    winograd=not args.no_winograd, graph=not args.no_graph)
+                    winograd=not args.no_winograd, graph=not args.no_graph,
+                    precision=args.precision)
     plan, columns = runner.plan, runner.columns
 
     # The one exchange of the path (north_star: "RCCL gather of per-word scores
@@ -1458,7 +1497,7 @@ def run_batch(args, rank, world, device, host):
     if rank == 0:
         roof, committed = roofline(
             kernels, passes, line['ms_per_step'], args.config,
-            spans=stack_spans, layers=frame_layers)
+            spans=stack_spans, layers=frame_layers, precision=args.precision)
         total_utterances = UTTERANCES * world
         result = {
             'metric': 'utterances/s (10 s @16 kHz) whole-node',
@@ -1476,7 +1515,10 @@ def run_batch(args, rank, world, device, host):
                 'ranks)'),
             'preroll': ramp,
             'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None,
+            'dtype': 'f32' if args.precision == 'f32' else
+            f'f32 operands, attention products as {args.precision} '
+            '(bf16 pieces, fp32 accumulation)', 'data': 'synthetic',
             'config': {
                 'workload': (
                     f'{UTTERANCES} synthetic 10 s 16 kHz utterances per GPU, '
@@ -1528,8 +1570,16 @@ def run_batch(args, rank, world, device, host):
                     end_to_end_api, audios, alignments)
             if not args.no_side:
                 result['files_api'] = guarded(side_files_api, device)
-                result['configs_2_transformer'] = guarded(
+                plain = guarded(
                     side_transformer, device, audios, alignments, args)
+                reference_scores = plain.pop('_scores', None)
+                result['configs_2_transformer'] = plain
+                for precision in ('bf16x3', 'bf16x6'):
+                    entry = guarded(
+                        side_transformer, device, audios, alignments, args,
+                        precision, reference_scores)
+                    entry.pop('_scores', None)
+                    result[f'configs_2_transformer_{precision}'] = entry
                 result['configs_4_longform'] = guarded(side_longform, device)
                 result['configs_3_corpus'] = guarded(side_corpus, device)
         emit(result)

@@ -47,12 +47,15 @@ def active_config():
 
 
 @functools.lru_cache(maxsize=8)
-def _engine(checkpoint, device_index, config, conv_tile=None):
+def _engine(checkpoint, device_index, config, conv_tile=None,
+            precision='f32'):
     return engine_module.Engine(
-        config, checkpoint, device_index, conv_tile=conv_tile)
+        config, checkpoint, device_index, conv_tile=conv_tile,
+        precision=precision)
 
 
-def get_engine(checkpoint=None, gpu=None, config=None, conv_tile=None):
+def get_engine(checkpoint=None, gpu=None, config=None, conv_tile=None,
+               precision='f32'):
     """Cached `Engine` per (checkpoint, device, config, conv_tile) — the
     explicit form of the reference's function-attribute cache
     (`core.py:298-315`).  `conv_tile`: positions per frame-rate conv tile.
@@ -61,12 +64,14 @@ def get_engine(checkpoint=None, gpu=None, config=None, conv_tile=None):
     in any batch and on any shard; 64 / 32 / 16 pin a tile; 'auto' picks the
     lowest-latency variant by batch size (a few utterances then take the
     direct form, which agrees with the Winograd kernels to 1e-6, not
-    bitwise)."""
+    bitwise).  `precision`: 'f32', or the opt-in 'bf16x3' / 'bf16x6' of
+    `engine.Engine`."""
     device = runtime.require_gpu(gpu)
     index = device.index if device.index is not None else \
         torch.cuda.current_device()
     checkpoint = None if checkpoint is None else os.fspath(checkpoint)
-    return _engine(checkpoint, index, config or active_config(), conv_tile)
+    return _engine(checkpoint, index, config or active_config(), conv_tile,
+                   precision)
 
 
 ###############################################################################
@@ -108,26 +113,30 @@ def _tracks(engine, plan, audios, pitch_tracker, gpu):
 
 
 @functools.lru_cache(maxsize=8)
-def _session(checkpoint, device_index, config, conv_tile=None):
+def _session(checkpoint, device_index, config, conv_tile=None,
+             precision='f32'):
     from . import session
     return session.Session(
-        _engine(checkpoint, device_index, config, conv_tile), depth=2)
+        _engine(checkpoint, device_index, config, conv_tile, precision),
+        depth=2)
 
 
-def get_session(checkpoint=None, gpu=None, config=None, conv_tile=None):
+def get_session(checkpoint=None, gpu=None, config=None, conv_tile=None,
+                precision='f32'):
     """Cached `session.Session` (batches in flight on their own streams) of
     the cached engine."""
     device = runtime.require_gpu(gpu)
     index = device.index if device.index is not None else \
         torch.cuda.current_device()
     checkpoint = None if checkpoint is None else os.fspath(checkpoint)
-    return _session(checkpoint, index, config or active_config(), conv_tile)
+    return _session(checkpoint, index, config or active_config(), conv_tile,
+                    precision)
 
 
 def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
                                checkpoint=None, batch_size=None, gpu=None,
                                config=None, pitch_tracker=None,
-                               conv_tile=None):
+                               conv_tile=None, precision='f32'):
     """Scores for many utterances in one ragged batch.
 
     audios: float tensors [1, S] (or [S]); int16 tensors are taken as 16-bit
@@ -137,8 +146,9 @@ def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
         the stand-in for `penn.from_audio` (`data/preprocess/core.py:84-92`):
         `(chunk audio [1, Sc]) -> (pitch [1, Fc] Hz, periodicity [1, Fc])`;
         default: `penn` itself, if installed.
+    precision: 'f32' (default), or 'bf16x3' / 'bf16x6' (`engine.Engine`).
     Returns a list of float32 tensors [1, W_i] (CPU if `gpu is None`)."""
-    session = get_session(checkpoint, gpu, config, conv_tile)
+    session = get_session(checkpoint, gpu, config, conv_tile, precision)
     with runtime.few_host_threads():
         return session.run(
             alignments, audios, sample_rate, batch_size,

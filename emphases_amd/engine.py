@@ -28,6 +28,8 @@ from . import runtime
 from . import weights as weights_module
 
 FRONTEND_BLOCK = None   # frames per front-end tile: emph_frontend_block()
+# `precision` of an engine -> bf16 pieces per fp32 operand (0: fp32 MFMA)
+PRECISIONS = {'f32': 0, 'bf16x3': 2, 'bf16x6': 3}
 ATTENTION_BLOCK = 64    # queries per attention wave (csrc/transformer.hip)
 ATTENTION_GROUP = 256   # queries per attention workgroup (LDS-staged keys/values)
 # Which kernel takes a segment depends on the segment alone (scores must not
@@ -95,8 +97,19 @@ class Engine:
     """Weights + constants on one device, and the kernel sequence."""
 
     def __init__(self, config=cfg.DEFAULT, state=None, device=None,
-                 conv_tile=None, winograd=True):
+                 conv_tile=None, winograd=True, precision='f32'):
+        """`precision`: 'f32' (default: every product on the fp32 matrix
+        instruction) or, an opt-in for the Transformer's attention over long
+        segments, 'bf16x3' / 'bf16x6': fp32 operands split into two / three
+        bf16 pieces, three / six products per term on the bf16 matrix pipe,
+        fp32 accumulation (csrc/attention_split.hip; the reference itself
+        runs these matmuls under bf16 / fp16 autocast, core.py:594-607)."""
+        if precision not in PRECISIONS:
+            raise ValueError(
+                f'precision {precision!r} is not one of {sorted(PRECISIONS)}')
         self.config = config
+        self.precision = precision
+        self.split_pieces = PRECISIONS[precision]
         self.winograd = winograd
         self.device = runtime.require_gpu(device)
         self.lib = runtime.library()
@@ -714,6 +727,47 @@ class Engine:
                     config.layer_norm_eps, 0, ld, runtime.stream()),
                     'emph_add_layernorm')
 
+        # precision='bf16x3' / 'bf16x6': long segments take the bf16 matrix
+        # pipe - the layer's keys and values are split once (all 64-position
+        # tiles of the axis), the grouped launch reads the pieces
+        split_images = None
+        if self.split_pieces and config.channels // config.heads == 40 and \
+                any(tile_n == ATTENTION_GROUP for _, _, tile_n in launches):
+            size = int(self.lib.emph_split_kv_bytes(
+                ld, len(plan.segments), channels, config.heads,
+                self.split_pieces))
+            key = (tag + '_split_kv', (size,))
+            split_images = self._workspace.get(key)
+            if split_images is None:
+                for stale in [k for k in self._workspace if k[0] == key[0]]:
+                    del self._workspace[stale]
+                split_images = torch.empty(
+                    size, dtype=torch.uint8, device=self.device)
+                self._workspace[key] = split_images
+
+        def attend():
+            for tiles, count, tile_n in launches:
+                counts_pointer = None if key_counts is None else \
+                    key_counts.data_ptr()
+                if split_images is not None and tile_n == ATTENTION_GROUP:
+                    runtime.check(self.lib.emph_split_kv(
+                        qk.data_ptr(), v.data_ptr(), ld, channels,
+                        config.heads, att_tiles.data_ptr(), att_count,
+                        ATTENTION_BLOCK, self.split_pieces,
+                        split_images.data_ptr(), runtime.stream()),
+                        'emph_split_kv')
+                    runtime.check(self.lib.emph_attention_split(
+                        qk.data_ptr(), split_images.data_ptr(),
+                        attended.data_ptr(), ld, channels, config.heads,
+                        tiles.data_ptr(), count, tile_n, counts_pointer,
+                        self.split_pieces, runtime.stream()),
+                        'emph_attention_split')
+                    continue
+                runtime.check(self.lib.emph_attention(
+                    qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld,
+                    channels, config.heads, tiles.data_ptr(), count, tile_n,
+                    counts_pointer, runtime.stream()), 'emph_attention')
+
         projected_ahead = False     # this layer's Q, K, V came out of the last block
         for layer in layers:
             if projected_ahead:
@@ -735,13 +789,7 @@ class Engine:
                            None, transpose_out=True)
             projected_ahead = False
             with self._timed(f'attention_{tag}', attention_flops):
-                for tiles, count, tile_n in launches:
-                    runtime.check(self.lib.emph_attention(
-                        qk.data_ptr(), v.data_ptr(), attended.data_ptr(), ld,
-                        channels, config.heads, tiles.data_ptr(), count,
-                        tile_n,
-                        None if key_counts is None else key_counts.data_ptr(),
-                        runtime.stream()), 'emph_attention')
+                attend()
             if layer['block_qkv'] is not None and block <= 32 and self.fuse_qkv:
                 # (attention has consumed qk / v: the next layer's go there)
                 packs, vectors = layer['block_qkv']

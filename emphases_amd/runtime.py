@@ -137,6 +137,12 @@ SIGNATURES = {
         _ptr, _i64, _ptr, _i32, _i32, _ptr, _i32, _i32, _ptr]),
     'emph_attention': (_c.c_int, [
         _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i32, _i32, _ptr, _ptr]),
+    'emph_split_kv_bytes': (_i64, [_i64, _i32, _i32, _i32, _i32]),
+    'emph_split_kv': (_c.c_int, [
+        _ptr, _ptr, _i64, _i32, _i32, _ptr, _i32, _i32, _i32, _ptr, _ptr]),
+    'emph_attention_split': (_c.c_int, [
+        _ptr, _ptr, _ptr, _i64, _i32, _i32, _ptr, _i32, _i32, _ptr, _i32,
+        _ptr]),
     'emph_word_transformer_pack_size': (_i64, [_i32, _i32]),
     'emph_word_transformer_pack': (_c.c_int, [_ptr] * 12 + [_i32, _i32, _ptr]),
     'emph_word_transformer': (_c.c_int, [

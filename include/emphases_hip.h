@@ -604,6 +604,30 @@ int emph_attention(const float* qk, const float* v, float* out, int64_t ld,
                    int32_t n_tiles, int32_t tile_n, const int32_t* key_counts,
                    void* stream);
 
+/* The same attention for segments of >= 128 positions (tile_n 256: the tile
+ * table of emph_attention's grouped kernel) on the bf16 matrix pipe, every
+ * fp32 operand split into `pieces` bf16 pieces (emphases_amd/csrc/
+ * attention_split.hip): pieces = 2 keeps three products per term ("bf16x3",
+ * each product within 2^-16), pieces = 3 six ("bf16x6": the pieces represent
+ * the fp32 operands exactly and what is dropped is below one fp32 rounding).
+ * fp32 in, fp32 accumulation, fp32 out; head dimension 40.  An opt-in of the
+ * host side (`precision=`): the reference's own inference path runs its
+ * matmuls under bf16 / fp16 autocast (emphases/core.py:594-607).
+ *
+ * Two calls per layer: emph_split_kv splits this layer's keys and values once
+ * (tile_n 64 tile table of the frame axis; `images` = scratch of
+ * emph_split_kv_bytes(ld, n_segments, ...) bytes, 16-byte aligned), then
+ * emph_attention_split reads Q from `qk` and the keys / values from `images`. */
+int64_t emph_split_kv_bytes(int64_t ld, int32_t n_segments, int32_t channels,
+                            int32_t heads, int32_t pieces);
+int emph_split_kv(const float* qk, const float* v, int64_t ld, int32_t channels,
+                  int32_t heads, const int32_t* tiles, int32_t n_tiles,
+                  int32_t tile_n, int32_t pieces, void* images, void* stream);
+int emph_attention_split(const float* qk, const void* images, float* out,
+                         int64_t ld, int32_t channels, int32_t heads,
+                         const int32_t* tiles, int32_t n_tiles, int32_t tile_n,
+                         const int32_t* key_counts, int32_t pieces, void* stream);
+
 /* y = LayerNorm(x + r) over channels for columns [first_column,
  * first_column + columns) (post-LN residual of nn.TransformerEncoderLayer,
  * transformer.py:18-23; eps 1e-5).  channels <= 128. */

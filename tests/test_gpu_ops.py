@@ -593,6 +593,83 @@ def test_attention(channels, heads, tile_n):
         assert float((out[:, off:off + count] - want).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize('pieces', [2, 3])
+def test_attention_split(pieces):
+    """emph_attention_split (bf16 pieces on the bf16 matrix pipe) against a
+    float64 reference, with the fp32-MFMA kernel's own error beside it:
+    three pieces stay within 2x of the fp32 kernel, two pieces within 2e-5."""
+    lib = runtime.library()
+    channels, heads, tile_n = 80, 2, 256
+    plan = ragged_plan([130, 16, 1, 700, 65, 1000, 257])
+    axis = runtime.AXIS_FRAMES
+    meta = Meta(plan, [(axis, tile_n), (axis, 64)])
+    ld = plan.ld_frames
+    qk = random_packed(2 * channels, plan, axis, 21) * 3.0
+    v = torch.from_numpy(synth.weights(22, (ld, channels), 1.0))
+    # padding of the packed axes may hold anything
+    for off, count in spans(plan, axis):
+        qk[:, off + count:off + count + 3] = float('nan')
+        v[off + count:off + count + 3] = float('nan')
+    tiles, size = meta.view(('tiles', axis, tile_n))
+    stage_tiles, stage_size = meta.view(('tiles', axis, 64))
+    qk_dev, v_dev = qk.to(DEVICE), v.to(DEVICE)
+    d = channels // heads
+    image_bytes = lib.emph_split_kv_bytes(
+        ld, len(plan.segments), channels, heads, pieces)
+    assert image_bytes > 0
+    # (stale bytes of another use of the scratch: every NaN pattern)
+    images = torch.full((image_bytes // 2,), -1, dtype=torch.int16,
+                        device=DEVICE)
+
+    def reference(off, count, keys):
+        q = qk[:channels, off:off + count].T.reshape(count, heads, d).double()
+        k = qk[channels:, off:off + keys].T.reshape(keys, heads, d).double()
+        vv = v[off:off + keys].reshape(keys, heads, d).double()
+        scores = torch.einsum('qhd,khd->hqk', q, k) / np.sqrt(d)
+        return torch.einsum(
+            'hqk,khd->qhd', torch.softmax(scores, -1), vv).reshape(
+                count, channels).T
+
+    for key_counts in (None, np.array([50, 16, 1, 333, 17, 999, 200],
+                                      dtype=np.int32)):
+        counts_dev = None if key_counts is None else \
+            torch.from_numpy(key_counts).to(DEVICE)
+        pointer = None if key_counts is None else counts_dev.data_ptr()
+        plain = torch.full((channels, ld), float('nan'), device=DEVICE)
+        split = torch.full((channels, ld), float('nan'), device=DEVICE)
+        runtime.check(lib.emph_attention(
+            qk_dev.data_ptr(), v_dev.data_ptr(), plain.data_ptr(), ld,
+            channels, heads, tiles.data_ptr(), size // 4, tile_n, pointer,
+            None), 'emph_attention')
+        runtime.check(lib.emph_split_kv(
+            qk_dev.data_ptr(), v_dev.data_ptr(), ld, channels, heads,
+            stage_tiles.data_ptr(), stage_size // 4, 64, pieces,
+            images.data_ptr(), None), 'emph_split_kv')
+        runtime.check(lib.emph_attention_split(
+            qk_dev.data_ptr(), images.data_ptr(), split.data_ptr(), ld,
+            channels, heads, tiles.data_ptr(), size // 4, tile_n, pointer,
+            pieces, None), 'emph_attention_split')
+        plain, split = plain.cpu().double(), split.cpu().double()
+        worst_plain = worst_split = 0.
+        for index, (off, count) in enumerate(spans(plan, axis)):
+            keys = count if key_counts is None else int(key_counts[index])
+            want = reference(off, count, keys)
+            worst_plain = max(worst_plain, float(
+                (plain[:, off:off + count] - want).abs().max()))
+            worst_split = max(worst_split, float(
+                (split[:, off:off + count] - want).abs().max()))
+        print(f'pieces {pieces}: |split - f64| {worst_split:.2e}, '
+              f'|fp32 kernel - f64| {worst_plain:.2e}')
+        assert worst_plain < 5e-6
+        assert worst_split < (4e-5 if pieces == 2 else
+                              max(2. * worst_plain, 2e-6))
+    with pytest.raises(runtime.LibraryError, match='pieces'):
+        runtime.check(lib.emph_attention_split(
+            qk_dev.data_ptr(), images.data_ptr(), split.data_ptr(), ld,
+            channels, heads, tiles.data_ptr(), size // 4, tile_n, None, 4,
+            None), 'emph_attention_split')
+
+
 def test_add_layernorm_and_position():
     lib = runtime.library()
     plan = ragged_plan([100, 37])

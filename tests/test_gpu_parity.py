@@ -408,6 +408,62 @@ def test_full_size_transformer_batch():
             assert np.abs(a.numpy() - want.numpy()).max() < SCORE_TOLERANCE
 
 
+@pytest.mark.parametrize('precision,budget', [('bf16x3', 1e-5), ('bf16x6', 3e-6)])
+def test_split_precision_attention(variants, precision, budget):
+    """The opt-in split-bf16 attention (`precision=` of the engine; csrc/
+    attention_split.hip) on the reference's Transformer goldens and on
+    BASELINE configs[2] utterances: the scores stay within `budget` of the
+    f32 engine's and within the f32 tests' own bound of the reference's; the
+    default stays f32."""
+    config = cfg.Config(architecture='transformer')
+    assert engine_module.Engine(
+        config, weights.random_state(config, 0), 0).precision == 'f32'
+    with pytest.raises(ValueError, match='precision'):
+        engine_module.Engine(config, weights.random_state(config, 0), 0,
+                             precision='bf16')
+    audio = synth.pcm_to_float(variants['audio_pcm'])
+    bounds = variants['bounds_frames'].astype(np.int64)
+    worst_reference = 0.
+    for name in variants['names']:
+        if 'architecture=transformer' not in str(name):
+            continue
+        variant, _ = variant_config(name)
+        engine = engine_module.Engine(
+            variant, variant_state(variants, name, variant), 0,
+            precision=precision)
+        plan, scores, logits = run_case(engine, audio, bounds, None)
+        columns = plan.word_columns()
+        delta = np.abs(scores.cpu().numpy()[columns] -
+                       variants[f'{name}/scores']).max()
+        worst_reference = max(worst_reference, float(delta))
+        # (two of the four are 'input' variants: word pieces are short
+        # segments and keep the fp32 kernel - the bound holds for all)
+        assert delta < max(budget, 5e-6), (str(name), delta)
+    # BASELINE configs[2]: 10 s utterances, every word of every utterance
+    state = weights.random_state(config, seed=0)
+    count, frames = 8, 1000
+    audios = [torch.from_numpy(synth.audio(i, frames)) for i in range(count)]
+    aligns = [emphases_amd.Alignment.from_frames(synth.word_frames(i, frames))
+              for i in range(count)]
+    plain = emphases_amd.from_alignments_and_audios(
+        aligns, audios, checkpoint=state_file(state), config=config)
+    split = emphases_amd.from_alignments_and_audios(
+        aligns, audios, checkpoint=state_file(state), config=config,
+        precision=precision)
+    again = emphases_amd.from_alignments_and_audios(
+        aligns, audios, checkpoint=state_file(state), config=config,
+        precision=precision)
+    worst = 0.
+    for a, b, c in zip(plain, split, again):
+        assert torch.equal(b, c)                    # deterministic
+        assert not torch.equal(a, b)                # (it IS another kernel)
+        worst = max(worst, float((a - b).abs().max()))
+    print(f'{precision}: worst |score - f32 engine| {worst:.2e} over '
+          f'{sum(a.shape[1] for a in plain)} words; worst |score - '
+          f'reference golden| {worst_reference:.2e}')
+    assert worst < budget
+
+
 _STATE_FILES = {}
 
 
