@@ -19,6 +19,7 @@ instead of ATen.  Deliberate, documented deviations:
 import contextlib
 import functools
 import os
+import time
 
 import numpy as np
 import torch
@@ -149,10 +150,9 @@ def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
     precision: 'f32' (default), or 'bf16x3' / 'bf16x6' (`engine.Engine`).
     Returns a list of float32 tensors [1, W_i] (CPU if `gpu is None`)."""
     session = get_session(checkpoint, gpu, config, conv_tile, precision)
-    with runtime.few_host_threads():
-        return session.run(
-            alignments, audios, sample_rate, batch_size,
-            on_device=gpu is not None, pitch_tracker=pitch_tracker)
+    return session.run(
+        alignments, audios, sample_rate, batch_size,
+        on_device=gpu is not None, pitch_tracker=pitch_tracker)
 
 
 def from_alignment_and_audio(alignment, audio, sample_rate, checkpoint=None,
@@ -232,35 +232,68 @@ def files_to_scores(text_files, audio_files, session, batch_size=None,
     for file in text_files:
         if not str(file).endswith(('.TextGrid', '.json')):
             from_text_and_audio(None, None, None)
-    with runtime.few_host_threads():
-        _files_to_scores(text_files, audio_files, session, batch_size,
-                         utterances_per_batch, deliver, deliver_batch)
+    _files_to_scores(text_files, audio_files, session, batch_size,
+                     utterances_per_batch, deliver, deliver_batch)
+
+
+# `files_to_scores` appends (stage, batch, start, end) in perf_counter_ns here when
+# it is a list (tools/files_timeline.py): where the three stages of a batch run
+TIMELINE = None
+
+
+def _stamp(stage, position, start):
+    if TIMELINE is not None:
+        TIMELINE.append((stage, position, start, time.perf_counter_ns()))
 
 
 def _files_to_scores(text_files, audio_files, session, batch_size,
                      utterances_per_batch, deliver, deliver_batch):
-    """Three things run side by side (two helper threads; what they call are
-    library or numpy routines that leave the interpreter lock alone):
+    """Three stages run side by side, each on a thread of its own (what the
+    helpers call are library or numpy routines that leave the interpreter lock
+    alone; none of them enters a torch CPU parallel region):
 
-        opener   batch i + 1: open + parse + header walk (`files.FileBatch`),
-                 the samples into a pinned buffer of the session
-                 (`read_all`), the plan (`batch.plan_batch`)
-        caller   batch i: metadata tables (`Engine.prepare`), DMA + kernels
-                 (`Session.submit`), then the scores of batch i - 1
-        writer   batch i - 1: `<prefix>.TextGrid` + `<prefix>.pt`"""
+        openers  batches i + 1 and i + 2 (two threads: an opener waits on the
+                 library's pool and on the interpreter lock in turn, so one of
+                 them delivered a batch per 4.9 ms against 2.5 ms alone,
+                 profiles/r5_files_timeline.txt): open + parse + header walk
+                 (`files.FileBatch`), the samples into a pinned buffer of the
+                 session (`read_all`), the plan (`batch.plan_batch`) and its
+                 metadata tables (`Engine.prepare`)
+        caller   batch i: DMA + kernels (`Session.submit`), then the scores
+                 of batch i - 1
+        writer   batch i - 1: `<prefix>.TextGrid` + `<prefix>.pt`
+
+    The library's file pool is sized per stage from the CPUs the process may
+    keep busy (`files.stage_threads`): a cgroup that allows fewer CPUs than the
+    machine shows FREEZES the process for the rest of the period when opener,
+    writer, caller and the HIP runtime's threads together exceed the quota.
+    A failure anywhere still finishes and writes every batch submitted before
+    it - like the reference's loop (`core.py:169-179`), which leaves the
+    outputs of every file in front of the bad one - then raises."""
+    import collections
     import concurrent.futures
     from . import files
+    from . import session as session_module
     engine = session.engine
+    open_threads, write_threads = files.stage_threads(session_module.FILE_BUFFERS - 2)
 
     def open_batch(first, last, turn):
-        torch.set_num_threads(1)        # (this thread's OpenMP setting too)
+        start = time.perf_counter_ns()
         opened = files.FileBatch(
-            text_files[first:last], audio_files[first:last])
-        alignments = opened.all_alignments()
+            text_files[first:last], audio_files[first:last], open_threads)
+        _stamp('open.parse', turn, start)
+        begin = time.perf_counter_ns()
+        # (word-time tables, not alignment objects: nothing per file for the
+        # interpreter's collector to trace; `deliver` builds what it asks for)
+        alignments = opened.all_times()
         loaded = opened.all_audios()
+        _stamp('open.objects', turn, begin)
+        begin = time.perf_counter_ns()
         # the samples: straight into one of the session's pinned buffers
         with torch.cuda.device(session.engine.device):
             opened.read_all(session.file_buffer(turn, opened.audio_bytes()))
+        _stamp('open.read', turn, begin)
+        begin = time.perf_counter_ns()
         groups = []
         for rate in sorted({rate for _, rate in loaded}):
             chosen = [i for i, (_, r) in enumerate(loaded) if r == rate]
@@ -269,54 +302,79 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
             plan = None
             if rate == cfg.SAMPLE_RATE and all(
                     a.dim() == 1 or a.shape[0] == 1 for a in audios):
-                plan = batch.plan_batch(
-                    picked, [int(a.shape[-1]) for a in audios], batch_size)
+                plan = engine.prepare(batch.plan_batch(
+                    picked, [int(a.shape[-1]) for a in audios], batch_size))
             groups.append((rate, chosen, picked, audios, plan))
+        _stamp('open.plan', turn, begin)
+        _stamp('open', turn, start)
         return opened, groups
 
-    def write(opened, chosen, indices, scores):
-        torch.set_num_threads(1)
+    def write(position, opened, chosen, indices, scores):
+        start = time.perf_counter_ns()
+        opened.threads = write_threads
         if deliver_batch is not None:
             deliver_batch(opened, chosen, indices, scores)
         else:
             for local, index, item in zip(chosen, indices, scores):
                 deliver(index, opened.alignment(local), item)
+        _stamp('write', position, start)
 
     starts = list(range(0, len(text_files), utterances_per_batch))
-    with concurrent.futures.ThreadPoolExecutor(2) as helpers:
-        writes, in_flight = [], []
+    ahead = session_module.FILE_BUFFERS - 2
+    opener = concurrent.futures.ThreadPoolExecutor(
+        ahead, thread_name_prefix='emphases-open')
+    writer = concurrent.futures.ThreadPoolExecutor(
+        1, thread_name_prefix='emphases-write')
+    writes, in_flight, failure = [], [], None
 
-        def finish(jobs):
-            for pending, opened, chosen, indices in jobs:
-                scores = pending.result()
-                writes.append(helpers.submit(
-                    write, opened, chosen, indices, scores))
-            while len(writes) > 2:          # (errors surface; memory bounded)
-                writes.pop(0).result()
+    def finish(jobs, drain=2):
+        for position, pending, opened, chosen, indices in jobs:
+            start = time.perf_counter_ns()
+            scores = pending.scores()
+            _stamp('scores', position, start)
+            writes.append(writer.submit(
+                write, position, opened, chosen, indices, scores))
+        while len(writes) > drain:          # (errors surface; memory bounded)
+            writes.pop(0).result()
 
-        opening = helpers.submit(
-            open_batch, starts[0],
-            min(starts[0] + utterances_per_batch, len(text_files)), 0) \
-            if starts else None
+    def ask(position):
+        first = starts[position]
+        return opener.submit(
+            open_batch, first,
+            min(first + utterances_per_batch, len(text_files)), position)
+
+    try:
+        opening = collections.deque(
+            ask(position) for position in range(min(ahead, len(starts))))
         for position, first in enumerate(starts):
-            opened, groups = opening.result()
-            opening = None
-            if position + 1 < len(starts):
-                following = starts[position + 1]
-                opening = helpers.submit(
-                    open_batch, following,
-                    min(following + utterances_per_batch, len(text_files)),
-                    position + 1)
-            jobs = [(session.submit(
-                picked, audios, rate, batch_size,
-                plan=None if plan is None else engine.prepare(plan)),
+            opened, groups = opening.popleft().result()
+            if position + ahead < len(starts):
+                opening.append(ask(position + ahead))
+            start = time.perf_counter_ns()
+            jobs = [(position, session.submit(
+                picked, audios, rate, batch_size, plan=plan),
                      opened, chosen, [first + i for i in chosen])
                     for rate, chosen, picked, audios, plan in groups]
-            finish(in_flight)
-            in_flight = jobs
-        finish(in_flight)
-        for pending_write in writes:
+            _stamp('submit', position, start)
+            previous, in_flight = in_flight, jobs
+            finish(previous)
+    except BaseException as error:      # noqa: BLE001
+        failure = error
+    # what was submitted is finished and written whatever happened after it
+    for jobs in (in_flight,):
+        try:
+            finish(jobs, drain=0)
+        except BaseException as error:      # noqa: BLE001
+            failure = failure or error
+    for pending_write in writes:
+        try:
             pending_write.result()
+        except BaseException as error:      # noqa: BLE001
+            failure = failure or error
+    opener.shutdown(wait=True, cancel_futures=True)
+    writer.shutdown(wait=True)
+    if failure is not None:
+        raise failure
 
 
 def from_files_to_files(text_files, audio_files, output_prefixes=None,

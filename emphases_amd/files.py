@@ -54,10 +54,29 @@ THREADS = int(os.environ.get(
     'EMPHASES_FILE_THREADS', max(2, min(16, _cpu_budget() // 2))))
 
 
+def stage_threads(openers=1):
+    """(threads of an open call, threads of a write call) for the file API's
+    pipeline, where `openers` open calls, a write call, the calling thread and
+    the HIP runtime's own threads run at once: together they stay under the
+    CPU budget (a throttled cgroup loses whole scheduler periods).  Opening
+    has the most to do (parse + read), so it gets the larger share."""
+    if 'EMPHASES_OPEN_THREADS' in os.environ or \
+            'EMPHASES_WRITE_THREADS' in os.environ:
+        return (int(os.environ.get('EMPHASES_OPEN_THREADS', THREADS)),
+                int(os.environ.get('EMPHASES_WRITE_THREADS', THREADS)))
+    if 'EMPHASES_FILE_THREADS' in os.environ:
+        return THREADS, THREADS
+    spare = max(2, _cpu_budget() - 4)        # the caller, HIP's threads, the helpers
+    opening = max(1, min(12, spare * 3 // 5))
+    writing = max(1, min(8, spare - opening))
+    return max(1, opening // max(1, openers)), writing
+
+
 class FileAudio:
     """Stands in for the 1-D tensor of a mono 16-bit PCM / float32 WAVE file
     whose samples have not been read: the session reads them straight into its
     staging buffer (`Session` looks at `shape`, `dtype`, `is_cuda` only)."""
+    __slots__ = ('batch', 'index', 'shape', 'dtype', 'rate', 'staged')
     is_cuda = False
 
     def __init__(self, batch, index, samples, dtype, rate):
@@ -233,6 +252,17 @@ class FileBatch:
                 lambda i=i: (self.words(i), self.tiers(i)))
             for i in range(self.count)]
 
+    def all_times(self):
+        """Word times of every file as float64 [W, 2] views of one table (what
+        `batch.plan_batch` and `session.layout_key` take in place of alignment
+        objects); `alignment(i)` itself for a file the library does not vouch
+        for."""
+        first = self.word_first.tolist()
+        bad = (self.status & 1).tolist()
+        times = self.times
+        return [self.alignment(i) if bad[i] else times[first[i]:first[i + 1]]
+                for i in range(self.count)]
+
     def all_audios(self):
         """`audio(i)` for every file: `[(FileAudio | tensor, rate)]`."""
         rows = self.sizes.tolist()
@@ -305,11 +335,19 @@ class FileBatch:
                 core._save(self.alignment(index), scores[k], prefixes[k])
         if not native:
             return
-        flat = torch.cat(
-            [scores[k].reshape(-1) for k in native] + [torch.zeros(1)]).to(
-                torch.float32).contiguous()      # (never an empty buffer)
-        first = np.concatenate([[0], np.cumsum(
-            [scores[k].numel() for k in native])]).astype(np.int64)
+        if hasattr(scores, 'flat') and \
+                len(native) == len(indices) == len(scores) and \
+                scores.flat.dtype == torch.float32 and \
+                not scores.flat.is_cuda and scores.flat.numel():
+            # (`session.Scores`: the batch's dense row as it is)
+            flat = scores.flat.reshape(-1).contiguous()
+            first = scores.first
+        else:
+            flat = torch.cat(
+                [scores[k].reshape(-1) for k in native] +
+                [torch.zeros(1)]).to(torch.float32).contiguous()
+            first = np.concatenate([[0], np.cumsum(
+                [scores[k].numel() for k in native])]).astype(np.int64)
         which = np.array([indices[k] for k in native], dtype=np.int32)
         paths = (ctypes.c_char_p * len(native))(
             *[str(prefixes[k]).encode() for k in native])

@@ -186,27 +186,18 @@ def library():
     return _library
 
 
-class few_host_threads:
-    """Context: torch's intra-op CPU pool limited to one thread for the
-    duration of an API call.  The host side of this package only touches
-    small tensors, but ANY parallel region wakes the whole OpenMP pool - as
-    many threads as the machine shows cores - and the pool spins after the
-    region; in a container whose cgroup allows fewer CPUs than it shows
-    (128 cores, quota 16 on the test box) a few such regions exhaust the
-    quota and the kernel FREEZES the process for the rest of the 100 ms
-    period: `from_files_to_files` ran at 5 k files/s with four such freezes
-    in 0.4 s, and at 24 k files/s without (tools/files_probe.py)."""
-
-    def __enter__(self):
-        self.before = torch.get_num_threads()
-        if self.before > 1:
-            torch.set_num_threads(1)
-        return self
-
-    def __exit__(self, *exc):
-        if self.before > 1:
-            torch.set_num_threads(self.before)
-        return False
+# Host code of this package enters no torch CPU parallel region: what it does
+# with tensors on the host is either small (below ATen's grain size) or goes
+# through numpy / the library (`session.host_*`).  ANY parallel region wakes
+# torch's whole OpenMP pool - as many threads as the machine shows cores - and
+# the pool spins after the region; in a container whose cgroup allows fewer
+# CPUs than it shows (128 cores, quota 16 on the test box) a few such regions
+# exhaust the quota and the kernel FREEZES the process for the rest of the
+# 100 ms period (`from_files_to_files`: 5 k files/s with four freezes in
+# 0.4 s, 24 k without; tools/files_probe.py).  Round 4 capped torch's pool
+# around every API call instead (`torch.set_num_threads(1)`, restored after):
+# a process-global switch that throttled a caller's own CPU work in other
+# threads.  It is gone: nothing in this package calls torch.set_num_threads.
 
 
 def require_gpu(device=None):

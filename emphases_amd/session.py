@@ -37,6 +37,34 @@ COPY_THREADS = min(64, max(1, int(os.environ.get('EMPHASES_COPY_THREADS', 16))))
 # run under the PCIe transfer of the next (a rank's 1.28 GB share of BASELINE
 # configs[3]: 23 ms of DMA at 55 GB/s in front of 5.4 ms of kernels).
 SPLIT_BYTES = int(os.environ.get('EMPHASES_SPLIT_BYTES', 256 << 20))
+# pinned buffers the file API's openers rotate through (`core.files_to_scores`
+# keeps FILE_BUFFERS - 2 batches being opened ahead of the one in flight)
+FILE_BUFFERS = 4
+
+
+def host_float32(audio):
+    """float32 copy of a host tensor of another dtype, through numpy: a
+    `Tensor.to` of a long signal is a torch CPU parallel region (runtime.py)."""
+    if audio.is_cuda:
+        return audio.to(torch.float32)
+    return torch.from_numpy(audio.detach().numpy().astype(np.float32))
+
+
+def host_contiguous(audio):
+    """`audio.contiguous()` of a host tensor without a torch copy kernel."""
+    if audio.is_cuda or audio.is_contiguous():
+        return audio.contiguous()
+    return torch.from_numpy(np.ascontiguousarray(audio.detach().numpy()))
+
+
+def host_pcm_to_float(audio):
+    """16-bit PCM -> float32 (x / 32768, exact) on the host, through numpy."""
+    if audio.dtype != torch.int16:
+        return audio if audio.dtype == torch.float32 else host_float32(audio)
+    if audio.is_cuda:
+        return audio.to(torch.float32) / 32768.
+    return torch.from_numpy(
+        audio.detach().numpy().astype(np.float32) * np.float32(1. / 32768.))
 
 
 def mono(audio):
@@ -46,7 +74,7 @@ def mono(audio):
         return audio                  # files.FileAudio: mono by construction
     audio = audio[0] if audio.dim() == 2 else audio.reshape(-1)
     if audio.dtype not in (torch.float32, torch.int16):
-        audio = audio.to(torch.float32)
+        audio = host_float32(audio)
     return audio
 
 
@@ -109,7 +137,7 @@ class _Lane:
         # it is gathered, so the DMA of one runs under the gather of the next.
         from . import runtime
         lib = runtime.library()
-        sources = [audios[i].contiguous() for i in on_host]
+        sources = [host_contiguous(audios[i]) for i in on_host]
         pointers = np.array([a.data_ptr() for a in sources], dtype=np.int64)
         nbytes = np.array([lengths[i] * item for i in on_host], dtype=np.int64)
         where = np.array([offsets[i] * item for i in on_host], dtype=np.int64)
@@ -192,7 +220,7 @@ class _Lane:
                     [int(offsets[i]) * item for i in members],
                     [lengths[i] * item for i in members], base)
             if tensors:
-                sources = [audios[i].contiguous() for i in tensors]
+                sources = [host_contiguous(audios[i]) for i in tensors]
                 runtime.check(runtime.library().emph_host_gather(
                     np.array([a.data_ptr() for a in sources],
                              dtype=np.int64).ctypes.data,
@@ -242,8 +270,35 @@ def layout_key(alignments, lengths, batch_size, dtype):
             tuple(lengths), batch_size, dtype)
 
 
+class Scores:
+    """The scores of a batch as a sequence of per-utterance [1, W_u] views of
+    ONE dense row (`flat`, with `first[u] .. first[u + 1]` the columns of
+    utterance u): the views are made when asked for, so a consumer that wants
+    the row itself (`files.FileBatch.write`) creates no object per utterance."""
+
+    def __init__(self, dense, counts):
+        self.flat = dense                            # [1, total]
+        self.first = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+
+    def __len__(self):
+        return len(self.first) - 1
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            return [self[i] for i in range(*index.indices(len(self)))]
+        if index < 0:
+            index += len(self)
+        if not 0 <= index < len(self):
+            raise IndexError(index)
+        return self.flat[:, int(self.first[index]):int(self.first[index + 1])]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class Pending:
-    """Scores of a submitted batch; `result()` waits for them."""
+    """Scores of a submitted batch; `result()` waits for them (a list of
+    per-utterance tensors), `scores()` for the same as a `Scores`."""
 
     def __init__(self, lane, plan, count, on_device, ld_words):
         self._lane = lane
@@ -253,20 +308,26 @@ class Pending:
         self._ld_words = ld_words
         self._scores = None
         self._value = None
+        self._dense = None
 
     def result(self):
-        if self._value is not None:
-            return self._value
+        if self._value is None:
+            self._value = list(self.scores())
+        return self._value
+
+    def scores(self):
+        if self._dense is not None:
+            return self._dense
         lane, plan = self._lane, self._plan
-        empty = torch.zeros((1, 0))
         if plan is None or not len(plan):
-            self._value = [
-                empty.to(lane.device) if self._on_device else empty.clone()
-                for _ in range(self._count)]
-            return self._value
+            empty = torch.zeros((1, 0))
+            if self._on_device:
+                empty = empty.to(lane.device)
+            self._dense = Scores(empty, np.zeros(self._count, dtype=np.int64))
+            return self._dense
         with lane.lock:
-            if self._value is not None:
-                return self._value
+            if self._dense is not None:
+                return self._dense
             lane.done.synchronize()
             if self._on_device:
                 packed = self._scores
@@ -274,20 +335,24 @@ class Pending:
                 # caching allocator must not hand the block to the lane's next
                 # clone while the caller's kernels still read it
                 packed.record_stream(torch.cuda.current_stream(lane.device))
+                columns = torch.from_numpy(plan.word_columns())
+                dense = packed[columns.to(packed.device)][None]
             else:
-                packed = lane.result[:self._ld_words].clone()
+                # (numpy: the gather of a corpus-sized batch through torch would
+                # be a CPU parallel region, runtime.py; the fancy index copies,
+                # so the pinned buffer is free for the lane's next batch)
+                dense = torch.from_numpy(
+                    lane.result[:self._ld_words].numpy()[
+                        plan.word_columns()])[None]
             if lane.pending is self:
                 lane.pending = None
         # one gather of the valid word columns, one split: per-utterance views
         # [1, W_u] of a dense row (an utterance's chunks are consecutive)
-        columns = torch.from_numpy(plan.word_columns())
-        dense = packed[columns.to(packed.device)][None]
         counts = np.bincount(
             plan.utterance, weights=plan.words, minlength=self._count)
-        self._value = list(
-            dense.split(counts.astype(np.int64).tolist(), dim=1))
+        self._dense = Scores(dense, counts.astype(np.int64))
         self._scores = None
-        return self._value
+        return self._dense
 
 
 class Session:
@@ -334,13 +399,13 @@ class Session:
         return out, targets
 
     def file_buffer(self, turn, nbytes):
-        """Pinned uint8 tensor number `turn % 3` of at least `nbytes` (three
-        rotate: one being read into, one in flight, one whose batch is being
-        finished); kept by the session, since pinning memory takes
-        milliseconds."""
-        while len(self._file_buffers) < 3:
+        """Pinned uint8 tensor number `turn % FILE_BUFFERS` of at least
+        `nbytes` (four rotate: two being read into by the openers, one in
+        flight, one whose batch is being finished); kept by the session, since
+        pinning memory takes milliseconds."""
+        while len(self._file_buffers) < FILE_BUFFERS:
             self._file_buffers.append(None)
-        slot = turn % 3
+        slot = turn % FILE_BUFFERS
         buffer = self._file_buffers[slot]
         if buffer is None or buffer.numel() < nbytes:
             buffer = torch.empty(
@@ -361,9 +426,7 @@ class Session:
         pcm = all(audio.dtype == torch.int16 for audio in audios)
         dtype = torch.int16 if pcm else torch.float32
         if not pcm:
-            audios = [audio.to(torch.float32) / 32768.
-                      if audio.dtype == torch.int16 else audio.to(torch.float32)
-                      for audio in audios]
+            audios = [host_pcm_to_float(audio) for audio in audios]
         lengths = [int(audio.shape[0]) for audio in audios]
         _, orig, new, _ = load.resample_kernel(sample_rate, target_rate)
         targets = [load.resampled_length(n, orig, new) for n in lengths]
@@ -432,7 +495,7 @@ class Session:
             audios = [audio if torch.is_tensor(audio) or
                       audio.dtype != torch.int16 else audio.tensor()
                       for audio in audios]
-            audios = [audio.to(torch.float32) / 32768.
+            audios = [host_pcm_to_float(audio)
                       if audio.dtype == torch.int16 else audio
                       for audio in audios]
         raw_lengths = [int(audio.shape[0]) for audio in audios]

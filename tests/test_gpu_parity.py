@@ -761,6 +761,89 @@ def test_file_api_and_cli(tmp_path, cases):
     assert torch.equal(torch.load(tmp_path / 'cli.pt'), scores)
 
 
+def test_api_leaves_torch_threads_alone(tmp_path, monkeypatch):
+    """No public entry point touches torch's process-global thread settings
+    (round 4 flipped `torch.set_num_threads(1)` around every call): a second
+    thread watching `torch.get_num_threads()` sees one value throughout, and
+    `torch.set_num_threads` is never called."""
+    import threading
+    from emphases_amd import load
+    calls = []
+    real = torch.set_num_threads
+    monkeypatch.setattr(
+        torch, 'set_num_threads',
+        lambda n: (calls.append(n), real(n))[1])
+    before = torch.get_num_threads()
+    seen, stop = set(), threading.Event()
+
+    def watch():
+        while not stop.is_set():
+            seen.add(torch.get_num_threads())
+
+    watcher = threading.Thread(target=watch)
+    watcher.start()
+    try:
+        count, frames = 64, 1000
+        audios = [torch.from_numpy(synth.audio(i, frames)) for i in range(count)]
+        aligns = [emphases_amd.Alignment.from_frames(
+            synth.word_frames(i, frames)) for i in range(count)]
+        emphases_amd.from_alignments_and_audios(aligns, audios)
+        emphases_amd.from_alignments_and_audios(
+            aligns, [a.double() for a in audios])      # (host conversion)
+        emphases_amd.from_alignment_and_audio(aligns[0], audios[0], 16000)
+        texts, waves = [], []
+        for index in range(40):
+            load.save_wav(tmp_path / f'a{index}.wav', synth.audio(index, 300))
+            emphases_amd.Alignment.from_frames(
+                synth.word_frames(index, 300)).save(tmp_path / f'a{index}.TextGrid')
+            texts.append(tmp_path / f'a{index}.TextGrid')
+            waves.append(tmp_path / f'a{index}.wav')
+        emphases_amd.from_files_to_files(
+            texts, waves, [tmp_path / f'o{i}' for i in range(40)], gpu=0,
+            utterances_per_batch=16)
+    finally:
+        stop.set()
+        watcher.join()
+    assert calls == [], calls
+    assert seen == {before}, (seen, before)
+    assert torch.get_num_threads() == before
+
+
+def test_file_api_failure_keeps_the_outputs_in_front_of_it(tmp_path):
+    """A corrupt alignment late in a corpus: every batch submitted before the
+    failure is still finished and written (the reference's loop leaves the
+    outputs of every file in front of the bad one, `core.py:169-179`), then
+    the error is raised."""
+    from emphases_amd import load
+    count, per_batch, bad = 80, 16, 70
+    texts, waves, prefixes = [], [], []
+    for index in range(count):
+        load.save_wav(tmp_path / f'a{index}.wav', synth.audio(index, 200))
+        text = tmp_path / f'a{index}.TextGrid'
+        if index == bad:
+            text.write_text('File type = "ooTextFile"\nObject class = "TextGrid"\n'
+                            'xmin = 0\nxmax = nonsense\n')
+        else:
+            emphases_amd.Alignment.from_frames(
+                synth.word_frames(index, 200)).save(text)
+        texts.append(text), waves.append(tmp_path / f'a{index}.wav')
+        prefixes.append(tmp_path / f'o{index}')
+    with pytest.raises(Exception):
+        emphases_amd.from_files_to_files(
+            texts, waves, prefixes, gpu=0, utterances_per_batch=per_batch)
+    written = [i for i in range(count) if (tmp_path / f'o{i}.pt').exists()]
+    # the batches in front of the bad file's batch, all of them
+    assert written[:bad // per_batch * per_batch] == \
+        list(range(bad // per_batch * per_batch)), written
+    assert bad not in written
+    for index in (0, 31, 63):
+        scores = torch.load(tmp_path / f'o{index}.pt')
+        want = emphases_amd.from_alignment_and_audio(
+            emphases_amd.Alignment(texts[index]),
+            load.audio(waves[index]), 16000)
+        assert torch.equal(scores, want)
+
+
 def test_session_pipeline_pcm_and_layout_cache(default_engine):
     """session.Session: batches in flight on alternating lanes, 16-bit PCM
     input (x / 32768 on the device: identical bits), and the layout cache -

@@ -1092,3 +1092,28 @@ def test_conv_span_table_invariants():
         assert (need <= computed + 256).all(), count
         pieces = 1 if count <= 256 else max(2, 2 + -(-(count - 504) // 248))
         assert len(rows) == pieces, (count, len(rows), pieces)
+
+
+def test_package_never_switches_torch_threads():
+    """`torch.set_num_threads` is process-global: a drop-in library must not
+    call it (round 4 did, around every API call)."""
+    import glob
+    package = os.path.join(ROOT, 'emphases_amd')
+    for path in glob.glob(os.path.join(package, '**', '*.py'), recursive=True):
+        with open(path) as file:
+            for number, line in enumerate(file, 1):
+                code = line.split('#')[0]
+                assert 'set_num_threads(' not in code, (path, number)
+    from emphases_amd import runtime
+    assert not hasattr(runtime, 'few_host_threads')
+
+
+def test_file_pipeline_threads_fit_the_cpu_budget(monkeypatch):
+    from emphases_amd import files
+    for budget in (1, 2, 4, 8, 16, 64, 256):
+        monkeypatch.setattr(files, '_cpu_budget', lambda budget=budget: budget)
+        monkeypatch.delenv('EMPHASES_FILE_THREADS', raising=False)
+        opening, writing = files.stage_threads()
+        assert opening >= 1 and writing >= 1 and opening >= writing
+        # opener + writer pools, the calling thread and HIP's own threads
+        assert opening + writing + 4 <= max(budget, 6), (budget, opening, writing)
