@@ -468,7 +468,18 @@ bool scan_values(const std::string& text, std::vector<Value>* values) {
                         }
                     }
                     Value value{Value::kNumber, std::string(), 0.};
-                    value.number = strtod(text.substr(i, j - i).c_str(), nullptr);
+                    // (std::from_chars: strtod follows the process's LC_NUMERIC - in a
+                    // host application under a comma-decimal locale "0.5" would read
+                    // as 0 - and Python's float(), the oracle, never does.  A value
+                    // that does not fit a double - 1e999 - is not vouched for: the
+                    // file goes to the Python reader, which raises as it always did)
+                    size_t from = i;
+                    if (text[from] == '+') ++from;
+                    const auto parsed = std::from_chars(text.data() + from, text.data() + j,
+                                                        value.number);
+                    if (parsed.ec != std::errc() || parsed.ptr != text.data() + j ||
+                        !std::isfinite(value.number))
+                        return false;
                     values->push_back(std::move(value));
                     i = j;
                     continue;
@@ -692,6 +703,8 @@ bool parse_grid(const std::string& text, Grid* grid, std::string* error) {
 // for 1e-4 <= |x| < 1e16, else d.ddde+XX
 std::string python_repr(double value) {
     if (value == 0.) return std::signbit(value) ? "-0.0" : "0.0";
+    if (std::isnan(value)) return "nan";
+    if (std::isinf(value)) return value < 0 ? "-inf" : "inf";
     char buffer[64];
     auto result = std::to_chars(buffer, buffer + sizeof(buffer), value, std::chars_format::scientific);
     std::string text(buffer, result.ptr);
@@ -728,8 +741,9 @@ std::string python_repr(double value) {
 
 // alignment._number: integers without a fraction
 std::string number(double value) {
-    if (value == static_cast<double>(static_cast<long long>(value)) &&
-        (value < 0 ? -value : value) < 1e15)
+    // (the range check first: a cast of inf or of |x| >= 2^63 is undefined)
+    if (std::isfinite(value) && (value < 0 ? -value : value) < 1e15 &&
+        value == static_cast<double>(static_cast<long long>(value)))
         return std::to_string(static_cast<long long>(value));
     return python_repr(value);
 }

@@ -121,7 +121,13 @@ def save_wav(file, audio, sample_rate=cfg.SAMPLE_RATE):
 def audio(file, raw=False):
     """Load audio and maybe resample (`emphases/load.py:11-17`).  `raw`: a
     16 kHz 16-bit PCM file is returned as int16 (no conversion, half the
-    bytes); anything else as float32 like the reference."""
+    bytes); anything else as float32 like the reference.
+
+    A file that is not at 16 kHz NEEDS THE GPU, unlike the reference's
+    `load.audio`: the package has exactly one resampler, `emph_resample`, so
+    that every entry point agrees bit for bit at any input rate, and no CPU
+    fallback (on a host without an MI355X this raises `runtime.LibraryError`;
+    `wav(file)` reads any rate on the host, unresampled)."""
     samples, rate = wav(file, raw)
     if rate == cfg.SAMPLE_RATE:
         return samples

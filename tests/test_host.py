@@ -970,6 +970,44 @@ def test_file_batch_reports_bad_files_like_the_python_readers(tmp_path):
         opened.audio(5)
 
 
+def test_textgrid_numbers_do_not_follow_the_locale_or_overflow(tmp_path):
+    """The library reads numbers with std::from_chars: `strtod` follows the
+    process's LC_NUMERIC (under a comma-decimal locale '0.5' reads as 0) and
+    Python's float(), the oracle, never does; a time no double holds (1e999)
+    is not vouched for - the Python reader gets the file - instead of being
+    written back as 'i.nf'."""
+    import ctypes
+    from emphases_amd import files
+    good = _grid_variants(tmp_path)[0]
+    load.save_wav(tmp_path / 'good.wav', synth.weights(1, (1, 300), .3))
+    text = good.read_text()
+    # every available comma-decimal locale (the image may have none: then the
+    # library's parse is at least shown not to call the C locale machinery by
+    # giving the same times under LC_NUMERIC='' as under 'C')
+    libc = ctypes.CDLL(None)
+    libc.setlocale.restype = ctypes.c_char_p
+    LC_NUMERIC = 1
+    before = libc.setlocale(LC_NUMERIC, None)
+    want = files.FileBatch([good], [tmp_path / 'good.wav']).times.copy()
+    assert want.size and np.any(want != np.floor(want))       # (fractions in there)
+    try:
+        for name in (b'de_DE.UTF-8', b'de_DE.utf8', b'fr_FR.UTF-8', b'de_DE', b''):
+            if libc.setlocale(LC_NUMERIC, name) is None:
+                continue
+            got = files.FileBatch([good], [tmp_path / 'good.wav']).times
+            assert np.array_equal(got, want), name
+    finally:
+        libc.setlocale(LC_NUMERIC, before)
+    # a time beyond the doubles
+    huge = tmp_path / 'huge.TextGrid'
+    huge.write_text(text.replace(text.split('xmax = ')[1].split('\n')[0], '1e999', 1))
+    opened = files.FileBatch([huge, good], [tmp_path / 'good.wav'] * 2)
+    assert opened.status.tolist()[0] & 1 and opened.status.tolist()[1] == 0
+    plus = tmp_path / 'plus.TextGrid'
+    plus.write_text(text.replace('xmin = 0', 'xmin = +0', 1))
+    assert files.FileBatch([plus], [tmp_path / 'good.wav']).status.tolist() == [0]
+
+
 def test_plan_tables_of_the_library_match_numpy():
     """emph_plan_tiles / emph_plan_word_sums (host arithmetic in the library,
     what `batch.Plan` calls) against the numpy restatement in
