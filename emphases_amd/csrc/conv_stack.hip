@@ -9,7 +9,7 @@
 // Why: a layer-by-layer launch spends 9.3 us of its 18.6 us in the matrix pipe; the
 // rest is launch ramp, the 153.6 KB pack transfer that nothing can run under
 // (the pack fills the LDS), and the store burst of 20.5 MB per layer
-// (DESIGN.md section 6).  Here a workgroup owns a SPAN of up to 252 consecutive
+// (EXPERIMENTS.md, rounds 1-4 section 6).  Here a workgroup owns a SPAN of up to 252 consecutive
 // positions of one segment for all the layers of the launch:
 //
 //   * 256 computed positions = 4 MFMA column tiles of 16 quads = the span plus a

@@ -411,7 +411,7 @@ int emph_conv1d_stack(const float* x, int64_t ldx, float* y, int64_t ldy,
                       int32_t relu_mask, const int32_t* spans, int32_t n_spans,
                       const int32_t* slot_map, void* stream);
 
-/* EXPERIMENTAL (measured in DESIGN.md section 6, not used by the engine):
+/* EXPERIMENTAL (measured in EXPERIMENTS.md, rounds 1-4 section 6, not used by the engine):
  * the F(4,3) layer as TWO independent launches ("halves"): half 0 computes the
  * output channels of the first ceil(m_tiles / 2) 16-channel tiles, half 1 the
  * rest, each around its own rows of the pack only (92 KB + 61 KB of LDS for

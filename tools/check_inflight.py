@@ -40,7 +40,7 @@ def assembly(path):
     with tempfile.TemporaryDirectory() as scratch:
         out = Path(scratch) / 'kernel.s'
         subprocess.run(
-            ['hipcc', '-O3', '--offload-arch=gfx950', '-std=c++17', f'-I{ROOT}/include',
+            ["/opt/rocm/bin/hipcc", "-O3", '--offload-arch=gfx950', '-std=c++17', f'-I{ROOT}/include',
              f'-I{ROOT}/emphases_amd/csrc', '-S', '--cuda-device-only', str(path), '-o', str(out)],
             check=True, stderr=subprocess.DEVNULL)
         return out.read_text()

@@ -1,6 +1,6 @@
 // Standalone micro-benchmark of emph_conv1d on the C2 layout (64 x 1000 frames).
 // NOTE: the conv kernels of the product carry no EMPH_STAMP hooks any more (they distorted
-// the kernels they timed): this file times whole launches; the stamp
+// the kernels they timed, EXPERIMENTS.md, rounds 1-4 section 6): this file times whole launches; the stamp
 // machinery below is inert.  In-kernel timelines: tools/micro/stack_bench.hip (STACK_STAMP).
 // Build: hipcc -O3 --offload-arch=gfx950 -DEMPH_STAMPS -I. tools/micro/conv_bench.hip \
 //            emphases_amd/csrc/frontend.hip -o gpurun_out/conv_bench   (frontend.hip supplies set_error)

@@ -1,6 +1,6 @@
 // Standalone timeline of emph_logmel on the C2 layout (64 x 10 s).
 // NOTE: the front-end kernels of the product carry no EMPH_STAMP hooks any more (they distorted
-// the kernels they timed): this file times whole launches; the stamp
+// the kernels they timed, EXPERIMENTS.md, rounds 1-4 section 6): this file times whole launches; the stamp
 // machinery below is inert.  In-kernel timelines: tools/micro/stack_bench.hip (STACK_STAMP).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
