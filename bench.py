@@ -853,6 +853,37 @@ def side_transformer(device, audios, alignments, args, precision='f32',
     return line
 
 
+def side_conv_split(device, audios, alignments, args, baseline):
+    """BASELINE configs[1] with the opt-in precision='bf16x3' (the frame-rate
+    convs on the bf16 matrix pipe, operands split into two bf16 pieces): same
+    protocol as the headline, never the headline; `baseline`: the f32 run's
+    scores."""
+    runner = Runner(cfg.DEFAULT, None, device, audios, alignments, streams=2,
+                    precision='bf16x3')
+    steps = max(10, min(args.steps, 40))
+    laps, ramp, scores = timed_regions(runner, steps, 5, 5, 1)
+    line = summary(laps, steps)
+    kept = scores[runner.columns]
+    kernels, passes = runner.kernel_times(5)
+    kernels.pop('launch_probe', None)
+    line.update({
+        'precision': 'bf16x3',
+        'workload': '64 synthetic 10 s 16 kHz utterances, conv config, the seven '
+                    'frame-rate layers as two launches of emph_conv1d_split '
+                    '(bf16x3, direct form); two batches in flight, hipGraph '
+                    'replay (BASELINE.json configs[1], opt-in precision)',
+        'steps': steps,
+        'utterances_per_s': UTTERANCES / line['ms_per_step'] * 1e3,
+        'max_abs_dscore_vs_f32': float((kept - baseline).abs().max()),
+        'words_compared': int(kept.numel()),
+        'kernels_us_per_step': {
+            name: value[1] / passes * 1e6 for name, value in kernels.items()},
+        'preroll': ramp})
+    del runner
+    torch.cuda.empty_cache()
+    return line
+
+
 def replay_time(engine, packed, alignments, lengths, batch_size, least=0.25):
     """(seconds per pass, words, frames, checksum) of one ragged batch with
     its audio resident, replayed as a graph."""
@@ -1472,6 +1503,7 @@ def run_batch(args, rank, world, device, host):
     runner.after = None
     kernels, passes = runner.kernel_times(20)
     checksum = float(scores[columns].sum().item())
+    headline_scores = scores[columns].clone()
     meta_tile, lanes = runner.meta['tile'], len(runner.lanes)
     stack_spans = runner.meta['conv_spans'][1] // 8 \
         if 'conv_spans' in runner.meta else None
@@ -1569,6 +1601,9 @@ def run_batch(args, rank, world, device, host):
                 result['end_to_end_api'] = guarded(
                     end_to_end_api, audios, alignments)
             if not args.no_side:
+                result['configs_1_conv_bf16x3'] = guarded(
+                    side_conv_split, device, audios, alignments, args,
+                    headline_scores)
                 result['files_api'] = guarded(side_files_api, device)
                 plain = guarded(
                     side_transformer, device, audios, alignments, args)

@@ -364,7 +364,10 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
         }
     };
     // softmax numerators of a block's scores and their product with the values
-    auto attend = [&](f32x16 s16, const u32x4 (&av)[2][2][PIECES], int key0, bool masked) {
+    // (`pending`: the scores of the NEXT block, already issued against the reference as
+    // it stands - when the reference moves they move with it)
+    auto attend = [&](f32x16 s16, f32x16& pending, const u32x4 (&av)[2][2][PIECES], int key0,
+                      bool masked) {
         SPLIT_STAMP(1);
         if (masked) {                     // wave-uniform: a segment's last block only
             asm volatile("" ::: "memory");
@@ -388,6 +391,8 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
                 for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s16[r] -= shift;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pending[r] -= shift;
             reference += shift;
             set_reference(reference);
         }
@@ -472,7 +477,7 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
                 next_stage();
                 next = scores(following, 0);
             }
-            attend(current, av, key_base, keys < 32);
+            attend(current, next, av, key_base, keys < 32);
             current = next;
         }
         if (keys > 32) {
@@ -484,7 +489,7 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
                 next_stage();
                 next = scores(following, 0);
             }
-            attend(current, av, key_base + 32, keys < 64);
+            attend(current, next, av, key_base + 32, keys < 64);
             current = next;
         }
     }

@@ -222,6 +222,14 @@ class Engine:
                 [layer.winograd4 for layer in frame_stack])
             self._stack_biases = torch.cat(
                 [layer.bias for layer in frame_stack])
+        # precision='bf16x3': the same layers on the bf16 matrix pipe, direct
+        # form, operands split into two bf16 pieces (csrc/conv_split.hip); up
+        # to five layers per launch.  ('bf16x6' keeps the fp32 kernel here:
+        # six products of the direct form would not beat F(4,3) in fp32)
+        self.split_conv = bool(self.stack and self.split_pieces == 2)
+        if self.split_conv:
+            self._split_packs = to(np.concatenate(
+                [runtime.conv_split_pack(layer.weight) for layer in frame_stack]))
         self.model = self._conv_model()
 
     def lane(self):
@@ -848,6 +856,11 @@ class Engine:
         pack = self.input_layer.winograd4.numel()
         relu_layers = config.activation == 'relu'
         source, buffers, done = features, (a, b), 0
+        if self.split_conv:
+            # bf16x3: up to five layers per launch, the per-word sum unfolded
+            fold = False
+            groups = -(-total // 5)
+            split_bytes = int(self.lib.emph_conv_split_pack_size())
         for group in range(groups if frames else 0):
             size = -(-(total - done) // (groups - group))
             relu = sum(1 << l for l in range(size)
@@ -855,6 +868,17 @@ class Engine:
             to_sums = fold and group == groups - 1
             target = sums if to_sums else buffers[group & 1]
             flops = 2. * 80 * 80 * 3 * plan.total_frames * size
+            if self.split_conv:
+                with self._timed('conv1d_split_frames_80x80_k3', flops):
+                    runtime.check(self.lib.emph_conv1d_split(
+                        source.data_ptr(), ld_f, target.data_ptr(), ld_f,
+                        self._split_packs[done * split_bytes:].data_ptr(),
+                        self._stack_biases[done * channels:].data_ptr(), size,
+                        relu, spans.data_ptr(), span_size // 8,
+                        runtime.stream()), 'emph_conv1d_split')
+                source = target
+                done += size
+                continue
             with self._timed('conv1d_stack_frames_80x80_k3', flops):
                 runtime.check(self.lib.emph_conv1d_stack(
                     source.data_ptr(), ld_f, target.data_ptr(),
@@ -970,7 +994,7 @@ class Engine:
         ld_f, ld_w = plan.ld_frames, plan.ld_words
         frames, words = runtime.AXIS_FRAMES, runtime.AXIS_WORDS
         if self.model is not None and stages is None and features is None \
-                and self.timers is None and \
+                and self.timers is None and not self.split_conv and \
                 block in ((64,) if self.quad else (32, 64)) and \
                 len(plan.segments):
             # the whole path behind one C call

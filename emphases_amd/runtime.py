@@ -83,6 +83,10 @@ SIGNATURES = {
     'emph_conv1d_stack': (_c.c_int, [
         _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _i32, _ptr,
         _ptr]),
+    'emph_conv_split_pack_size': (_i64, []),
+    'emph_conv_split_pack': (_c.c_int, [_ptr, _ptr]),
+    'emph_conv1d_split': (_c.c_int, [
+        _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _i32, _ptr]),
     'emph_word_sums': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _ptr]),
     'emph_conv_winograd4_split_pack': (_c.c_int, [_ptr, _i32, _i32, _ptr]),
@@ -327,6 +331,18 @@ def word_decoder_pack(weight):
     check(lib.emph_word_decoder_pack(
         weight.ctypes.data, channels, kernel_size, pack.ctypes.data),
         'emph_word_decoder_pack')
+    return pack
+
+
+def conv_split_pack(weight):
+    """bf16x3 pack (two bf16 pieces per weight, `emph_conv_split_pack`) of a
+    [80, 80, 3] weight (host, numpy uint8)."""
+    lib = library()
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    assert weight.shape == (80, 80, 3)
+    pack = np.zeros(lib.emph_conv_split_pack_size(), dtype=np.uint8)
+    check(lib.emph_conv_split_pack(weight.ctypes.data, pack.ctypes.data),
+          'emph_conv_split_pack')
     return pack
 
 

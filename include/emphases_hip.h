@@ -411,6 +411,21 @@ int emph_conv1d_stack(const float* x, int64_t ldx, float* y, int64_t ldy,
                       int32_t relu_mask, const int32_t* spans, int32_t n_spans,
                       const int32_t* slot_map, void* stream);
 
+/* The same group of layers on the bf16 matrix pipe, direct form, every fp32
+ * operand split into two bf16 pieces (three products per term, fp32
+ * accumulation; emphases_amd/csrc/conv_split.hip): the opt-in
+ * precision='bf16x3' of the host side - the reference runs these convolutions
+ * under bf16 / fp16 autocast (emphases/core.py:594-607).  Same spans as
+ * emph_conv1d_stack; `packs`: emph_conv_split_pack of every layer back to back
+ * (emph_conv_split_pack_size() bytes each, device, 16-byte aligned); the last
+ * layer always writes its output (no folded word sums). */
+int64_t emph_conv_split_pack_size(void);
+int emph_conv_split_pack(const float* host_weight, void* host_pack);
+int emph_conv1d_split(const float* x, int64_t ldx, float* y, int64_t ldy,
+                      const void* packs, const float* biases, int32_t layers,
+                      int32_t relu_mask, const int32_t* spans, int32_t n_spans,
+                      void* stream);
+
 /* EXPERIMENTAL (measured in EXPERIMENTS.md, rounds 1-4 section 6, not used by the engine):
  * the F(4,3) layer as TWO independent launches ("halves"): half 0 computes the
  * output channels of the first ceil(m_tiles / 2) 16-channel tiles, half 1 the

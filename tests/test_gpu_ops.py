@@ -296,6 +296,82 @@ def test_conv1d_stack_equals_layer_by_layer(layers, relu_mask):
     assert lib.emph_conv_stack_max_layers() == 3
 
 
+@pytest.mark.parametrize('layers,relu_mask', [
+    (1, 0b1), (2, 0b10), (3, 0b110), (4, 0b1110), (5, 0b11111), (5, -0b11110)])
+def test_conv1d_split(layers, relu_mask):
+    """emph_conv1d_split (the same group of layers on the bf16 matrix pipe,
+    operands split into two bf16 pieces, direct form) against torch conv1d in
+    float64 and against the fp32 kernel emph_conv1d_stack, on the span
+    boundaries of `test_conv1d_stack_equals_layer_by_layer`; NaN in all
+    padding.  Three products per term: 2e-5 x scale per layer (the fp32 kernel
+    holds 2e-6)."""
+    lib = runtime.library()
+    frames = [1000, 1, 2, 3, 4, 5, 37, 64, 65, 252, 253, 256, 257, 504, 505,
+              600, 3000, 130]
+    if relu_mask < 0:
+        relu_mask = -relu_mask
+        rng = np.random.default_rng(2000 + layers)
+        frames = [int(n) for n in rng.integers(1, 3001, size=40)]
+    plan = ragged_plan(frames)
+    axis = runtime.AXIS_FRAMES
+    spans_host = plan.conv_spans()
+    spans_dev = torch.from_numpy(spans_host).to(DEVICE)
+    x = random_packed(80, plan, axis, 31)
+    x[:, :batch.LEAD] = float('nan')
+    x[:, -batch.TAIL:] = float('nan')
+    for off, count in spans(plan, axis):
+        x[:, off + count:off + count + (-count) % 16] = float('nan')
+    weights = [synth.weights(40 + l, (80, 80, 3), 0.12) for l in range(layers)]
+    biases = [synth.weights(50 + l, (80,), 0.3) for l in range(layers)]
+    packs = torch.from_numpy(np.concatenate(
+        [runtime.conv_split_pack(w) for w in weights])).to(DEVICE)
+    plain_packs = torch.from_numpy(np.concatenate(
+        [runtime.conv_winograd4_pack(w) for w in weights])).to(DEVICE)
+    biases_dev = torch.from_numpy(np.concatenate(biases)).to(DEVICE)
+    x_dev = x.to(DEVICE)
+    y = torch.full((80, plan.ld_frames), 7.0, device=DEVICE)
+    runtime.check(lib.emph_conv1d_split(
+        x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
+        packs.data_ptr(), biases_dev.data_ptr(), layers, relu_mask,
+        spans_dev.data_ptr(), len(spans_host), None), 'emph_conv1d_split')
+    # the fp32 kernel beside it (three layers per launch at most)
+    plain, source, done = None, x_dev, 0
+    pack_floats = plain_packs.numel() // layers
+    while done < layers:
+        size = min(3, layers - done)
+        plain = torch.full((80, plan.ld_frames), 7.0, device=DEVICE)
+        runtime.check(lib.emph_conv1d_stack(
+            source.data_ptr(), plan.ld_frames, plain.data_ptr(), plan.ld_frames,
+            plain_packs[done * pack_floats:].data_ptr(),
+            biases_dev[80 * done:].data_ptr(), size, relu_mask >> done,
+            spans_dev.data_ptr(), len(spans_host), None, None),
+            'emph_conv1d_stack')
+        source, done = plain, done + size
+    got, plain = y.cpu().double(), plain.cpu().double()
+    worst = worst_plain = 0.
+    for off, count in spans(plan, axis):
+        value = x[None, :, off:off + count].double()
+        for l in range(layers):
+            value = torch.nn.functional.conv1d(
+                value, torch.from_numpy(weights[l]).double(),
+                torch.from_numpy(biases[l]).double(), padding=1)
+            if (relu_mask >> l) & 1:
+                value = torch.relu(value)
+        scale = max(1.0, float(value.abs().max()))
+        delta = float((got[:, off:off + count] - value[0]).abs().max())
+        assert delta < 2e-5 * scale * layers, (count, delta, scale)
+        worst = max(worst, delta / scale)
+        worst_plain = max(worst_plain, float(
+            (plain[:, off:off + count] - value[0]).abs().max()) / scale)
+    print(f'{layers} layers: |split - f64| / scale {worst:.2e}, '
+          f'|fp32 kernel - f64| / scale {worst_plain:.2e}')
+    assert float(y[:, :batch.LEAD].min()) == 7.0      # columns outside: untouched
+    assert lib.emph_conv1d_split(
+        x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
+        packs.data_ptr(), biases_dev.data_ptr(), 6, 0, spans_dev.data_ptr(),
+        len(spans_host), None) != 0         # (five layers at most)
+
+
 @pytest.mark.parametrize('c_in,c_out,activation,max_positions', [
     (80, 80, None, 5000), (80, 80, 'relu', 150), (64, 64, None, 131),
     (48, 33, None, 5000)])
@@ -597,7 +673,10 @@ def test_attention(channels, heads, tile_n):
 def test_attention_split(pieces):
     """emph_attention_split (bf16 pieces on the bf16 matrix pipe) against a
     float64 reference, with the fp32-MFMA kernel's own error beside it:
-    three pieces stay within 2x of the fp32 kernel, two pieces within 2e-5."""
+    three pieces stay within 2x of the fp32 kernel on inputs built to be
+    harsh (keys whose scores tower over the others by more than 2^64, so that
+    the lazy softmax reference moves); two pieces do not - that is what
+    'bf16x3' trades."""
     lib = runtime.library()
     channels, heads, tile_n = 80, 2, 256
     plan = ragged_plan([130, 16, 1, 700, 65, 1000, 257])
@@ -605,6 +684,10 @@ def test_attention_split(pieces):
     meta = Meta(plan, [(axis, tile_n), (axis, 64)])
     ld = plan.ld_frames
     qk = random_packed(2 * channels, plan, axis, 21) * 3.0
+    # keys whose scores tower over the first block's (the lazy softmax
+    # reference must MOVE, with a block's scores already issued against the
+    # old one): every 97th key of the long segments is 12 x larger
+    qk[channels:, 40::97] *= 12.0
     v = torch.from_numpy(synth.weights(22, (ld, channels), 1.0))
     # padding of the packed axes may hold anything
     for off, count in spans(plan, axis):
@@ -660,8 +743,12 @@ def test_attention_split(pieces):
                 (split[:, off:off + count] - want).abs().max()))
         print(f'pieces {pieces}: |split - f64| {worst_split:.2e}, '
               f'|fp32 kernel - f64| {worst_plain:.2e}')
-        assert worst_plain < 5e-6
-        assert worst_split < (4e-5 if pieces == 2 else
+        # (the towering keys make this a harsh regime for fp32 itself)
+        assert worst_plain < 2e-5
+        # two pieces: the scores' error (2^-17 of sum |q k|) sits in front of
+        # an exponential, so it grows with the score range - 3e-4 here, 2e-5
+        # without the towering keys; three pieces stay with the fp32 kernel
+        assert worst_split < (1e-3 if pieces == 2 else
                               max(2. * worst_plain, 2e-6))
     with pytest.raises(runtime.LibraryError, match='pieces'):
         runtime.check(lib.emph_attention_split(

@@ -464,6 +464,52 @@ def test_split_precision_attention(variants, precision, budget):
     assert worst < budget
 
 
+def test_split_precision_conv(cases):
+    """precision='bf16x3' on the DEFAULT configuration (the shipped checkpoint):
+    the seven frame-rate layers run as two launches of emph_conv1d_split (bf16
+    matrix pipe, operands split into two bf16 pieces, direct form).  All eight
+    reference goldens and a 64-utterance batch stay within 1e-5 of the
+    reference / of the f32 engine on the scores; 'bf16x6' leaves the conv path
+    in fp32 (bitwise the default)."""
+    split = emphases_amd.get_engine(precision='bf16x3')
+    assert split.split_conv and split.precision == 'bf16x3'
+    assert not emphases_amd.get_engine(precision='bf16x6').split_conv
+    assert not emphases_amd.get_engine().split_conv
+    worst_reference = 0.
+    for name in CASES:
+        audio, bounds, batch_size = case_inputs(cases, name)
+        plan, scores, logits = run_case(split, audio, bounds, batch_size)
+        columns = plan.word_columns()
+        delta = float(np.abs(scores.cpu().numpy()[columns] -
+                             cases[f'{name}/scores']).max())
+        worst_reference = max(worst_reference, delta)
+        assert delta < 1e-5, (name, delta)
+        scale = max(1., float(np.abs(cases[f'{name}/logits']).max()))
+        assert np.abs(logits.cpu().numpy()[columns] -
+                      cases[f'{name}/logits']).max() < 1e-4 * scale
+    count, frames = 64, 1000
+    audios = [torch.from_numpy(synth.audio(i, frames)) for i in range(count)]
+    aligns = [emphases_amd.Alignment.from_frames(synth.word_frames(i, frames))
+              for i in range(count)]
+    plain = emphases_amd.from_alignments_and_audios(aligns, audios)
+    got = emphases_amd.from_alignments_and_audios(
+        aligns, audios, precision='bf16x3')
+    again = emphases_amd.from_alignments_and_audios(
+        aligns[::-1], audios[::-1], precision='bf16x3')[::-1]
+    same = emphases_amd.from_alignments_and_audios(
+        aligns, audios, precision='bf16x6')
+    worst = 0.
+    for a, b, c, d in zip(plain, got, again, same):
+        assert torch.equal(b, c)            # independent of the batch's order
+        assert torch.equal(a, d)            # bf16x6: the conv path stays fp32
+        assert not torch.equal(a, b)
+        worst = max(worst, float((a - b).abs().max()))
+    print(f'bf16x3 conv: worst |score - f32 engine| {worst:.2e} over '
+          f'{sum(a.shape[1] for a in plain)} words; worst |score - reference '
+          f'golden| {worst_reference:.2e}')
+    assert worst < 1e-5
+
+
 _STATE_FILES = {}
 
 
