@@ -24,3 +24,6 @@ from .core import (  # noqa: F401
     from_alignments_and_audios, from_file, from_file_to_file,
     from_files_to_files, from_text_and_audio, get_engine, get_session, infer,
     inference_context, postprocess, preprocess, resample)
+# the torch.library operator seams (torch.ops.emphases_amd.*): registration
+# only, nothing runs at import
+from . import ops  # noqa: F401,E402

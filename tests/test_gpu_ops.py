@@ -1284,3 +1284,126 @@ def test_word_metrics_match_reference(loss):
     np.testing.assert_allclose(
         [got['pearson_correlation'], got['bce'], got['mse']],
         golden[f'{loss}/result'], rtol=3e-6, atol=2e-7)
+
+
+###############################################################################
+# torch.library operator seams: torch.ops.emphases_amd.*
+###############################################################################
+
+
+def _cu(counts):
+    return torch.tensor(np.concatenate([[0], np.cumsum(counts)]),
+                        dtype=torch.int32)
+
+
+def test_torch_ops_logmel_conv_and_reduce():
+    """The varlen ops on back-to-back segments (no alignment, no padding
+    between them) against torch CPU fp32 / the oracle, one segment at a time."""
+    import emphases_amd  # noqa: F401  (registers the ops)
+    from oracle import prominence as oracle
+    ops = torch.ops.emphases_amd
+    # logmel: chunks of 1 s, 0.37 s and 2.5 s back to back
+    samples = [16000, 5920, 40000]
+    audios = [torch.from_numpy(synth.audio(7 + i, n // 160))[0, :n]
+              for i, n in enumerate(samples)]
+    mel = ops.logmel(torch.cat(audios).to(DEVICE), _cu(samples))
+    frames = [n // 160 for n in samples]
+    assert mel.shape == (80, sum(frames)) and mel.is_cuda
+    start = 0
+    for audio, count in zip(audios, frames):
+        want = oracle.logmel(audio[None])
+        got = mel[:, start:start + count].cpu()
+        assert got.shape == want.shape
+        assert float((got - want).abs().max()) < 5e-4
+        start += count
+    # conv1d_same_act: the three kernel families
+    counts = [130, 1, 64, 257, 1000, 3]
+    x = torch.from_numpy(synth.weights(3, (80, sum(counts)), 1.0))
+    for c_in, c_out, k, act in ((80, 80, 3, 'relu'), (80, 80, 3, 'gelu'),
+                                (80, 64, 5, 'none'), (80, 1, 3, 'none')):
+        weight = torch.from_numpy(synth.weights(4 + k, (c_out, c_in, k), 0.1))
+        bias = torch.from_numpy(synth.weights(5, (c_out,), 0.3))
+        y = ops.conv1d_same_act(x[:c_in].to(DEVICE), weight.to(DEVICE),
+                                bias.to(DEVICE), _cu(counts), act)
+        assert y.shape == (c_out, sum(counts))
+        start = 0
+        for count in counts:
+            want = torch.nn.functional.conv1d(
+                x[None, :c_in, start:start + count], weight, bias,
+                padding=(k - 1) // 2)[0]
+            if act == 'relu':
+                want = torch.relu(want)
+            elif act == 'gelu':
+                want = torch.nn.functional.gelu(want)
+            delta = float((y[:, start:start + count].cpu() - want).abs().max())
+            assert delta < 5e-5 * max(1., float(want.abs().max())), (k, act, count)
+            start += count
+    with pytest.raises(ValueError, match='Activation'):
+        ops.conv1d_same_act(x.to(DEVICE), weight.to(DEVICE), bias.to(DEVICE),
+                            _cu(counts), 'tanh')
+    # segment_reduce
+    words = [synth.word_frames(i, n, 1, 25) if n else np.zeros((2, 0), np.int64)
+             for i, n in enumerate(counts)]
+    bounds = torch.from_numpy(np.concatenate(words, axis=1))
+    cu_words = _cu([w.shape[1] for w in words])
+    for mode in ('sum', 'average', 'max', 'center'):
+        got = ops.segment_reduce(x.to(DEVICE), bounds, _cu(counts), cu_words, mode)
+        start = first = 0
+        for count, own in zip(counts, words):
+            want = oracle.downsample(
+                x[:, start:start + count], torch.from_numpy(own), mode)
+            assert float((got[:, first:first + own.shape[1]].cpu() -
+                          want).abs().max()) < 2e-5, mode
+            start, first = start + count, first + own.shape[1]
+    with pytest.raises(ValueError, match='Interpolation'):
+        ops.segment_reduce(x.to(DEVICE), bounds, _cu(counts), cu_words, 'median')
+
+
+def test_torch_ops_encoder_layer_and_forward(cases):
+    import emphases_amd
+    from conftest import case_inputs
+    ops = torch.ops.emphases_amd
+    # encoder_layer against nn.TransformerEncoderLayer, a segment at a time
+    channels, heads = 80, 2
+    torch.manual_seed(5)
+    layer = torch.nn.TransformerEncoderLayer(channels, heads, channels, 0.1).eval()
+    counts = [300, 17, 1, 140]
+    x = torch.from_numpy(synth.weights(9, (channels, sum(counts)), 1.0))
+    parameters = [p.detach().to(DEVICE) for p in (
+        layer.self_attn.in_proj_weight, layer.self_attn.in_proj_bias,
+        layer.self_attn.out_proj.weight, layer.self_attn.out_proj.bias,
+        layer.norm1.weight, layer.norm1.bias, layer.linear1.weight,
+        layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
+        layer.norm2.weight, layer.norm2.bias)]
+    got = ops.encoder_layer(x.to(DEVICE), *parameters, _cu(counts), heads)
+    assert got.shape == x.shape
+    start = 0
+    with torch.no_grad():
+        for count in counts:
+            want = layer(x[:, start:start + count].T[:, None])[:, 0].T
+            assert float((got[:, start:start + count].cpu() -
+                          want).abs().max()) < 2e-5, count
+            start += count
+    # prominence_forward: the chunks `preprocess` hands to `infer`, two
+    # utterances back to back; bitwise what the public API returns
+    chunks, all_bounds, words_per_chunk, want = [], [], [], []
+    for name in ('utt_2p5s', 'utt_10s'):
+        audio, bounds, _ = case_inputs(cases, name)
+        alignment = emphases_amd.Alignment.from_frames(bounds)
+        segments = batch.chunk_utterance(alignment, audio.shape[1])
+        assert len(segments) == 1
+        padded = np.pad(audio[0], (432, 432))
+        segment = segments[0]
+        chunks.append(torch.from_numpy(
+            padded[segment.start_sample:segment.start_sample + segment.length]))
+        all_bounds.append(segment.bounds)
+        words_per_chunk.append(segment.bounds.shape[1])
+        want.append(emphases_amd.from_alignment_and_audio(
+            alignment, torch.from_numpy(audio), 16000))
+    scores = ops.prominence_forward(
+        torch.cat(chunks).to(DEVICE), _cu([len(c) for c in chunks]),
+        torch.from_numpy(np.concatenate(all_bounds, axis=1)),
+        _cu(words_per_chunk))
+    assert torch.equal(scores.cpu(), torch.cat([w[0] for w in want]))
+    with pytest.raises(runtime.LibraryError, match='HIP device only'):
+        ops.logmel(torch.zeros(16000), _cu([16000]))

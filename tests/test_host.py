@@ -1155,3 +1155,24 @@ def test_file_pipeline_threads_fit_the_cpu_budget(monkeypatch):
         assert opening >= 1 and writing >= 1 and opening >= writing
         # opener + writer pools, the calling thread and HIP's own threads
         assert opening + writing + 4 <= max(budget, 6), (budget, opening, writing)
+
+
+def test_torch_library_ops_are_registered_and_refuse_the_cpu():
+    """SURVEY 8b's operator seams exist as torch.ops.emphases_amd.* with the
+    varlen signatures, and there is no CPU implementation behind them."""
+    import emphases_amd  # noqa: F401
+    from emphases_amd import runtime
+    ops = torch.ops.emphases_amd
+    assert str(ops.logmel.default._schema) == \
+        'emphases_amd::logmel(Tensor audio_packed, Tensor cu_samples) -> Tensor'
+    assert 'Tensor cu_T, str activation' in str(ops.conv1d_same_act.default._schema)
+    assert 'Tensor cu_frames, Tensor cu_words, str mode' in \
+        str(ops.segment_reduce.default._schema)
+    assert 'Tensor cu_T, SymInt heads' in str(ops.encoder_layer.default._schema)
+    assert 'Tensor bounds, Tensor cu_words' in \
+        str(ops.prominence_forward.default._schema)
+    edges = torch.tensor([0, 16000], dtype=torch.int32)
+    with pytest.raises(runtime.LibraryError, match='no CPU'):
+        ops.logmel(torch.zeros(16000), edges)
+    with pytest.raises(runtime.LibraryError, match='no CPU'):
+        ops.segment_reduce(torch.zeros(80, 10), torch.zeros(2, 1), edges, edges, 'sum')
