@@ -35,6 +35,8 @@
 // into LDS - once per workgroup, not per wave:
 //     K image  [piece][d / 8][key][8 d]  bf16   (A fragment of a k-step: 16 B)
 //     V image  [piece][d][64 keys, permuted]  bf16, row stride 144 B
+#include <type_traits>
+
 #include "common.h"
 
 // (tools/micro/attention_split_bench.hip defines SPLIT_STAMP for an in-kernel timeline)
@@ -133,22 +135,25 @@ constexpr int kSplitRing = 4;                         // stages in LDS
 // Keys beyond the segment are ZEROS (their probabilities are zero; padding of the
 // packed axis may hold NaN).  Images are indexed by SLOT = offset / 64 + segment +
 // stage: distinct for all stages of all segments of a packed axis.
-template <int D, int PIECES>
+// PK pieces of the keys (and queries), PV of the values (and probabilities): a stage is
+// [K piece 0 .. PK - 1][V piece 0 .. PV - 1].
+template <int D, int PK, int PV>
 struct SplitImages {
     static constexpr int kOctets = (D + 15) / 16 * 2;               // k-steps of 16, two octets each
     static constexpr int kKeyBytes = kOctets * kSplitStage * 16;
     static constexpr int kRows = D + 2;
     static constexpr int kValueBytes = (kSplitStage / 8) * kRows * 16;
-    static constexpr int kPieceBytes = kKeyBytes + kValueBytes;     // one piece of one stage
-    static constexpr int kStageBytes = PIECES * kPieceBytes;        // what a buffer of LDS holds
+    static constexpr int kStageBytes = PK * kKeyBytes + PV * kValueBytes;   // a buffer of LDS
+    static constexpr int key_piece(int piece) { return piece * kKeyBytes; }
+    static constexpr int value_piece(int piece) { return PK * kKeyBytes + piece * kValueBytes; }
 };
 
 // grid = n_tiles (blocks of 64 positions of the frame axis); block = 256
-template <int D, int PIECES>
+template <int D, int PK, int PV>
 __global__ __launch_bounds__(256) void split_kv_kernel(
     const float* __restrict__ qk, const float* __restrict__ v, int64_t ld, int channels,
     int heads, const int32_t* __restrict__ tiles, unsigned char* __restrict__ images) {
-    typedef SplitImages<D, PIECES> Images;
+    typedef SplitImages<D, PK, PV> Images;
     constexpr int STAGE = kSplitStage;
     const Tile tile = load_tile(tiles, blockIdx.x);
     const int slot = (tile.offset >> 6) + tile.segment + (tile.first >> 6);
@@ -159,7 +164,8 @@ __global__ __launch_bounds__(256) void split_kv_kernel(
         float values[8];
         int head;
         int byte;
-        if (task < k_tasks) {
+        const bool is_key = task < k_tasks;
+        if (is_key) {
             const int key = task % STAGE, octet = task / STAGE % (D / 8);
             head = task / STAGE / (D / 8);
             const float* source = qk + static_cast<int64_t>(channels + head * D + 8 * octet) * ld +
@@ -181,59 +187,66 @@ __global__ __launch_bounds__(256) void split_kv_kernel(
                                     head * D + d]
                                 : 0.f;
             }
-            byte = Images::kKeyBytes + (chunk * Images::kRows + d) * 16;
+            byte = (chunk * Images::kRows + d) * 16;
         }
-        u32x4 parts[PIECES];
-        split_eight<PIECES>(values, parts);
+        unsigned char* stage =
+            images + (static_cast<int64_t>(slot) * heads + head) * Images::kStageBytes;
+        if (is_key) {
+            u32x4 parts[PK];
+            split_eight<PK>(values, parts);
 #pragma unroll
-        for (int piece = 0; piece < PIECES; ++piece)
-            *reinterpret_cast<u32x4*>(
-                images + (static_cast<int64_t>(slot) * heads + head) * Images::kStageBytes +
-                piece * Images::kPieceBytes + byte) = parts[piece];
+            for (int piece = 0; piece < PK; ++piece)
+                *reinterpret_cast<u32x4*>(stage + Images::key_piece(piece) + byte) = parts[piece];
+        } else {
+            u32x4 parts[PV];
+            split_eight<PV>(values, parts);
+#pragma unroll
+            for (int piece = 0; piece < PV; ++piece)
+                *reinterpret_cast<u32x4*>(stage + Images::value_piece(piece) + byte) = parts[piece];
+        }
     }
     // the constant parts: K's octets from D / 8 on (ones at d = D in piece 0), V's ones
     // and zero rows
     constexpr int PAD_OCTETS = Images::kOctets - D / 8;
-    const int k_fill = heads * PIECES * PAD_OCTETS * STAGE;
-    const int v_fill = heads * PIECES * (STAGE / 8) * 2;
+    const int k_fill = heads * PK * PAD_OCTETS * STAGE;
+    const int v_fill = heads * PV * (STAGE / 8) * 2;
     for (int index = threadIdx.x; index < k_fill + v_fill; index += blockDim.x) {
-        int head, piece, byte;
+        int head, byte;
         u32x4 fill = {0u, 0u, 0u, 0u};
         if (index < k_fill) {
             const int key = index % STAGE, octet = D / 8 + index / STAGE % PAD_OCTETS;
-            piece = index / STAGE / PAD_OCTETS % PIECES;
-            head = index / STAGE / PAD_OCTETS / PIECES;
+            const int piece = index / STAGE / PAD_OCTETS % PK;
+            head = index / STAGE / PAD_OCTETS / PK;
             if (octet == D / 8 && piece == 0) fill[0] = 0x3f80u;        // bf16 1.0 at d = D
-            byte = (octet * STAGE + key) * 16;
+            byte = Images::key_piece(piece) + (octet * STAGE + key) * 16;
         } else {
             const int rest = index - k_fill;
             const int chunk = rest % (STAGE / 8), row = D + rest / (STAGE / 8) % 2;
-            piece = rest / (STAGE / 8) / 2 % PIECES;
-            head = rest / (STAGE / 8) / 2 / PIECES;
+            const int piece = rest / (STAGE / 8) / 2 % PV;
+            head = rest / (STAGE / 8) / 2 / PV;
             if (row == D && piece == 0) fill = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-            byte = Images::kKeyBytes + (chunk * Images::kRows + row) * 16;
+            byte = Images::value_piece(piece) + (chunk * Images::kRows + row) * 16;
         }
         *reinterpret_cast<u32x4*>(
-            images + (static_cast<int64_t>(slot) * heads + head) * Images::kStageBytes +
-            piece * Images::kPieceBytes + byte) = fill;
+            images + (static_cast<int64_t>(slot) * heads + head) * Images::kStageBytes + byte) = fill;
     }
 }
 
 // grid = (n_tiles, heads); block = 512
-template <int D, int PIECES>
+template <int D, int PK, int PV>
 __global__ __launch_bounds__(64 * kSplitWaves) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void attention_split_kernel(const float* __restrict__ qk, const unsigned char* __restrict__ images,
                             float* __restrict__ out, int64_t ld, int channels,
                             const int32_t* __restrict__ tiles,
                             const int32_t* __restrict__ key_counts SPLIT_STAMP_ARGUMENT) {
-    typedef SplitImages<D, PIECES> Images;
+    typedef SplitImages<D, PK, PV> Images;
     SPLIT_STAMP_DECLARE
     constexpr int THREADS = 64 * kSplitWaves;
     constexpr int KSTEPS = (D + 15) / 16;                 // of the S^T product
     constexpr int STAGE = kSplitStage;
     constexpr int UNITS = Images::kStageBytes / 16;       // 16-byte units of a stage
     constexpr int PASSES = (UNITS + THREADS - 1) / THREADS;
-    static_assert(PASSES == 3 || PASSES == 5, "the s_waitcnt below count the requests");
+    static_assert(PASSES >= 3 && PASSES <= 5, "the s_waitcnt below count the requests");
     static_assert(D % 8 == 0 && D % 16 != 0 && D > 32 && D <= 62,
                   "two m-tiles of 32 rows, a spare row for the ones, a spare d for the reference");
     extern __shared__ __align__(16) unsigned char split_lds[];
@@ -284,10 +297,10 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
         }
     };
     auto key_image = [&](int buffer, int piece) {
-        return split_lds + buffer * Images::kStageBytes + piece * Images::kPieceBytes;
+        return split_lds + buffer * Images::kStageBytes + Images::key_piece(piece);
     };
     auto value_image = [&](int buffer, int piece) {
-        return key_image(buffer, piece) + Images::kKeyBytes;
+        return split_lds + buffer * Images::kStageBytes + Images::value_piece(piece);
     };
 
     // ---- the wave's queries: B fragments of Q^T, scaled, split once.  k-step
@@ -295,7 +308,7 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
     // All loads are issued before anything waits (a clamped address and a factor of
     // zero instead of a branch per element: hipcc sinks a conditional load into its
     // branch and waits for each in turn - 24 trips to memory, a fifth of the kernel).
-    u32x4 bq[KSTEPS][PIECES];
+    u32x4 bq[KSTEPS][PK];
     {
         const int query = q0 + column;
         const float* source = q_rows + min(query, queries - 1);
@@ -314,15 +327,15 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
             for (int e = 0; e < 8; ++e)
                 values[e] = raw[s][e] *
                             ((16 * s + 8 * half + e < D && query < queries) ? scale : 0.f);
-            split_eight<PIECES>(values, bq[s]);
+            split_eight<PK>(values, bq[s]);
         }
     }
     auto set_reference = [&](float reference) {
         // (lanes of the upper half: element 0 of the last k-step is d = D)
-        uint32_t parts[PIECES];
-        split_pair<PIECES>(-reference, 0.f, parts);
+        uint32_t parts[PK];
+        split_pair<PK>(-reference, 0.f, parts);
 #pragma unroll
-        for (int piece = 0; piece < PIECES; ++piece)
+        for (int piece = 0; piece < PK; ++piece)
             if (half == (D % 16) / 8) bq[KSTEPS - 1][piece][(D % 8) / 2] = parts[piece];
     };
     f32x16 o[2];
@@ -340,24 +353,24 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
         for (int r = 0; r < 16; ++r) s16[r] = 0.f;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
-            u32x4 ak[PIECES];
+            u32x4 ak[PK];
 #pragma unroll
-            for (int piece = 0; piece < PIECES; ++piece)
+            for (int piece = 0; piece < PK; ++piece)
                 ak[piece] = *reinterpret_cast<const u32x4*>(
                     key_image(buffer, piece) + ((2 * s + half) * STAGE + local + column) * 16);
-            s16 = split_product<PIECES>(ak, bq[s], s16);
+            s16 = split_product<PK>(ak, bq[s], s16);
         }
         return s16;
     };
     // V fragments of a block: rows 32 m + column, the eight keys 16 ks + 8 half ..
-    auto values = [&](int buffer, int local, u32x4 (&av)[2][2][PIECES]) {
+    auto values = [&](int buffer, int local, u32x4 (&av)[2][2][PV]) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int row = min(32 * m + column, D + 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int piece = 0; piece < PIECES; ++piece)
+                for (int piece = 0; piece < PV; ++piece)
                     av[m][ks][piece] = *reinterpret_cast<const u32x4*>(
                         value_image(buffer, piece) +
                         (((local >> 3) + 2 * ks + half) * Images::kRows + row) * 16);
@@ -366,7 +379,7 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
     // softmax numerators of a block's scores and their product with the values
     // (`pending`: the scores of the NEXT block, already issued against the reference as
     // it stands - when the reference moves they move with it)
-    auto attend = [&](f32x16 s16, f32x16& pending, const u32x4 (&av)[2][2][PIECES], int key0,
+    auto attend = [&](f32x16 s16, f32x16& pending, const u32x4 (&av)[2][2][PV], int key0,
                       bool masked) {
         SPLIT_STAMP(1);
         if (masked) {                     // wave-uniform: a segment's last block only
@@ -396,19 +409,19 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
             reference += shift;
             set_reference(reference);
         }
-        u32x4 bp[2][PIECES];
+        u32x4 bp[2][PV];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             float p[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) p[e] = __builtin_amdgcn_exp2f(s16[8 * ks + e]);
-            split_eight<PIECES>(p, bp[ks]);
+            split_eight<PV>(p, bp[ks]);
         }
         SPLIT_STAMP(3);                   // probabilities split
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int m = 0; m < 2; ++m) o[m] = split_product<PIECES>(av[m][ks], bp[ks], o[m]);
+            for (int m = 0; m < 2; ++m) o[m] = split_product<PV>(av[m][ks], bp[ks], o[m]);
         SPLIT_STAMP(4);                   // O^T issued
     };
     // the next stage for every wave: this wave's share has landed (all but the newest
@@ -416,6 +429,7 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
     auto next_stage = [&] {
         SPLIT_STAMP(5);
         if (PASSES == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (PASSES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         SPLIT_STAMP(6);
         __syncthreads();
@@ -468,7 +482,7 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
         const int keys = min(STAGE, length - key_base);
         {
             SPLIT_STAMP(0);
-            u32x4 av[2][2][PIECES];
+            u32x4 av[2][2][PV];
             values(buffer, 0, av);
             f32x16 next = current;
             if (keys > 32) {
@@ -482,7 +496,7 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
         }
         if (keys > 32) {
             SPLIT_STAMP(0);
-            u32x4 av[2][2][PIECES];
+            u32x4 av[2][2][PV];
             values(buffer, 32, av);
             f32x16 next = current;
             if (more) {
@@ -520,16 +534,43 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
 
 using namespace emph;
 
+namespace {
+
+// `pieces` of the C ABI -> (pieces of keys / queries, pieces of values / probabilities)
+//   2   two and two: three products per term everywhere ("bf16x3"; the scores' error,
+//       2^-17 of sum |q k|, sits in front of the exponential and grows with their range)
+//   3   three and three: six products per term, fp32 grade ("bf16x6")
+//   32  three for the scores, two behind the softmax: six products where the error is
+//       amplified, three where it is not
+template <typename F>
+int with_pieces(int pieces, const char* what, F&& call) {
+    switch (pieces) {
+        case 2: return call(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+        case 3: return call(std::integral_constant<int, 3>{}, std::integral_constant<int, 3>{});
+        case 32: return call(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+        default:
+            set_error("%s: pieces %d (2: two bf16 pieces per operand; 3: three; 32: three for "
+                      "the scores, two for the values)", what, pieces);
+            return EMPH_EINVAL;
+    }
+}
+
+}  // namespace
+
 extern "C" {
 
 /* bytes of scratch emph_split_kv fills for a packed frame axis of `ld` columns
  * and `n_segments` segments */
 int64_t emph_split_kv_bytes(int64_t ld, int32_t n_segments, int32_t channels, int32_t heads,
                             int32_t pieces) {
-    if (heads <= 0 || channels / heads != 40 || (pieces != 2 && pieces != 3)) return -1;
+    if (heads <= 0 || channels / heads != 40) return -1;
     const int64_t slots = ld / kSplitStage + n_segments + 1;
-    return slots * heads *
-           (pieces == 2 ? SplitImages<40, 2>::kStageBytes : SplitImages<40, 3>::kStageBytes);
+    int64_t stage = -1;
+    with_pieces(pieces, "emph_split_kv_bytes", [&](auto pk, auto pv) {
+        stage = SplitImages<40, decltype(pk)::value, decltype(pv)::value>::kStageBytes;
+        return EMPH_OK;
+    });
+    return stage < 0 ? -1 : slots * heads * stage;
 }
 
 int emph_split_kv(const float* qk, const float* v, int64_t ld, int32_t channels, int32_t heads,
@@ -539,20 +580,18 @@ int emph_split_kv(const float* qk, const float* v, int64_t ld, int32_t channels,
     EMPH_REQUIRE(qk && v && tiles && images, EMPH_EINVAL, "emph_split_kv: null pointer");
     EMPH_REQUIRE(tile_n == kSplitStage, EMPH_EINVAL,
                  "emph_split_kv: tile_n %d (a stage is %d keys)", tile_n, kSplitStage);
-    EMPH_REQUIRE(pieces == 2 || pieces == 3, EMPH_EINVAL, "emph_split_kv: %d pieces (2 or 3)", pieces);
     EMPH_REQUIRE(heads > 0 && channels % heads == 0 && channels / heads == 40, EMPH_ERANGE,
                  "emph_split_kv: head dimension %d (built for 40 = 80 channels, 2 heads)",
                  heads > 0 ? channels / heads : 0);
     EMPH_REQUIRE((reinterpret_cast<uintptr_t>(images) & 15) == 0, EMPH_EINVAL,
                  "emph_split_kv: images must be 16-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (pieces == 2)
-        EMPH_LAUNCH((split_kv_kernel<40, 2>), dim3(n_tiles), dim3(256), 0, s, qk, v, ld, channels,
-                    heads, tiles, static_cast<unsigned char*>(images));
-    else
-        EMPH_LAUNCH((split_kv_kernel<40, 3>), dim3(n_tiles), dim3(256), 0, s, qk, v, ld, channels,
-                    heads, tiles, static_cast<unsigned char*>(images));
-    return check_launch("emph_split_kv");
+    return with_pieces(pieces, "emph_split_kv", [&](auto pk, auto pv) {
+        EMPH_LAUNCH((split_kv_kernel<40, decltype(pk)::value, decltype(pv)::value>), dim3(n_tiles),
+                    dim3(256), 0, s, qk, v, ld, channels, heads, tiles,
+                    static_cast<unsigned char*>(images));
+        return check_launch("emph_split_kv");
+    });
 }
 
 int emph_attention_split(const float* qk, const void* images, float* out, int64_t ld,
@@ -564,34 +603,24 @@ int emph_attention_split(const float* qk, const void* images, float* out, int64_
     EMPH_REQUIRE(tile_n == kSplitQueries, EMPH_EINVAL,
                  "emph_attention_split: tile_n %d (a workgroup owns %d queries)", tile_n,
                  kSplitQueries);
-    EMPH_REQUIRE(pieces == 2 || pieces == 3, EMPH_EINVAL,
-                 "emph_attention_split: %d pieces (2: three products per term, 3: six)", pieces);
     EMPH_REQUIRE(heads > 0 && channels % heads == 0 && channels / heads == 40, EMPH_ERANGE,
                  "emph_attention_split: head dimension %d (built for 40 = 80 channels, 2 heads)",
                  heads > 0 ? channels / heads : 0);
     hipStream_t s = static_cast<hipStream_t>(stream);
     dim3 grid(n_tiles, heads);
     const unsigned char* bytes = static_cast<const unsigned char*>(images);
-    if (pieces == 2) {
-        auto kernel = attention_split_kernel<40, 2>;
-        const size_t lds = kSplitRing * SplitImages<40, 2>::kStageBytes;
+    return with_pieces(pieces, "emph_attention_split", [&](auto pk, auto pv) {
+        constexpr int PK = decltype(pk)::value, PV = decltype(pv)::value;
+        auto kernel = attention_split_kernel<40, PK, PV>;
+        const size_t lds = kSplitRing * SplitImages<40, PK, PV>::kStageBytes;
         static LdsReservation reserved;
         if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,
                                      "emph_attention_split"))
             return status;
         EMPH_LAUNCH(kernel, grid, dim3(64 * kSplitWaves), lds, s, qk, bytes, out, ld, channels,
                     tiles, key_counts SPLIT_STAMP_PASS);
-    } else {
-        auto kernel = attention_split_kernel<40, 3>;
-        const size_t lds = kSplitRing * SplitImages<40, 3>::kStageBytes;
-        static LdsReservation reserved;
-        if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), lds,
-                                     "emph_attention_split"))
-            return status;
-        EMPH_LAUNCH(kernel, grid, dim3(64 * kSplitWaves), lds, s, qk, bytes, out, ld, channels,
-                    tiles, key_counts SPLIT_STAMP_PASS);
-    }
-    return check_launch("emph_attention_split");
+        return check_launch("emph_attention_split");
+    });
 }
 
 }  // extern "C"

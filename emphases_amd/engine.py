@@ -28,8 +28,14 @@ from . import runtime
 from . import weights as weights_module
 
 FRONTEND_BLOCK = None   # frames per front-end tile: emph_frontend_block()
-# `precision` of an engine -> bf16 pieces per fp32 operand (0: fp32 MFMA)
-PRECISIONS = {'f32': 0, 'bf16x3': 2, 'bf16x6': 3}
+# `precision` of an engine -> (bf16 pieces per operand of the frame-rate convs,
+# `pieces` code of emph_attention_split); 0: the fp32 kernels.
+#   'bf16x3'  convs: two pieces, three products per term.  Attention: THREE pieces
+#             for queries and keys (six products: the scores' error sits in front of an
+#             exponential and would grow with their range), two behind the softmax
+#   'bf16x6'  attention: three pieces everywhere (fp32 grade); the convs stay fp32
+#             (six products of the direct form would not beat fp32 F(4,3))
+PRECISIONS = {'f32': (0, 0), 'bf16x3': (2, 32), 'bf16x6': (0, 3)}
 ATTENTION_BLOCK = 64    # queries per attention wave (csrc/transformer.hip)
 ATTENTION_GROUP = 256   # queries per attention workgroup (LDS-staged keys/values)
 # Which kernel takes a segment depends on the segment alone (scores must not
@@ -103,13 +109,14 @@ class Engine:
         segments, 'bf16x3' / 'bf16x6': fp32 operands split into two / three
         bf16 pieces, three / six products per term on the bf16 matrix pipe,
         fp32 accumulation (csrc/attention_split.hip; the reference itself
-        runs these matmuls under bf16 / fp16 autocast, core.py:594-607)."""
+        runs these matmuls under bf16 / fp16 autocast, core.py:594-607).
+        See `PRECISIONS` for what each name selects per kernel."""
         if precision not in PRECISIONS:
             raise ValueError(
                 f'precision {precision!r} is not one of {sorted(PRECISIONS)}')
         self.config = config
         self.precision = precision
-        self.split_pieces = PRECISIONS[precision]
+        self.split_pieces, self.attention_pieces = PRECISIONS[precision]
         self.winograd = winograd
         self.device = runtime.require_gpu(device)
         self.lib = runtime.library()
@@ -739,11 +746,11 @@ class Engine:
         # pipe - the layer's keys and values are split once (all 64-position
         # tiles of the axis), the grouped launch reads the pieces
         split_images = None
-        if self.split_pieces and config.channels // config.heads == 40 and \
+        if self.attention_pieces and config.channels // config.heads == 40 and \
                 any(tile_n == ATTENTION_GROUP for _, _, tile_n in launches):
             size = int(self.lib.emph_split_kv_bytes(
                 ld, len(plan.segments), channels, config.heads,
-                self.split_pieces))
+                self.attention_pieces))
             key = (tag + '_split_kv', (size,))
             split_images = self._workspace.get(key)
             if split_images is None:
@@ -761,14 +768,14 @@ class Engine:
                     runtime.check(self.lib.emph_split_kv(
                         qk.data_ptr(), v.data_ptr(), ld, channels,
                         config.heads, att_tiles.data_ptr(), att_count,
-                        ATTENTION_BLOCK, self.split_pieces,
+                        ATTENTION_BLOCK, self.attention_pieces,
                         split_images.data_ptr(), runtime.stream()),
                         'emph_split_kv')
                     runtime.check(self.lib.emph_attention_split(
                         qk.data_ptr(), split_images.data_ptr(),
                         attended.data_ptr(), ld, channels, config.heads,
                         tiles.data_ptr(), count, tile_n, counts_pointer,
-                        self.split_pieces, runtime.stream()),
+                        self.attention_pieces, runtime.stream()),
                         'emph_attention_split')
                     continue
                 runtime.check(self.lib.emph_attention(

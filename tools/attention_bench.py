@@ -53,7 +53,7 @@ def main():
     run('fp32 MFMA (emph_attention)', lambda out: runtime.check(lib.emph_attention(
         qk.data_ptr(), v.data_ptr(), out.data_ptr(), ld, channels, heads, tiles.data_ptr(),
         size // 4, 256, None, None), 'emph_attention'))
-    for pieces in (2, 3):
+    for pieces in (2, 32, 3):
         images = torch.zeros(lib.emph_split_kv_bytes(ld, count, channels, heads, pieces),
                              dtype=torch.uint8, device=device)
 

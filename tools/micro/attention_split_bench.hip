@@ -85,8 +85,8 @@ int main() {
         printf("%s\n", emph::bench_error);
         return 1;
     }
-    auto kernel = emph::attention_split_kernel<40, BENCH_PIECES>;
-    const size_t lds = emph::kSplitRing * emph::SplitImages<40, BENCH_PIECES>::kStageBytes;
+    auto kernel = emph::attention_split_kernel<40, (BENCH_PIECES == 32 ? 3 : BENCH_PIECES), (BENCH_PIECES == 32 ? 2 : BENCH_PIECES)>;
+    const size_t lds = emph::kSplitRing * emph::SplitImages<40, (BENCH_PIECES == 32 ? 3 : BENCH_PIECES), (BENCH_PIECES == 32 ? 2 : BENCH_PIECES)>::kStageBytes;
     CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -127,6 +127,6 @@ int main() {
         printf("  %-40s %9.0f  (%5.1f %%)  %7.1f per %s\n", what[i], sum[i] / waves, 100. * sum[i] / waves / total,
                sum[i] / waves / (i >= 5 || i == 0 ? stages : blocks), i >= 5 || i == 0 ? "stage" : "block");
     printf("  total %.0f cycles per wave = %.1f us at 2.1 GHz; matrix pipe alone: %d MFMAs x 32 cycles x 2 waves = %d per block pair\n",
-           total, total / 2.1e3, 7 * (BENCH_PIECES == 2 ? 3 : 6), 7 * (BENCH_PIECES == 2 ? 3 : 6) * 64);
+           total, total / 2.1e3, (BENCH_PIECES == 2 ? 21 : BENCH_PIECES == 3 ? 42 : 30), (BENCH_PIECES == 2 ? 21 : BENCH_PIECES == 3 ? 42 : 30) * 64);
     return 0;
 }

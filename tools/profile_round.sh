@@ -30,6 +30,10 @@ done
 cd $repo
 python3 bench.py --config transformer --steps 50 --warmup 5 --no-cpu-baseline --no-side \
     > $out/${tag}_transformer_bench.json 2>> $out/${tag}_bench.err
+for precision in bf16x3 bf16x6; do
+    python3 bench.py --config transformer --precision $precision --steps 50 --warmup 5 --no-cpu-baseline --no-side \
+        > $out/${tag}_transformer_$precision.json 2>> $out/${tag}_bench.err
+done
 cd /tmp
 rm -rf /tmp/prof_t
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_t -- \
@@ -44,6 +48,15 @@ for counter in FETCH_SIZE WRITE_SIZE; do
         --streams 1 --no-graph > /dev/null 2>> $out/${tag}_bench.err
     cp $(find /tmp/pmct_$counter -name '*counter_collection.csv' | head -1) \
         $out/${tag}_transformer_pmc_$(echo $counter | tr A-Z a-z).csv
+done
+# the opt-in precisions under rocprofv3: the split kernels' own durations
+for config in conv transformer; do
+    rm -rf /tmp/prof_s_$config
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_s_$config -- \
+        python3 $repo/bench.py --config $config --precision bf16x3 --steps 20 --warmup 5 --regions 3 --no-cpu-baseline \
+        --no-api --no-side --streams 1 > /dev/null 2>> $out/${tag}_bench.err
+    cp $(find /tmp/prof_s_$config -name '*kernel_stats.csv' | head -1) \
+        $out/${tag}_${config}_bf16x3_kernel_stats_1stream.csv
 done
 ls -la $out | grep $tag
 cat $out/${tag}_bench.json
