@@ -360,12 +360,13 @@ class Plan:
             self._tiles['conv_spans'] = cached
         return cached
 
-    def sum_restarts(self, spans=None, tile=64):
+    def sum_restarts(self, spans=None, tile=64, step=64):
         """Packed frame columns at which the running sum of the last
         frame-rate layer restarts: every `tile` frames from a segment's start
         (`emph_conv1d_winograd4_word_sums`), or - `spans` - at a span's first
-        own position and every 64 COMPUTED positions inside it
-        (`emph_conv1d_stack`)."""
+        own position and every `step` COMPUTED positions inside it (64:
+        `emph_conv1d_stack`; 32: `emph_conv1d_split`, whose waves own 32
+        positions each)."""
         if spans is None:
             tiles = -(-self.frames // tile)
             segment = np.repeat(np.arange(len(self.frames)), tiles)
@@ -375,7 +376,8 @@ class Plan:
         first, column = spans[:, 1].astype(np.int64), spans[:, 2].astype(np.int64)
         owned, computed = spans[:, 4].astype(np.int64), spans[:, 5].astype(np.int64)
         starts = np.maximum(
-            first[:, None], computed[:, None] + 64 * np.arange(4)[None])
+            first[:, None],
+            computed[:, None] + step * np.arange(256 // step)[None])
         keep = starts < (first + owned)[:, None]
         keep[:, 1:] &= starts[:, 1:] > starts[:, :-1]
         return np.unique((column[:, None] + starts)[keep])
@@ -450,7 +452,8 @@ class Plan:
         """Packed word-axis column of every word, in segment order."""
         return self._columns
 
-    def pack_metadata(self, tile_requests, word_sums=False, spans=False):
+    def pack_metadata(self, tile_requests, word_sums=False, spans=False,
+                      sum_step=64):
         """All integer metadata as one int32 array plus the element offset of
         every piece (the int64 table first, so it stays 8-byte aligned;
         every piece starts on a 16-byte boundary).  `word_sums`: with the
@@ -463,7 +466,8 @@ class Plan:
             pieces.append(('conv_spans', self.conv_spans().ravel()))
         if word_sums:
             tables = self.word_sum_tables(
-                self.sum_restarts(self.conv_spans()) if spans else None)
+                self.sum_restarts(self.conv_spans(), step=sum_step)
+                if spans else None)
             pieces += [(('word_sums', name), tables[name])
                        for name in ('slot_map', 'terms', 'first', 'lengths')]
         for request in tile_requests:

@@ -85,10 +85,18 @@ __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f
 }
 
 // spans: int32 [n][8] of emph_conv_stack_spans
+// WORD_SUMS: the launch's last layer is the one in front of the per-word sum
+// (emphases/core.py:438-454): instead of its output it leaves, in y = sums[slot][ldy],
+// the running sum of the span's own positions - restarting at the span's first own
+// position and at every wave's column tile of 32 - at the frames `slot_map` marks
+// (`Plan.word_sum_tables` with restarts every 32 computed positions); emph_word_sums
+// adds a word's handful of signed terms (as conv_stack.hip does for the fp32 kernel).
+template <bool WORD_SUMS>
 __global__ __launch_bounds__(kSplitThreads) void conv1d_split_kernel(
     const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
     const unsigned char* __restrict__ packs, const float* __restrict__ biases, int layers,
-    int relu_mask, const int32_t* __restrict__ spans CONV_STAMP_ARGUMENT) {
+    int relu_mask, const int32_t* __restrict__ spans,
+    const int32_t* __restrict__ slot_map CONV_STAMP_ARGUMENT) {
     CONV_STAMP_DECLARE
     extern __shared__ __align__(16) unsigned char conv_split_lds[];
     unsigned char* image = conv_split_lds;                         // [2 pieces][264 rows][176 B]
@@ -257,6 +265,44 @@ __global__ __launch_bounds__(kSplitThreads) void conv1d_split_kernel(
         }
         // ---- the launch's last layer: the span's own positions leave the chip as fp32
         const bool mine = inside && p_mine >= owned_first && p_mine < owned_first + owned;
+        if (WORD_SUMS) {
+            // running sums over the wave's 32 positions, channel by channel: an inclusive
+            // scan over the 32 lanes of a half (two DPP rows of 16: row_shr 1, 2, 4, 8
+            // inside a row, then lane 15 of the lower row into the upper one), a fixed
+            // order; positions that are not the span's own count as zero
+            const int slot = mine ? slot_map[column + p_mine] : -1;
+#pragma unroll
+            for (int m = 0; m < kSplitMTiles; ++m)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (32 * m + 8 * b >= kSplitChannels) continue;
+                    const int channel = 32 * m + 8 * b + 4 * half;
+                    float sum[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float out = acc[m][4 * b + i];
+                        if (relu) out = fmaxf(out, 0.f);
+                        float scan = mine ? out : 0.f;
+                        scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, scan), 0x111, 0xf, 0xf, true));
+                        scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, scan), 0x112, 0xf, 0xf, true));
+                        scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, scan), 0x114, 0xf, 0xf, true));
+                        scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, scan), 0x118, 0xf, 0xf, true));
+                        // row_bcast15 into rows 1 and 3: the lower row's total
+                        scan += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(
+                            0, __builtin_bit_cast(int, scan), 0x142, 0xa, 0xf, true));
+                        sum[i] = scan;
+                    }
+                    if (slot >= 0)
+                        *reinterpret_cast<float4*>(y + static_cast<int64_t>(slot) * ldy + channel) =
+                            make_float4(sum[0], sum[1], sum[2], sum[3]);
+                }
+            CONV_STAMP(5);
+            continue;
+        }
         if (mine) {
 #pragma unroll
             for (int m = 0; m < kSplitMTiles; ++m)
@@ -336,24 +382,42 @@ int emph_conv_split_pack(const float* host_weight, void* host_pack) {
 //   biases  float32 [layers][80]
 //   relu_mask  bit l: layer l is followed by ReLU (else identity)
 //   spans   int32 [n_spans][8] from emph_conv_stack_spans (device copy)
+//   slot_map != NULL: the last layer leaves running sums in y = sums[slot][ldy]
+//   (restarts at a span's first own position and every 32 computed positions:
+//   `Plan.word_sum_tables(Plan.sum_restarts(spans, step=32))`), for emph_word_sums
 int emph_conv1d_split(const float* x, int64_t ldx, float* y, int64_t ldy, const void* packs,
                       const float* biases, int32_t layers, int32_t relu_mask,
-                      const int32_t* spans, int32_t n_spans, void* stream) {
+                      const int32_t* spans, int32_t n_spans, const int32_t* slot_map,
+                      void* stream) {
     if (n_spans == 0) return EMPH_OK;
     EMPH_REQUIRE(x && y && packs && biases && spans, EMPH_EINVAL, "emph_conv1d_split: null pointer");
     EMPH_REQUIRE(layers >= 1 && layers <= kSplitMaxLayers, EMPH_ERANGE,
                  "emph_conv1d_split: %d layers (1 .. %d)", layers, kSplitMaxLayers);
     EMPH_REQUIRE((reinterpret_cast<uintptr_t>(packs) & 15) == 0, EMPH_EINVAL,
                  "emph_conv1d_split: the packs must be 16-byte aligned");
-    auto kernel = conv1d_split_kernel;
-    static LdsReservation reserved;
-    if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel), kSplitLdsBytes,
-                                 "emph_conv1d_split"))
-        return status;
-    EMPH_LAUNCH(kernel, dim3(n_spans), dim3(kSplitThreads), kSplitLdsBytes,
-                static_cast<hipStream_t>(stream), x, ldx, y, ldy,
-                static_cast<const unsigned char*>(packs), biases, layers, relu_mask,
-                spans CONV_STAMP_PASS);
+    EMPH_REQUIRE(slot_map == nullptr ||
+                     ((reinterpret_cast<uintptr_t>(y) & 15) == 0 && (ldy & 3) == 0 &&
+                      ldy >= kSplitChannels),
+                 EMPH_EINVAL, "emph_conv1d_split: bad sums buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned char* bytes = static_cast<const unsigned char*>(packs);
+    if (slot_map != nullptr) {
+        auto kernel = conv1d_split_kernel<true>;
+        static LdsReservation reserved;
+        if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel),
+                                     kSplitLdsBytes, "emph_conv1d_split"))
+            return status;
+        EMPH_LAUNCH(kernel, dim3(n_spans), dim3(kSplitThreads), kSplitLdsBytes, s, x, ldx, y, ldy,
+                    bytes, biases, layers, relu_mask, spans, slot_map CONV_STAMP_PASS);
+    } else {
+        auto kernel = conv1d_split_kernel<false>;
+        static LdsReservation reserved;
+        if (int status = reserve_lds(reserved, reinterpret_cast<const void*>(kernel),
+                                     kSplitLdsBytes, "emph_conv1d_split"))
+            return status;
+        EMPH_LAUNCH(kernel, dim3(n_spans), dim3(kSplitThreads), kSplitLdsBytes, s, x, ldx, y, ldy,
+                    bytes, biases, layers, relu_mask, spans, slot_map CONV_STAMP_PASS);
+    }
     return check_launch("emph_conv1d_split");
 }
 

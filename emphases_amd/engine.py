@@ -234,6 +234,8 @@ class Engine:
         # to five layers per launch.  ('bf16x6' keeps the fp32 kernel here:
         # six products of the direct form would not beat F(4,3) in fp32)
         self.split_conv = bool(self.stack and self.split_pieces == 2)
+        # computed positions between two restarts of the folded running sum
+        self.sum_step = 32 if self.split_conv else 64
         if self.split_conv:
             self._split_packs = to(np.concatenate(
                 [runtime.conv_split_pack(layer.weight) for layer in frame_stack]))
@@ -480,7 +482,7 @@ class Engine:
         fold = self.fold and not nested and tile == 64
         stack = self.stack and not nested and tile == 64
         host, offsets = plan.pack_metadata(
-            requests, word_sums=fold, spans=stack)
+            requests, word_sums=fold, spans=stack, sum_step=self.sum_step)
         return host, offsets, fold, stack
 
     def upload(self, plan, tile=None, nested=False):
@@ -500,8 +502,8 @@ class Engine:
             views[name] = (device_buffer[start:start + size], size)
         if fold:
             views['n_slots'] = plan.word_sum_tables(
-                plan.sum_restarts(plan.conv_spans()) if stack else None)[
-                    'n_slots']
+                plan.sum_restarts(plan.conv_spans(), step=self.sum_step)
+                if stack else None)['n_slots']
             views['word_sum_tables'] = runtime.WordSumTables(
                 *[views[('word_sums', name)][0].data_ptr() for name in (
                     'slot_map', 'terms', 'first', 'lengths')],
@@ -864,8 +866,7 @@ class Engine:
         relu_layers = config.activation == 'relu'
         source, buffers, done = features, (a, b), 0
         if self.split_conv:
-            # bf16x3: up to five layers per launch, the per-word sum unfolded
-            fold = False
+            # bf16x3: up to five layers per launch
             groups = -(-total // 5)
             split_bytes = int(self.lib.emph_conv_split_pack_size())
         for group in range(groups if frames else 0):
@@ -878,10 +879,12 @@ class Engine:
             if self.split_conv:
                 with self._timed('conv1d_split_frames_80x80_k3', flops):
                     runtime.check(self.lib.emph_conv1d_split(
-                        source.data_ptr(), ld_f, target.data_ptr(), ld_f,
+                        source.data_ptr(), ld_f, target.data_ptr(),
+                        channels if to_sums else ld_f,
                         self._split_packs[done * split_bytes:].data_ptr(),
                         self._stack_biases[done * channels:].data_ptr(), size,
                         relu, spans.data_ptr(), span_size // 8,
+                        view('slot_map').data_ptr() if to_sums else None,
                         runtime.stream()), 'emph_conv1d_split')
                 source = target
                 done += size

@@ -86,7 +86,8 @@ SIGNATURES = {
     'emph_conv_split_pack_size': (_i64, []),
     'emph_conv_split_pack': (_c.c_int, [_ptr, _ptr]),
     'emph_conv1d_split': (_c.c_int, [
-        _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _i32, _ptr]),
+        _ptr, _i64, _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _i32, _ptr,
+        _ptr]),
     'emph_word_sums': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i32, _i64, _i32, _ptr]),
     'emph_conv_winograd4_split_pack': (_c.c_int, [_ptr, _i32, _i32, _ptr]),

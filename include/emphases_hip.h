@@ -417,14 +417,17 @@ int emph_conv1d_stack(const float* x, int64_t ldx, float* y, int64_t ldy,
  * precision='bf16x3' of the host side - the reference runs these convolutions
  * under bf16 / fp16 autocast (emphases/core.py:594-607).  Same spans as
  * emph_conv1d_stack; `packs`: emph_conv_split_pack of every layer back to back
- * (emph_conv_split_pack_size() bytes each, device, 16-byte aligned); the last
- * layer always writes its output (no folded word sums). */
+ * (emph_conv_split_pack_size() bytes each, device, 16-byte aligned); up to
+ * FIVE layers per launch (the direct form spoils one position less per layer
+ * than F(4,3)).  `slot_map` != NULL: the last layer leaves running sums in
+ * y = sums[slot][ldy] for emph_word_sums, restarting at a span's first own
+ * position and every 32 computed positions. */
 int64_t emph_conv_split_pack_size(void);
 int emph_conv_split_pack(const float* host_weight, void* host_pack);
 int emph_conv1d_split(const float* x, int64_t ldx, float* y, int64_t ldy,
                       const void* packs, const float* biases, int32_t layers,
                       int32_t relu_mask, const int32_t* spans, int32_t n_spans,
-                      void* stream);
+                      const int32_t* slot_map, void* stream);
 
 /* EXPERIMENTAL (measured in EXPERIMENTS.md, rounds 1-4 section 6, not used by the engine):
  * the F(4,3) layer as TWO independent launches ("halves"): half 0 computes the

@@ -333,7 +333,7 @@ def test_conv1d_split(layers, relu_mask):
     runtime.check(lib.emph_conv1d_split(
         x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
         packs.data_ptr(), biases_dev.data_ptr(), layers, relu_mask,
-        spans_dev.data_ptr(), len(spans_host), None), 'emph_conv1d_split')
+        spans_dev.data_ptr(), len(spans_host), None, None), 'emph_conv1d_split')
     # the fp32 kernel beside it (three layers per launch at most)
     plain, source, done = None, x_dev, 0
     pack_floats = plain_packs.numel() // layers
@@ -369,7 +369,7 @@ def test_conv1d_split(layers, relu_mask):
     assert lib.emph_conv1d_split(
         x_dev.data_ptr(), plan.ld_frames, y.data_ptr(), plan.ld_frames,
         packs.data_ptr(), biases_dev.data_ptr(), 6, 0, spans_dev.data_ptr(),
-        len(spans_host), None) != 0         # (five layers at most)
+        len(spans_host), None, None) != 0         # (five layers at most)
 
 
 @pytest.mark.parametrize('c_in,c_out,activation,max_positions', [

@@ -677,6 +677,48 @@ def test_folded_word_sums_against_segment_reduce(method):
         fused[columns].nan_to_num(), stepped[columns].nan_to_num())
 
 
+@pytest.mark.parametrize('method', ['sum', 'average'])
+def test_folded_word_sums_of_the_split_conv(method):
+    """precision='bf16x3': the last launch of emph_conv1d_split leaves running
+    sums that restart every 32 computed positions (its waves own 32 each) -
+    same harsh bounds as above, against the f32 stage taps (the bf16x3 products
+    are 1e-5 of the activations' scale away; the TABLES are what is tested:
+    a wrong restart or slot is an error of the order of the values)."""
+    config = cfg.Config(downsample_method=method)
+    engine = engine_module.Engine(config, None, 0, precision='bf16x3')
+    assert engine.fold and engine.split_conv and engine.sum_step == 32
+    frames = [1000, 37, 130, 64, 65, 1, 447, 3000, 33, 31]
+    audios = [synth.audio(60 + i, n) for i, n in enumerate(frames)]
+    rng = np.random.default_rng(6)
+    bounds = []
+    for n in frames:
+        starts = np.sort(rng.integers(0, n + 1, size=max(2, n // 9)))
+        ends = np.minimum(starts + rng.integers(0, 150, size=starts.size), n + 40)
+        ends[0] = starts[0]                      # an empty word
+        starts[-1] = n + 3                       # starts beyond the chunk
+        ends[-1] = n + 9
+        bounds.append(np.stack([starts, ends]).astype(np.int64))
+    segments = [batch.Segment(i, 0, b.shape[1], 432, n * 160, n, b)
+                for i, (n, b) in enumerate(zip(frames, bounds))]
+    lengths = [a.shape[1] for a in audios]
+    offsets = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+    plan = batch.Plan(segments, offsets, lengths)
+    packed = torch.cat([torch.from_numpy(a).reshape(-1) for a in audios]).cuda()
+    meta = engine.upload(plan)
+    assert 'word_sum_tables' in meta
+    stages = {}
+    engine.forward(packed, plan, meta, stages=stages)     # taps: f32, unfolded
+    want = stages['downsampled']
+    engine.forward(packed, plan, meta)                    # bf16x3, folded
+    got = engine._buffer('words_a', config.channels, plan.ld_words)
+    columns = torch.from_numpy(plan.word_columns()).cuda()
+    got, want = got[:, columns].cpu(), want[:, columns].cpu()
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    scale = float(want.nan_to_num().abs().max())
+    worst = float((got - want).nan_to_num().abs().max())
+    assert worst < 1e-4 * max(scale, 1.), (worst, scale)
+
+
 def test_graph_replay_equals_eager(default_engine):
     """Engine.capture (what bench.py replays): same bits as the eager launch
     sequence, and a replay picks up audio written into the captured buffer."""

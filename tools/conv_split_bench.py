@@ -58,10 +58,10 @@ def main():
     pack_bytes = split.numel() // 7
     run('emph_conv1d_stack (fp32 MFMA, F(4,3))', lambda: stack(lib.emph_conv1d_stack, plain, pack_floats, (None, None)))
     want = stack(lib.emph_conv1d_stack, plain, pack_floats, (None, None)).clone()
-    run('emph_conv1d_split (bf16x3, direct form) 3+2+2', lambda: stack(lib.emph_conv1d_split, split, pack_bytes, (None,)))
-    run('emph_conv1d_split (bf16x3, direct form) 4+3', lambda: stack(lib.emph_conv1d_split, split, pack_bytes, (None,), (4, 3)))
-    run('emph_conv1d_split (bf16x3, direct form) 5+2', lambda: stack(lib.emph_conv1d_split, split, pack_bytes, (None,), (5, 2)))
-    got = stack(lib.emph_conv1d_split, split, pack_bytes, (None,), (4, 3)).clone()
+    run('emph_conv1d_split (bf16x3, direct form) 3+2+2', lambda: stack(lib.emph_conv1d_split, split, pack_bytes, (None, None)))
+    run('emph_conv1d_split (bf16x3, direct form) 4+3', lambda: stack(lib.emph_conv1d_split, split, pack_bytes, (None, None), (4, 3)))
+    run('emph_conv1d_split (bf16x3, direct form) 5+2', lambda: stack(lib.emph_conv1d_split, split, pack_bytes, (None, None), (5, 2)))
+    got = stack(lib.emph_conv1d_split, split, pack_bytes, (None, None), (4, 3)).clone()
     columns = np.concatenate([np.arange(o, o + n) for o, n in zip(plan.frame_off, plan.frames)])
     delta = (got[:, columns] - want[:, columns]).abs().max().item()
     print(f'worst |split - fp32| after seven layers {delta:.2e} at scale {want[:, columns].abs().max().item():.1f}')

@@ -82,11 +82,11 @@ int main() {
     CHECK(hipMemcpy(d_bias, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_packs, packs.data(), packs.size(), hipMemcpyHostToDevice));
     CHECK(hipMemcpy(d_spans, spans.data(), spans.size() * 4, hipMemcpyHostToDevice));
-    auto kernel = emph::conv1d_split_kernel;
+    auto kernel = emph::conv1d_split_kernel<false>;
     CHECK(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, emph::kSplitLdsBytes));
     auto launch = [&] {
         hipLaunchKernelGGL(kernel, dim3(n_spans), dim3(emph::kSplitThreads), emph::kSplitLdsBytes, 0, d_x, (int64_t)ld, d_y,
-                           (int64_t)ld, d_packs, d_bias, LAYERS, (1 << LAYERS) - 1, d_spans, stamps);
+                           (int64_t)ld, d_packs, d_bias, LAYERS, (1 << LAYERS) - 1, d_spans, (const int32_t*)nullptr, stamps);
     };
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
