@@ -50,7 +50,7 @@ __device__ __forceinline__ float activate_word(float x, int act) {
     }
 }
 
-// block = 576 threads: eight MFMA waves + one loader wave; grid = n_tiles.
+// block = 64 (8 + kLoaderWaves) threads: eight MFMA waves + the loader waves; grid = n_tiles.
 // MT = m-tiles per MFMA wave (half of C/16, rounded up).
 //
 // The loader wave: hipcc puts s_waitcnt vmcnt(0) in front of every LDS read
@@ -59,8 +59,18 @@ __device__ __forceinline__ float activate_word(float x, int act) {
 // LDS waits for q+1 to land first - the DMA latency (1.1 us per chunk,
 // measured) ends up in series with the MFMAs instead of under them.  The MFMA
 // waves never have a DMA in flight, so their waits are free.
+// A single wave's LDS-DMA requests complete one after the other (conv_stack.hip:
+// four waves keep a chunk ahead): a chunk is 46 KB here; with ONE loader wave the
+// decoder took 32.4 us, with four 28.5 (round 5).  A third ring slot with chunks
+// requested two ahead was tried and is slower (three smaller chunks per layer, one
+// more barrier each: 34 us).
+#ifndef EMPH_DECODER_LOADERS
+#define EMPH_DECODER_LOADERS 4
+#endif
+constexpr int kLoaderWaves = EMPH_DECODER_LOADERS;
+
 template <int KS, int MT>
-__global__ __launch_bounds__(576) void word_decoder_kernel(
+__global__ __launch_bounds__(64 * (8 + kLoaderWaves)) void word_decoder_kernel(
     const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ tiles,
     int block, int halo, int channels, const float* __restrict__ packs,
     const float* __restrict__ biases, int layers, int act, int chunk_trips,
@@ -70,7 +80,7 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
     const int m_tiles = channels >> 4;
     const int threads = blockDim.x;
     const int waves = threads >> 6;
-    const int compute_waves = waves - 1;
+    const int compute_waves = waves - kLoaderWaves;
     // (the two activation buffers are addressed as lds + index * size: a runtime-
     // indexed array of pointers would decay to flat addressing)
     const int buffer_floats = channels * kActStride;
@@ -119,19 +129,21 @@ __global__ __launch_bounds__(576) void word_decoder_kernel(
     const int chunks_per_layer = (trips + chunk_trips - 1) / chunk_trips;
     const int total_chunks = layers * chunks_per_layer;
     const int chunk_floats = chunk_trips * trip_floats;
-    auto request = [&](int q) {                       // loader wave only
+    auto request = [&](int q) {                       // loader waves only
         const int layer = q / chunks_per_layer;
         const int first = (q - layer * chunks_per_layer) * chunk_trips;
         const int quads = min(chunk_trips, trips - first) * (trip_floats >> 2);
         const float* source =
             packs + (static_cast<int64_t>(layer) * trips + first) * trip_floats;
         float* target = ring + (q & 1) * chunk_floats;
-        for (int base = 0; base < quads; base += 64)  // trip_floats % 256 == 0
+        // (1 KB requests dealt over the loader waves)
+        for (int base = 64 * (wave - compute_waves); base < quads;
+             base += 64 * kLoaderWaves)               // trip_floats % 256 == 0
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(source + 4 * (base + lane)),
                 (__attribute__((address_space(3))) void*)(target + 4 * base), 16, 0, 0);
     };
-    const bool loader = wave == waves - 1;
+    const bool loader = wave >= compute_waves;
     if (total_chunks > 0 && loader) request(0);
 
     // Everything else the stages need comes into LDS in the same round trip
@@ -459,7 +471,7 @@ int emph_word_decoder(const float* x, int64_t ldx, const int32_t* tiles,
                  "emph_word_decoder: receptive field too wide for a 64-word window");
     const int halo = (kWindow - block) / 2;
     const int m_tiles = channels / 16;
-    const int threads = 576;              // 8 MFMA waves + the loader wave
+    const int threads = 64 * (8 + kLoaderWaves);      // 8 MFMA waves + the loader waves
     // two weight chunks of whole trips in whatever LDS the activations leave
     // (80 channels: 3 + 2 trips per layer, i.e. one chunk barrier per layer;
     // each barrier costs about 0.3 us)
