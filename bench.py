@@ -1084,7 +1084,9 @@ def side_files_api(device, count=4096):
             prefixes.append(os.path.join(directory, f'out{index}'))
         # warm-up on files of their own, then every lap on files (alignments)
         # nobody has seen: no cached plan, no captured graph - what a corpus is
-        warm = slice(laps_wanted * count, laps_wanted * count + 512)
+        # (four batches: every pinned buffer of the session exists afterwards)
+        warm = slice(laps_wanted * count,
+                     laps_wanted * count + min(count, 2048))
         emphases_amd.from_files_to_files(
             texts[warm], waves[warm], prefixes[warm], gpu=device.index)
         laps = []
@@ -1107,7 +1109,7 @@ def side_files_api(device, count=4096):
                 '.TextGrid files in /dev/shm through '
                 'emphases_amd.from_files_to_files (emphases/core.py:115-179): '
                 'read + parse + plan + stage + H2D + kernels + D2H + write '
-                '.TextGrid and .pt per file; batches of 256 files, two in '
+                '.TextGrid and .pt per file; batches of 512 files, two in '
                 'flight; every lap on alignments never seen before'),
             'files': count, 'seconds': seconds, 'laps_s': laps,
             'files_per_s': count / seconds,

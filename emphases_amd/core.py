@@ -215,7 +215,7 @@ def from_file_to_file(text_file, audio_file, output_prefix=None,
 
 
 def files_to_scores(text_files, audio_files, session, batch_size=None,
-                    utterances_per_batch=256, deliver=None,
+                    utterances_per_batch=512, deliver=None,
                     deliver_batch=None):
     """The loop of `core.py:169-179` over ragged batches of
     `utterances_per_batch` files, two batches in flight.  A batch of files is
@@ -379,7 +379,7 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
 
 def from_files_to_files(text_files, audio_files, output_prefixes=None,
                         checkpoint=None, batch_size=None, gpu=None,
-                        utterances_per_batch=256, conv_tile=None):
+                        utterances_per_batch=512, conv_tile=None):
     """`core.py:115-179`, but the files are processed in ragged batches of
     `utterances_per_batch` instead of one at a time, two batches in flight,
     read, parsed and written by the library's host threads

@@ -67,9 +67,13 @@ def stage_threads(openers=1):
     if 'EMPHASES_FILE_THREADS' in os.environ:
         return THREADS, THREADS
     spare = max(2, _cpu_budget() - 4)        # the caller, HIP's threads, the helpers
-    opening = max(1, min(12, spare * 3 // 5))
+    # (measured on a 16-CPU budget, fresh alignments, tools/files_batchsize.py: 3 / 5
+    # threads 55 k files/s, 8 / 4 57-64 k, 12 / 4 59-65 k.  The two openers are
+    # seldom inside the library at once - each spends a third of a batch in Python -
+    # so every open call gets the whole share)
+    opening = max(1, min(12, spare * 2 // 3))
     writing = max(1, min(8, spare - opening))
-    return max(1, opening // max(1, openers)), writing
+    return opening, writing
 
 
 class FileAudio:

@@ -16,8 +16,9 @@ from emphases_amd import load, synth  # noqa: E402
 
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    sizes = (128, 256, 512, 1024)
-    laps_per_size = 3
+    # (utterances_per_batch, threads of an open call, threads of a write call)
+    sizes = ((256, 3, 5), (256, 5, 4), (256, 6, 4), (256, 8, 4), (256, 8, 2), (256, 12, 4), (128, 6, 4), (512, 8, 4))
+    laps_per_size = 4
     directory = tempfile.mkdtemp(prefix='emph_bs_', dir='/dev/shm')
     try:
         waves = []
@@ -39,15 +40,20 @@ def main():
         emphases_amd.from_files_to_files(sets[-1], audio, prefixes, gpu=0, utterances_per_batch=1024)
         emphases_amd.from_files_to_files(sets[-1], audio, prefixes, gpu=0)
         lap = 0
-        for size in sizes:
+        import gc
+        for size, opening, writing in sizes:
+            os.environ['EMPHASES_OPEN_THREADS'] = str(opening)
+            os.environ['EMPHASES_WRITE_THREADS'] = str(writing)
             times = []
             for _ in range(laps_per_size):
+                gc.collect()
                 start = time.perf_counter()
                 emphases_amd.from_files_to_files(sets[lap], audio, prefixes, gpu=0, utterances_per_batch=size)
                 times.append(time.perf_counter() - start)
                 lap += 1
-            print(f'utterances_per_batch {size:5d}: laps (ms) ' + ' '.join(f'{t * 1e3:.1f}' for t in times)
-                  + f' -> best {count / min(times):.0f} files/s, median {count / sorted(times)[1]:.0f}')
+            print(f'utterances_per_batch {size:5d}, file pools open {opening:2d} / write {writing}: laps (ms) '
+                  + ' '.join(f'{t * 1e3:.1f}' for t in times)
+                  + f' -> best {count / min(times):.0f} files/s, median {count / sorted(times)[len(times) // 2]:.0f}')
     finally:
         shutil.rmtree(directory, ignore_errors=True)
 
