@@ -319,7 +319,11 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
                 deliver(index, opened.alignment(local), item)
         _stamp('write', position, start)
 
+    # (a quarter and a half batch at both ends, to ramp the pipeline up and down,
+    # was measured and is not faster: 57-58 ms against 54-57 for 4 096 files)
     starts = list(range(0, len(text_files), utterances_per_batch))
+    ends = [min(first + utterances_per_batch, len(text_files))
+            for first in starts]
     ahead = session_module.FILE_BUFFERS - 2
     opener = concurrent.futures.ThreadPoolExecutor(
         ahead, thread_name_prefix='emphases-open')
@@ -338,10 +342,8 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
             writes.pop(0).result()
 
     def ask(position):
-        first = starts[position]
         return opener.submit(
-            open_batch, first,
-            min(first + utterances_per_batch, len(text_files)), position)
+            open_batch, starts[position], ends[position], position)
 
     try:
         opening = collections.deque(

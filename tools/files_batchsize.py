@@ -17,7 +17,7 @@ from emphases_amd import load, synth  # noqa: E402
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     # (utterances_per_batch, threads of an open call, threads of a write call)
-    sizes = ((256, 3, 5), (256, 5, 4), (256, 6, 4), (256, 8, 4), (256, 8, 2), (256, 12, 4), (128, 6, 4), (512, 8, 4))
+    sizes = ((512, 8, 4), (512, 12, 4), (1024, 8, 4), (384, 8, 4))
     laps_per_size = 4
     directory = tempfile.mkdtemp(prefix='emph_bs_', dir='/dev/shm')
     try:
@@ -41,6 +41,10 @@ def main():
         emphases_amd.from_files_to_files(sets[-1], audio, prefixes, gpu=0)
         lap = 0
         import gc
+        from emphases_amd import session as session_module
+        if len(sys.argv) > 2:
+            session_module.FILE_BUFFERS = int(sys.argv[2])
+        print('FILE_BUFFERS', session_module.FILE_BUFFERS)
         for size, opening, writing in sizes:
             os.environ['EMPHASES_OPEN_THREADS'] = str(opening)
             os.environ['EMPHASES_WRITE_THREADS'] = str(writing)
