@@ -1176,3 +1176,49 @@ def test_torch_library_ops_are_registered_and_refuse_the_cpu():
         ops.logmel(torch.zeros(16000), edges)
     with pytest.raises(runtime.LibraryError, match='no CPU'):
         ops.segment_reduce(torch.zeros(80, 10), torch.zeros(2, 1), edges, edges, 'sum')
+
+
+def test_conv_split_pack_is_two_bf16_pieces_in_fragment_order():
+    """emph_conv_split_pack (host): every weight as two bf16 pieces whose sum is
+    within 2^-17 of it, laid out [tap][block][m-tile][piece][lane][8] with lane =
+    (output channel 32 m + lane % 32, input channels 16 block + 8 (lane / 32) ..);
+    rows 80 .. 95 are zeros."""
+    from emphases_amd import runtime
+    lib = runtime.library()
+    weight = synth.weights(77, (80, 80, 3), 0.3)
+    pack = runtime.conv_split_pack(weight)
+    assert pack.nbytes == lib.emph_conv_split_pack_size() == 3 * 5 * 3 * 2 * 1024
+    halves = pack.view(np.uint16).reshape(3, 5, 3, 2, 64, 8)
+    values = (halves.astype(np.uint32) << 16).view(np.float32)
+    rebuilt = np.zeros((96, 80, 3), dtype=np.float64)
+    for tap in range(3):
+        for block in range(5):
+            for m in range(3):
+                for lane in range(64):
+                    row = 32 * m + lane % 32
+                    channels = 16 * block + 8 * (lane // 32) + np.arange(8)
+                    rebuilt[row, channels, tap] = \
+                        values[tap, block, m, 0, lane].astype(np.float64) + \
+                        values[tap, block, m, 1, lane]
+    assert np.all(rebuilt[80:] == 0.)
+    error = np.abs(rebuilt[:80] - weight)
+    assert float((error / np.maximum(np.abs(weight), 1e-30)).max()) < 2.0 ** -16
+    # the leading piece is the weight rounded to nearest (even) bf16
+    bits = weight.view(np.uint32)
+    nearest = ((bits + 0x7fff + ((bits >> 16) & 1)) >> 16).astype(np.uint16)
+    lane, m, block, tap = 37, 1, 3, 2
+    row, channels = 32 * m + lane % 32, 16 * block + 8 * (lane // 32) + np.arange(8)
+    assert np.array_equal(halves[tap, block, m, 0, lane], nearest[row, channels, tap])
+
+
+def test_split_kv_scratch_sizes_and_piece_codes():
+    from emphases_amd import runtime
+    lib = runtime.library()
+    key, value = 6 * 64 * 16, 8 * 42 * 16      # a piece of a 64-key stage: K, V
+    ld, segments = 64 * 100, 7
+    slots = ld // 64 + segments + 1
+    for code, (pk, pv) in ((2, (2, 2)), (3, (3, 3)), (32, (3, 2))):
+        assert lib.emph_split_kv_bytes(ld, segments, 80, 2, code) == \
+            slots * 2 * (pk * key + pv * value)
+    assert lib.emph_split_kv_bytes(ld, segments, 80, 2, 4) == -1      # no such split
+    assert lib.emph_split_kv_bytes(ld, segments, 64, 2, 2) == -1      # head dimension 32
