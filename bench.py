@@ -86,7 +86,7 @@ def parse_args():
     parser.add_argument('--config', default='conv',
                         choices=['conv', 'transformer'])
     parser.add_argument('--precision', default='f32',
-                        choices=['f32', 'bf16x3', 'bf16x6'],
+                        choices=['f32', 'bf16x3', 'bf16x3_fast', 'bf16x6'],
                         help='the opt-in split-bf16 precisions of '
                              'engine.Engine (conv stack / attention); the '
                              'headline is f32')
@@ -610,6 +610,7 @@ PEAK_BF16_MFMA = 2500.        # TFLOP/s dense, same guide
 # 41 -> 64) per 2 x 2 x 32 x 32 x 40 flops; 'bf16x3': six products for the scores, three
 # for the values
 SPLIT_EXECUTED = {'bf16x3': (3 * 6 + 4 * 3) * 32768 / 163840.,
+                  'bf16x3_fast': (3 * 6 + 4 * 3) * 32768 / 163840.,
                   'bf16x6': 7 * 6 * 32768 / 163840.}
 
 
@@ -1627,7 +1628,7 @@ def run_batch(args, rank, world, device, host):
                     side_transformer, device, audios, alignments, args)
                 reference_scores = plain.pop('_scores', None)
                 result['configs_2_transformer'] = plain
-                for precision in ('bf16x3', 'bf16x6'):
+                for precision in ('bf16x3', 'bf16x3_fast', 'bf16x6'):
                     entry = guarded(
                         side_transformer, device, audios, alignments, args,
                         precision, reference_scores)

@@ -65,8 +65,8 @@ def get_engine(checkpoint=None, gpu=None, config=None, conv_tile=None,
     in any batch and on any shard; 64 / 32 / 16 pin a tile; 'auto' picks the
     lowest-latency variant by batch size (a few utterances then take the
     direct form, which agrees with the Winograd kernels to 1e-6, not
-    bitwise).  `precision`: 'f32', or the opt-in 'bf16x3' / 'bf16x6' of
-    `engine.Engine`."""
+    bitwise).  `precision`: 'f32', or one of the opt-in split-bf16 names of
+    `engine.PRECISIONS`."""
     device = runtime.require_gpu(gpu)
     index = device.index if device.index is not None else \
         torch.cuda.current_device()
@@ -147,7 +147,8 @@ def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
         the stand-in for `penn.from_audio` (`data/preprocess/core.py:84-92`):
         `(chunk audio [1, Sc]) -> (pitch [1, Fc] Hz, periodicity [1, Fc])`;
         default: `penn` itself, if installed.
-    precision: 'f32' (default), or 'bf16x3' / 'bf16x6' (`engine.Engine`).
+    precision: 'f32' (default), or 'bf16x3' / 'bf16x3_fast' / 'bf16x6'
+        (`engine.PRECISIONS`).
     Returns a list of float32 tensors [1, W_i] (CPU if `gpu is None`)."""
     session = get_session(checkpoint, gpu, config, conv_tile, precision)
     return session.run(

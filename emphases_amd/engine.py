@@ -29,13 +29,21 @@ from . import weights as weights_module
 
 FRONTEND_BLOCK = None   # frames per front-end tile: emph_frontend_block()
 # `precision` of an engine -> (bf16 pieces per operand of the frame-rate convs,
-# `pieces` code of emph_attention_split); 0: the fp32 kernels.
-#   'bf16x3'  convs: two pieces, three products per term.  Attention: THREE pieces
-#             for queries and keys (six products: the scores' error sits in front of an
-#             exponential and would grow with their range), two behind the softmax
-#   'bf16x6'  attention: three pieces everywhere (fp32 grade); the convs stay fp32
-#             (six products of the direct form would not beat fp32 F(4,3))
-PRECISIONS = {'f32': (0, 0), 'bf16x3': (2, 32), 'bf16x6': (0, 3)}
+# `pieces` code of emph_attention_split, pieces per operand of the Transformer's
+# projections and position-wise GEMMs: csrc/block_split.hip); 0: the fp32 kernels.
+#   'bf16x3'       convs: two pieces, three products per term.  Attention: THREE pieces
+#                  for queries and keys (six products: the scores' error sits in front
+#                  of an exponential and would grow with their range), two behind the
+#                  softmax.  Projections and block: three pieces (24 GEMMs and 12
+#                  LayerNorms in a row: with two, 2e-5 on the scores of configs[2];
+#                  with three, 2e-6 - the f32 kernels' own noise)
+#   'bf16x3_fast'  ... two pieces there too: every GEMM but the scores at three
+#                  products per term
+#   'bf16x6'       attention, projections and block: three pieces everywhere (fp32
+#                  grade); the convs stay fp32 (six products of the direct form would
+#                  not beat fp32 F(4,3))
+PRECISIONS = {'f32': (0, 0, 0), 'bf16x3': (2, 32, 3), 'bf16x3_fast': (2, 32, 2),
+              'bf16x6': (0, 3, 3)}
 ATTENTION_BLOCK = 64    # queries per attention wave (csrc/transformer.hip)
 ATTENTION_GROUP = 256   # queries per attention workgroup (LDS-staged keys/values)
 # Which kernel takes a segment depends on the segment alone (scores must not
@@ -105,18 +113,22 @@ class Engine:
     def __init__(self, config=cfg.DEFAULT, state=None, device=None,
                  conv_tile=None, winograd=True, precision='f32'):
         """`precision`: 'f32' (default: every product on the fp32 matrix
-        instruction) or, an opt-in for the Transformer's attention over long
-        segments, 'bf16x3' / 'bf16x6': fp32 operands split into two / three
-        bf16 pieces, three / six products per term on the bf16 matrix pipe,
-        fp32 accumulation (csrc/attention_split.hip; the reference itself
-        runs these matmuls under bf16 / fp16 autocast, core.py:594-607).
-        See `PRECISIONS` for what each name selects per kernel."""
+        instruction) or an opt-in, 'bf16x3' / 'bf16x3_fast' / 'bf16x6': fp32
+        operands split into two / three bf16 pieces, three / six products
+        per term on the bf16 matrix pipe, fp32 accumulation (csrc/
+        conv_split.hip, attention_split.hip, block_split.hip; the reference
+        itself runs these matmuls under bf16 / fp16 autocast,
+        core.py:594-607).  See `PRECISIONS` for what each name selects per
+        kernel."""
         if precision not in PRECISIONS:
             raise ValueError(
                 f'precision {precision!r} is not one of {sorted(PRECISIONS)}')
         self.config = config
         self.precision = precision
-        self.split_pieces, self.attention_pieces = PRECISIONS[precision]
+        self.split_pieces, self.attention_pieces, self.linear_pieces = \
+            PRECISIONS[precision]
+        if os.environ.get('EMPHASES_LINEAR_PIECES'):      # (experiments)
+            self.linear_pieces = int(os.environ['EMPHASES_LINEAR_PIECES'])
         self.winograd = winograd
         self.device = runtime.require_gpu(device)
         self.lib = runtime.library()
@@ -344,8 +356,23 @@ class Engine:
                     runtime.linear_chain_pack(
                         in_w[part * channels:(part + 1) * channels], True)
                     for part in range(3)])), to(in_b.astype(np.float32)))
+            # precision='bf16x3': the same two launches on the bf16 matrix pipe
+            block_split = qkv_split = None
+            if self.linear_pieces and channels == 80 and block is not None:
+                pieces = self.linear_pieces
+                block_split = (
+                    to(np.concatenate([
+                        runtime.linear_split_pack(state[p + name], pieces)
+                        for name in ('self_attn.out_proj.weight',
+                                     'linear1.weight', 'linear2.weight')])),
+                    block[1])
+                qkv_split = (to(np.concatenate([
+                    runtime.linear_split_pack(
+                        in_w[part * channels:(part + 1) * channels], pieces)
+                    for part in range(3)])), qkv[1])
             layers.append(dict(
-                block=block, qkv=qkv,
+                block=block, qkv=qkv, block_split=block_split,
+                qkv_split=qkv_split,
                 qk=_Conv(in_w[:2 * channels], in_b[:2 * channels], dev),
                 v=_Conv(in_w[2 * channels:], in_b[2 * channels:], dev),
                 out=_Conv(state[p + 'self_attn.out_proj.weight'],
@@ -762,17 +789,24 @@ class Engine:
                     size, dtype=torch.uint8, device=self.device)
                 self._workspace[key] = split_images
 
-        def attend():
+        # ... or the projection kernel writes the pieces itself (no fp32 K and V,
+        # no second pass): when every segment of the axis is a long one
+        projected_images = split_images is not None and \
+            all(tile_n == ATTENTION_GROUP for _, _, tile_n in launches) and \
+            os.environ.get('EMPHASES_SPLIT_IMAGES', '1') != '0'
+
+        def attend(images_written):
             for tiles, count, tile_n in launches:
                 counts_pointer = None if key_counts is None else \
                     key_counts.data_ptr()
                 if split_images is not None and tile_n == ATTENTION_GROUP:
-                    runtime.check(self.lib.emph_split_kv(
-                        qk.data_ptr(), v.data_ptr(), ld, channels,
-                        config.heads, att_tiles.data_ptr(), att_count,
-                        ATTENTION_BLOCK, self.attention_pieces,
-                        split_images.data_ptr(), runtime.stream()),
-                        'emph_split_kv')
+                    if not images_written:
+                        runtime.check(self.lib.emph_split_kv(
+                            qk.data_ptr(), v.data_ptr(), ld, channels,
+                            config.heads, att_tiles.data_ptr(), att_count,
+                            ATTENTION_BLOCK, self.attention_pieces,
+                            split_images.data_ptr(), runtime.stream()),
+                            'emph_split_kv')
                     runtime.check(self.lib.emph_attention_split(
                         qk.data_ptr(), split_images.data_ptr(),
                         attended.data_ptr(), ld, channels, config.heads,
@@ -785,10 +819,38 @@ class Engine:
                     channels, config.heads, tiles.data_ptr(), count, tile_n,
                     counts_pointer, runtime.stream()), 'emph_attention')
 
+        split_tiles = None
+        if ('tiles', axis, 32) + select in meta:
+            split_tiles = meta[('tiles', axis, 32) + select]
         projected_ahead = False     # this layer's Q, K, V came out of the last block
         for layer in layers:
+            split = layer['block_split'] is not None and \
+                split_tiles is not None and block <= 32
+            images_written = False
             if projected_ahead:
                 pass
+            elif split:
+                packs, bias = layer['qkv_split']
+                tiles, size = split_tiles
+                with self._timed(f'qkv_projection_split_{tag}', 6. * channels *
+                                 channels * meta['positions'][axis]):
+                    if projected_images:
+                        runtime.check(self.lib.emph_qkv_projection_split_images(
+                            x.data_ptr(), ld, qk.data_ptr(),
+                            split_images.data_ptr(), channels, config.heads,
+                            packs.data_ptr(), self.linear_pieces,
+                            self.attention_pieces, bias.data_ptr(),
+                            tiles.data_ptr(), size // runtime.TILE_FIELDS, 32,
+                            runtime.stream()),
+                            'emph_qkv_projection_split_images')
+                        images_written = True
+                    else:
+                        runtime.check(self.lib.emph_qkv_projection_split(
+                            x.data_ptr(), ld, qk.data_ptr(), v.data_ptr(),
+                            channels, packs.data_ptr(), self.linear_pieces,
+                            bias.data_ptr(), tiles.data_ptr(),
+                            size // runtime.TILE_FIELDS, 32, runtime.stream()),
+                            'emph_qkv_projection_split')
             elif layer['qkv'] is not None and block <= 32:
                 packs, bias = layer['qkv']
                 tiles, size = meta[('tiles', axis, block) + select]
@@ -806,7 +868,19 @@ class Engine:
                            None, transpose_out=True)
             projected_ahead = False
             with self._timed(f'attention_{tag}', attention_flops):
-                attend()
+                attend(images_written)
+            if split:
+                packs, vectors = layer['block_split']
+                tiles, size = split_tiles
+                with self._timed(f'transformer_block_split_{tag}', 6. * channels *
+                                 channels * meta['positions'][axis]):
+                    runtime.check(self.lib.emph_transformer_block_split(
+                        attended.data_ptr(), x.data_ptr(), ld, channels,
+                        packs.data_ptr(), self.linear_pieces, vectors.data_ptr(),
+                        config.layer_norm_eps, runtime.ACTIVATIONS['relu'],
+                        tiles.data_ptr(), size // runtime.TILE_FIELDS, 32,
+                        runtime.stream()), 'emph_transformer_block_split')
+                continue
             if layer['block_qkv'] is not None and block <= 32 and self.fuse_qkv:
                 # (attention has consumed qk / v: the next layer's go there)
                 packs, vectors = layer['block_qkv']

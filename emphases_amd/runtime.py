@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -109,6 +109,17 @@ SIGNATURES = {
         _i32, _ptr, _ptr, _ptr]),
     'emph_qkv_projection': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i32, _ptr, _ptr, _ptr, _i32, _i32, _ptr]),
+    'emph_linear_split_pack_size': (_i64, [_i32]),
+    'emph_linear_split_pack': (_c.c_int, [_ptr, _i32, _ptr]),
+    'emph_transformer_block_split': (_c.c_int, [
+        _ptr, _ptr, _i64, _i32, _ptr, _i32, _ptr, _c.c_float, _i32, _ptr, _i32,
+        _i32, _ptr]),
+    'emph_qkv_projection_split': (_c.c_int, [
+        _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i32, _ptr, _ptr, _i32, _i32,
+        _ptr]),
+    'emph_qkv_projection_split_images': (_c.c_int, [
+        _ptr, _i64, _ptr, _ptr, _i32, _i32, _ptr, _i32, _i32, _ptr, _ptr,
+        _i32, _i32, _ptr]),
     'emph_prominence_workspace_floats': (
         _i64, [_i32, _i32, _i64, _i64, _i32]),
     'emph_prominence_forward': (_c.c_int, [
@@ -344,6 +355,19 @@ def conv_split_pack(weight):
     pack = np.zeros(lib.emph_conv_split_pack_size(), dtype=np.uint8)
     check(lib.emph_conv_split_pack(weight.ctypes.data, pack.ctypes.data),
           'emph_conv_split_pack')
+    return pack
+
+
+def linear_split_pack(weight, pieces=2):
+    """Pack of `pieces` bf16 pieces per weight (`emph_linear_split_pack`) of a
+    [80, 80] Linear weight (host, numpy uint8)."""
+    lib = library()
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    assert weight.shape == (80, 80)
+    pack = np.zeros(lib.emph_linear_split_pack_size(pieces), dtype=np.uint8)
+    check(lib.emph_linear_split_pack(weight.ctypes.data, pieces,
+                                     pack.ctypes.data),
+          'emph_linear_split_pack')
     return pack
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 25
+#define EMPH_ABI_VERSION 26
 
 /* Segment-table fields */
 enum {
@@ -699,6 +699,43 @@ int emph_qkv_projection(const float* x, int64_t ld, float* qk, float* v,
                         int32_t channels, const float* packs,
                         const float* bias, const int32_t* tiles,
                         int32_t n_tiles, int32_t tile_n, void* stream);
+
+/* emph_transformer_block and emph_qkv_projection on the bf16 matrix pipe
+ * (v_mfma_f32_32x32x16_bf16), every fp32 operand split into `pieces` bf16 pieces:
+ *   pieces 2  hi.hi + hi.lo + lo.hi, pieces rounded to nearest: 2^-16 per product
+ *   pieces 3  six products of exact (truncated) pieces: one fp32 rounding per product
+ * with fp32 accumulation; LayerNorm, bias, residual and ReLU in fp32.  The opt-in
+ * precisions 'bf16x3' / 'bf16x6' of the engine, never its default.  80 channels,
+ * tiles of 32 positions; the same transformer.py:18-23 arithmetic.
+ *   packs (block)  emph_linear_split_pack of out_proj.weight | linear1.weight |
+ *                  linear2.weight, back to back (device, 16-byte aligned)
+ *   packs (qkv)    emph_linear_split_pack of the q | k | v rows of in_proj_weight
+ *   vectors, bias, attended, x, qk, v, tiles: as the fp32 entries above */
+int64_t emph_linear_split_pack_size(int32_t pieces);
+int emph_linear_split_pack(const float* host_weight /* [80][80] */, int32_t pieces,
+                           void* host_pack);
+int emph_transformer_block_split(const float* attended, float* x, int64_t ld,
+                                 int32_t channels, const void* packs,
+                                 int32_t pieces, const float* vectors, float eps,
+                                 int32_t activation, const int32_t* tiles,
+                                 int32_t n_tiles, int32_t tile_n, void* stream);
+int emph_qkv_projection_split(const float* x, int64_t ld, float* qk, float* v,
+                              int32_t channels, const void* packs,
+                              int32_t pieces, const float* bias,
+                              const int32_t* tiles, int32_t n_tiles,
+                              int32_t tile_n, void* stream);
+/* ... with K and V written straight as the images emph_attention_split stages
+ * (what emph_split_kv would make of qk / v: no fp32 K and V, no second pass): Q
+ * into qk's first 80 rows (the K rows are left alone), `images` sized by
+ * emph_split_kv_bytes for `attention_pieces` (2, 3 or 32); two heads.  `tiles`
+ * (blocks of 32) must cover every segment whose images the attention will read. */
+int emph_qkv_projection_split_images(const float* x, int64_t ld, float* qk,
+                                     void* images, int32_t channels,
+                                     int32_t heads, const void* packs,
+                                     int32_t pieces, int32_t attention_pieces,
+                                     const float* bias, const int32_t* tiles,
+                                     int32_t n_tiles, int32_t tile_n,
+                                     void* stream);
 
 /* The word-rate Transformer decoder in ONE launch: positional encoding + all
  * `layers` post-LN encoder layers (transformer.py:13-52 as the word decoder,

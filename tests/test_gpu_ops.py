@@ -940,6 +940,182 @@ def test_qkv_projection(channels, tile):
     assert float(v[:batch.LEAD].min()) == 7.0
 
 
+@pytest.mark.parametrize('pieces,budget', [(2, 6e-5), (3, 5e-6)])
+def test_transformer_block_split(pieces, budget):
+    """emph_transformer_block_split (three / six bf16 products per fp32 product)
+    against a float64 reference, with the fp32 kernel's own error beside it."""
+    lib = runtime.library()
+    channels, tile = 80, 32
+    plan = ragged_plan([200, 1, 17, 33, 64, 31, 1000])
+    axis = runtime.AXIS_FRAMES
+    meta = Meta(plan, [(axis, tile)])
+    x = random_packed(channels, plan, axis, 21)
+    attended = random_packed(channels, plan, axis, 22)
+    x[:, :batch.LEAD] = float('nan')
+    names = ['out', 'l1', 'l2']
+    weight = {n: torch.from_numpy(synth.weights(30 + i, (channels, channels), 0.3))
+              for i, n in enumerate(names)}
+    order = ['b_o', 'g1', 'be1', 'b_1', 'b_2', 'g2', 'be2']
+    vector = {n: torch.from_numpy(synth.weights(40 + i, (channels,), 0.5))
+              for i, n in enumerate(order)}
+    vector['g1'] += 1.
+    vector['g2'] += 1.
+    split_packs = torch.from_numpy(np.concatenate([
+        runtime.linear_split_pack(weight[n].numpy(), pieces)
+        for n in names])).to(DEVICE)
+    plain_packs = torch.from_numpy(np.concatenate([
+        runtime.linear_chain_pack(weight['out'].numpy(), True),
+        runtime.linear_chain_pack(weight['l1'].numpy(), False),
+        runtime.linear_chain_pack(weight['l2'].numpy(), False)])).to(DEVICE)
+    vectors = torch.cat([vector[n] for n in order]).to(DEVICE)
+    x_dev, plain, attended_dev = x.to(DEVICE), x.to(DEVICE), attended.to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    runtime.check(lib.emph_transformer_block_split(
+        attended_dev.data_ptr(), x_dev.data_ptr(), plan.ld_frames, channels,
+        split_packs.data_ptr(), pieces, vectors.data_ptr(), 1e-5, 1,
+        tiles.data_ptr(), size // 4, tile, None),
+        'emph_transformer_block_split')
+    runtime.check(lib.emph_transformer_block(
+        attended_dev.data_ptr(), plain.data_ptr(), plan.ld_frames, channels,
+        plain_packs.data_ptr(), vectors.data_ptr(), 1e-5, 1, tiles.data_ptr(),
+        size // 4, tile, None), 'emph_transformer_block')
+    got, plain = x_dev.cpu(), plain.cpu()
+    norm = torch.nn.functional.layer_norm
+    wd = {n: w.double() for n, w in weight.items()}
+    vd = {n: w.double() for n, w in vector.items()}
+    worst = worst_plain = 0.
+    for off, count in spans(plan, axis):
+        xs = x[:, off:off + count].T.double()
+        a = attended[:, off:off + count].T.double()
+        y = norm(xs + a @ wd['out'].T + vd['b_o'], (channels,),
+                 vd['g1'], vd['be1'], 1e-5)
+        h = torch.relu(y @ wd['l1'].T + vd['b_1'])
+        want = norm(y + h @ wd['l2'].T + vd['b_2'], (channels,),
+                    vd['g2'], vd['be2'], 1e-5).T
+        worst = max(worst, float((got[:, off:off + count] - want).abs().max()))
+        worst_plain = max(worst_plain, float(
+            (plain[:, off:off + count] - want).abs().max()))
+    print(f'block, {pieces} pieces: {worst:.2e}  fp32 kernel {worst_plain:.2e}')
+    assert worst < budget
+    assert torch.isnan(got[:, :batch.LEAD]).all()   # padding untouched
+    # ... and untouched between the segments
+    keep = torch.ones(plan.ld_frames, dtype=torch.bool)
+    for off, count in spans(plan, axis):
+        keep[off:off + count] = False
+    keep[:batch.LEAD] = False
+    assert torch.equal(got[:, keep], x[:, keep])
+
+
+@pytest.mark.parametrize('pieces,budget', [(2, 4e-5), (3, 2e-6)])
+def test_qkv_projection_split(pieces, budget):
+    lib = runtime.library()
+    channels, tile = 80, 32
+    plan = ragged_plan([200, 1, 17, 33, 700])
+    axis = runtime.AXIS_FRAMES
+    meta = Meta(plan, [(axis, tile)])
+    x = random_packed(channels, plan, axis, 5)
+    weight = torch.from_numpy(synth.weights(6, (3 * channels, channels), 0.3))
+    bias = torch.from_numpy(synth.weights(7, (3 * channels,), 0.5))
+    packs = torch.from_numpy(np.concatenate([
+        runtime.linear_split_pack(
+            weight[part * channels:(part + 1) * channels].numpy(), pieces)
+        for part in range(3)])).to(DEVICE)
+    qk = torch.full((2 * channels, plan.ld_frames), 7.0, device=DEVICE)
+    v = torch.full((plan.ld_frames, channels), 7.0, device=DEVICE)
+    x_dev, bias_dev = x.to(DEVICE), bias.to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    runtime.check(lib.emph_qkv_projection_split(
+        x_dev.data_ptr(), plan.ld_frames, qk.data_ptr(), v.data_ptr(),
+        channels, packs.data_ptr(), pieces, bias_dev.data_ptr(),
+        tiles.data_ptr(), size // 4, tile, None), 'emph_qkv_projection_split')
+    qk, v = qk.cpu(), v.cpu()
+    worst = 0.
+    for off, count in spans(plan, axis):
+        want = weight.double() @ x[:, off:off + count].double() + \
+            bias.double()[:, None]
+        worst = max(worst, float((qk[:, off:off + count] -
+                                  want[:2 * channels]).abs().max()),
+                    float((v[off:off + count].T -
+                           want[2 * channels:]).abs().max()))
+    print(f'qkv, {pieces} pieces: {worst:.2e}')
+    assert worst < budget
+    assert float(qk[:, :batch.LEAD].min()) == 7.0
+    assert float(v[:batch.LEAD].min()) == 7.0
+
+
+@pytest.mark.parametrize('pieces,attention_pieces', [(2, 32), (3, 3), (2, 2)])
+def test_qkv_projection_split_images(pieces, attention_pieces):
+    """Q and the images of split keys and values straight out of the projection
+    kernel: what emph_split_kv makes of emph_qkv_projection_split's fp32 K and V
+    - the constant parts and the zeros behind every segment's end included."""
+    lib = runtime.library()
+    channels, heads, tile = 80, 2, 32
+    # (segments ending in the first and in the second half of a stage, at a
+    # stage's end, one shorter than a tile)
+    plan = ragged_plan([200, 1, 17, 33, 700, 64, 32, 96, 321])
+    axis = runtime.AXIS_FRAMES
+    meta = Meta(plan, [(axis, tile), (axis, 64)])
+    ld = plan.ld_frames
+    x = random_packed(channels, plan, axis, 5)
+    padding = torch.ones(ld, dtype=torch.bool)
+    for off, count in spans(plan, axis):
+        padding[off:off + count] = False
+    x[:, padding] = float('nan')        # (what lies between segments)
+    weight = torch.from_numpy(synth.weights(6, (3 * channels, channels), 0.3))
+    bias = torch.from_numpy(synth.weights(7, (3 * channels,), 0.5))
+    packs = torch.from_numpy(np.concatenate([
+        runtime.linear_split_pack(
+            weight[part * channels:(part + 1) * channels].numpy(), pieces)
+        for part in range(3)])).to(DEVICE)
+    x_dev, bias_dev = x.to(DEVICE), bias.to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    stage_tiles, stage_size = meta.view(('tiles', axis, 64))
+    image_bytes = lib.emph_split_kv_bytes(
+        ld, len(plan.segments), channels, heads, attention_pieces)
+    # the two-pass path
+    qk = torch.full((2 * channels, ld), 7.0, device=DEVICE)
+    v = torch.full((ld, channels), 7.0, device=DEVICE)
+    runtime.check(lib.emph_qkv_projection_split(
+        x_dev.data_ptr(), ld, qk.data_ptr(), v.data_ptr(), channels,
+        packs.data_ptr(), pieces, bias_dev.data_ptr(), tiles.data_ptr(),
+        size // 4, tile, None), 'emph_qkv_projection_split')
+    want = torch.full((image_bytes // 2,), 0x5555, dtype=torch.int16,
+                      device=DEVICE)
+    runtime.check(lib.emph_split_kv(
+        qk.data_ptr(), v.data_ptr(), ld, channels, heads,
+        stage_tiles.data_ptr(), stage_size // 4, 64, attention_pieces,
+        want.data_ptr(), None), 'emph_split_kv')
+    # ... and the one launch
+    q_only = torch.full((2 * channels, ld), 7.0, device=DEVICE)
+    got = torch.full((image_bytes // 2,), 0x5555, dtype=torch.int16,
+                     device=DEVICE)
+    runtime.check(lib.emph_qkv_projection_split_images(
+        x_dev.data_ptr(), ld, q_only.data_ptr(), got.data_ptr(), channels,
+        heads, packs.data_ptr(), pieces, attention_pieces,
+        bias_dev.data_ptr(), tiles.data_ptr(), size // 4, tile, None),
+        'emph_qkv_projection_split_images')
+    assert torch.equal(q_only[:channels], qk[:channels])
+    assert float(q_only[channels:].min()) == 7.0       # K's rows: not touched
+    same = torch.equal(got, want)
+    print('images bit for bit:', same)
+    if not same:
+        # the same pieces of values that differ in the last bit of an fp32
+        # sum (the V product runs with its operands swapped): decoded
+        pk, pv = {2: (2, 2), 3: (3, 3), 32: (3, 2)}[attention_pieces]
+        key_halfs, value_halfs = 6 * 64 * 8, 8 * 42 * 8
+
+        def decode(images):
+            bits = images.cpu().numpy().view(np.uint16).astype(np.uint32) << 16
+            stage = bits.view(np.float32).astype(np.float64).reshape(
+                -1, pk * key_halfs + pv * value_halfs)
+            keys = stage[:, :pk * key_halfs].reshape(-1, pk, key_halfs).sum(1)
+            values = stage[:, pk * key_halfs:].reshape(
+                -1, pv, value_halfs).sum(1)
+            return keys, values
+        for a, b in zip(decode(got), decode(want)):
+            assert np.abs(a - b).max() < 2e-6
+
+
 ###############################################################################
 # feature rows
 ###############################################################################

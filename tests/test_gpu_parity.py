@@ -408,10 +408,11 @@ def test_full_size_transformer_batch():
             assert np.abs(a.numpy() - want.numpy()).max() < SCORE_TOLERANCE
 
 
-@pytest.mark.parametrize('precision,budget', [('bf16x3', 1e-5), ('bf16x6', 3e-6)])
+@pytest.mark.parametrize('precision,budget', [
+    ('bf16x3', 1e-5), ('bf16x3_fast', 5e-5), ('bf16x6', 3e-6)])
 def test_split_precision_attention(variants, precision, budget):
-    """The opt-in split-bf16 attention (`precision=` of the engine; csrc/
-    attention_split.hip) on the reference's Transformer goldens and on
+    """The opt-in split-bf16 Transformer (`precision=` of the engine; csrc/
+    attention_split.hip, block_split.hip) on the reference's Transformer goldens and on
     BASELINE configs[2] utterances: the scores stay within `budget` of the
     f32 engine's and within the f32 tests' own bound of the reference's; the
     default stays f32."""
@@ -461,6 +462,42 @@ def test_split_precision_attention(variants, precision, budget):
     print(f'{precision}: worst |score - f32 engine| {worst:.2e} over '
           f'{sum(a.shape[1] for a in plain)} words; worst |score - '
           f'reference golden| {worst_reference:.2e}')
+    assert worst < budget
+
+
+@pytest.mark.parametrize('precision,budget', [
+    ('bf16x3', 1e-5), ('bf16x3_fast', 5e-5), ('bf16x6', 3e-6)])
+def test_split_precision_mixed_lengths(precision, budget):
+    """Short and long utterances in one batch: the long ones' keys and values
+    leave the projection kernel as split images only when EVERY segment is long
+    (then there is no fp32 K / V at all); a mixed batch takes emph_split_kv behind
+    fp32 projections.  Both routes, and a batch of one either way, give each
+    utterance the same scores to within the budget of the f32 engine's."""
+    config = cfg.Config(architecture='transformer')
+    state = weights.random_state(config, seed=0)
+    lengths = [1000, 50, 300, 127, 128, 700, 129]
+    audios = [torch.from_numpy(synth.audio(i, frames))
+              for i, frames in enumerate(lengths)]
+    aligns = [emphases_amd.Alignment.from_frames(synth.word_frames(i, frames))
+              for i, frames in enumerate(lengths)]
+    checkpoint = state_file(state)
+    plain = emphases_amd.from_alignments_and_audios(
+        aligns, audios, checkpoint=checkpoint, config=config)
+    mixed = emphases_amd.from_alignments_and_audios(
+        aligns, audios, checkpoint=checkpoint, config=config,
+        precision=precision)
+    long_only = [i for i, frames in enumerate(lengths) if frames >= 128]
+    images = emphases_amd.from_alignments_and_audios(
+        [aligns[i] for i in long_only], [audios[i] for i in long_only],
+        checkpoint=checkpoint, config=config, precision=precision)
+    worst = 0.
+    for a, b in zip(plain, mixed):
+        worst = max(worst, float((a - b).abs().max()))
+    for i, b in zip(long_only, images):
+        worst = max(worst, float((plain[i] - b).abs().max()))
+        # the two routes differ in nothing but who writes the images
+        assert torch.equal(mixed[i], b)
+    print(f'{precision}, mixed lengths: worst |score - f32 engine| {worst:.2e}')
     assert worst < budget
 
 

@@ -1211,6 +1211,46 @@ def test_conv_split_pack_is_two_bf16_pieces_in_fragment_order():
     assert np.array_equal(halves[tap, block, m, 0, lane], nearest[row, channels, tap])
 
 
+def test_linear_split_pack_pieces_in_chain_order():
+    """emph_linear_split_pack (host): a [80, 80] Linear weight as two (rounded) or
+    three (truncated: exact) bf16 pieces, [k-step][m-tile][piece][lane][8] with
+    lane = (output channel 32 m + lane % 32; input channels 16 j + 8 (e / 4) +
+    4 (lane / 32) + e % 4 - the order in which one GEMM's result lies in the
+    registers of the next); rows 80 .. 95 are zeros."""
+    from emphases_amd import runtime
+    lib = runtime.library()
+    weight = synth.weights(78, (80, 80), 0.3)
+    assert lib.emph_linear_split_pack_size(4) == 0
+    for pieces in (2, 3):
+        pack = runtime.linear_split_pack(weight, pieces)
+        assert pack.nbytes == lib.emph_linear_split_pack_size(pieces) == \
+            5 * 3 * pieces * 1024
+        halves = pack.view(np.uint16).reshape(5, 3, pieces, 64, 8)
+        values = (halves.astype(np.uint32) << 16).view(np.float32)
+        rebuilt = np.zeros((96, 80), dtype=np.float64)
+        e = np.arange(8)
+        for j in range(5):
+            for m in range(3):
+                for lane in range(64):
+                    channels = 16 * j + 8 * (e // 4) + 4 * (lane // 32) + e % 4
+                    rebuilt[32 * m + lane % 32, channels] = \
+                        values[j, m, :, lane].astype(np.float64).sum(0)
+        assert np.all(rebuilt[80:] == 0.)
+        error = np.abs(rebuilt[:80] - weight) / np.maximum(np.abs(weight), 1e-30)
+        if pieces == 3:
+            assert float(error.max()) == 0.         # 8 + 8 + 8 bits: all of fp32's
+            leading = (weight.view(np.uint32) >> 16).astype(np.uint16)
+        else:
+            assert float(error.max()) < 2.0 ** -16
+            bits = weight.view(np.uint32)
+            leading = ((bits + 0x7fff + ((bits >> 16) & 1)) >> 16).astype(
+                np.uint16)
+        lane, m, j = 37, 1, 3
+        channels = 16 * j + 8 * (e // 4) + 4 * (lane // 32) + e % 4
+        assert np.array_equal(halves[j, m, 0, lane],
+                              leading[32 * m + lane % 32, channels])
+
+
 def test_split_kv_scratch_sizes_and_piece_codes():
     from emphases_amd import runtime
     lib = runtime.library()
