@@ -1090,6 +1090,10 @@ def side_files_api(device, count=4096):
                      laps_wanted * count + min(count, 2048))
         emphases_amd.from_files_to_files(
             texts[warm], waves[warm], prefixes[warm], gpu=device.index)
+        # (the 24 000 files above are this function's own litter: collected now,
+        # not by a full collection of the interpreter inside the first lap)
+        import gc
+        gc.collect()
         laps = []
         for lap in range(laps_wanted):
             part = slice(lap * count, (lap + 1) * count)

@@ -119,65 +119,70 @@ def chunk_utterance(alignment, num_samples, batch_size=None, utterance=0):
     return segments
 
 
-def plan_batch(alignments, lengths, batch_size=None):
+def plan_batch(alignments, lengths, batch_size=None, tables=None):
     """`Plan` of a whole batch: utterance u has `lengths[u]` samples at offset
-    sum(lengths[:u]) of the packed audio.  One vectorised pass over all words
-    of all utterances when no utterance needs more than one chunk (the default
-    `batch_size=None`); the per-utterance planner otherwise."""
+    sum(lengths[:u]) of the packed audio.  One pass of the library over all
+    words of all utterances (`emph_plan_batch`) when no utterance needs more
+    than one chunk (the default `batch_size=None`); the per-utterance planner
+    otherwise.  `tables`: (times float64 [W, 2], counts int64 [U]) of the
+    alignments when the caller holds them as one table already
+    (`files.FileBatch`) - `alignments` is then only consulted on the slow path
+    (and may be a callable that builds the list)."""
     lengths = np.asarray(lengths, dtype=np.int64)
     offsets = np.cumsum(lengths) - lengths
-    slow = batch_size is not None or any(_foreign(a) for a in alignments)
-    if not slow and len(alignments):
-        tables = [a.times() if type(a) is alignment_module.Alignment else
-                  np.asarray(a, dtype=np.float64).reshape(-1, 2)
-                  if isinstance(a, (list, np.ndarray)) else _word_times(a)
-                  for a in alignments]
-        counts = np.array([len(t) for t in tables], dtype=np.int64)
-        keep = counts > 0
-        times = np.concatenate(tables) if counts.sum() else \
-            np.zeros((0, 2), dtype=np.float64)
-        starts, ends = times[:, 0], times[:, 1]
-        word_frames = convert.seconds_to_frames(ends - starts)
-        first = (np.cumsum(counts) - counts)[keep]
-        last = first + counts[keep] - 1
-        # one chunk holds the whole utterance unless the running frame count of
-        # its words (the last one never counts, core.py:369-381) passes the
-        # limit; the counts are whole numbers, so any summation order is exact
-        running = np.concatenate([[0.], np.cumsum(word_frames)])
-        padded = lengths[keep] + 2 * cfg.PADDING
-        limit = (padded / cfg.HOPSIZE).astype(np.int64)          # core.py:359
-        # the largest partial sum of an utterance is its last one (durations
-        # are not negative in a gap-free alignment; if they are, plan slowly)
-        slow = bool(np.any(
-            (running[last] - running[first]).astype(np.int64) > limit)) or \
-            bool(np.any(word_frames < 0))
-    if slow or not len(alignments):
-        segments = []
-        for index, (alignment, length) in enumerate(zip(alignments, lengths)):
-            segments.extend(
-                chunk_utterance(alignment, int(length), batch_size, index))
-        return Plan(segments, offsets, lengths)
-    start_frames = (starts * cfg.SAMPLE_RATE / cfg.HOPSIZE).astype(np.int64)
-    end_frames = (ends * cfg.SAMPLE_RATE / cfg.HOPSIZE).astype(np.int64)
-    start_sample = convert.seconds_to_frames(starts[first]).astype(np.int64) \
-        * cfg.HOPSIZE                                            # core.py:395
-    end_sample = convert.seconds_to_frames(ends[last]).astype(np.int64) \
-        * cfg.HOPSIZE                                            # core.py:398
-    start_sample = np.clip(start_sample, 0, padded)
-    end_sample = np.clip(end_sample, 0, padded)                  # slice clamps
-    length = np.maximum(0, end_sample - start_sample)
-    # reflect padding needs more than PADDING samples (mels.py:31-36)
-    alive = length > cfg.PADDING
-    utterance = np.nonzero(keep)[0][alive]
-    words = counts[keep][alive]
-    selected = np.repeat(alive, counts[keep])
-    origin = np.repeat(start_frames[first], counts[keep])
-    bounds = np.stack([start_frames, end_frames]) - origin
-    frames = 1 + (length + 2 * cfg.PADDING - cfg.NUM_FFT) // cfg.HOPSIZE
-    return Plan.from_columns(
-        utterance, np.zeros(len(utterance), dtype=np.int64),
-        start_sample[alive], length[alive], frames[alive], words,
-        bounds[:, selected], offsets, lengths)
+    slow = batch_size is not None
+    if not slow and tables is None:
+        slow = any(_foreign(a) for a in alignments)
+        if not slow and len(alignments):
+            rows = [a.times() if type(a) is alignment_module.Alignment else
+                    np.asarray(a, dtype=np.float64).reshape(-1, 2)
+                    if isinstance(a, (list, np.ndarray)) else _word_times(a)
+                    for a in alignments]
+            counts = np.array([len(t) for t in rows], dtype=np.int64)
+            tables = (np.concatenate(rows) if counts.sum() else
+                      np.zeros((0, 2), dtype=np.float64), counts)
+    if not slow and tables is not None and len(lengths):
+        columns = _plan_columns(tables[0], tables[1], lengths)
+        if columns is not None:
+            utterance, start_sample, length, frames, words, bounds = columns
+            return Plan.from_columns(
+                utterance, np.zeros(len(utterance), dtype=np.int64),
+                start_sample, length, frames, words, bounds, offsets, lengths)
+    if callable(alignments):
+        alignments = alignments()
+    segments = []
+    for index, (alignment, length) in enumerate(zip(alignments, lengths)):
+        segments.extend(
+            chunk_utterance(alignment, int(length), batch_size, index))
+    return Plan(segments, offsets, lengths)
+
+
+def _plan_columns(times, counts, lengths):
+    """`emph_plan_batch`: per-chunk columns (utterance, start_sample, length,
+    frames, words, bounds [2, words]) of a batch in which every utterance is
+    one chunk, or None when it has to be planned one utterance at a time
+    (tests/plan_reference.py holds the numpy restatement)."""
+    import ctypes
+    lib = runtime.library()
+    times = np.ascontiguousarray(times, dtype=np.float64)
+    counts = np.ascontiguousarray(counts, dtype=np.int64)
+    lengths = np.ascontiguousarray(lengths, dtype=np.int64)
+    count, total = len(counts), int(times.shape[0])
+    if int(counts.sum()) != total or len(lengths) != count:
+        raise ValueError('word tables and utterance counts disagree')
+    columns = np.empty((5, max(count, 1)), dtype=np.int64)
+    bounds = np.empty((2, max(total, 1)), dtype=np.int64)
+    segments, words = ctypes.c_int64(0), ctypes.c_int64(0)
+    status = lib.emph_plan_batch(
+        times.ctypes.data, counts.ctypes.data, lengths.ctypes.data, count,
+        cfg.SAMPLE_RATE, cfg.HOPSIZE, cfg.PADDING, cfg.NUM_FFT,
+        *[columns[row].ctypes.data for row in range(5)], bounds.ctypes.data,
+        bounds.shape[1], ctypes.byref(segments), ctypes.byref(words))
+    if status == 1:
+        return None
+    runtime.check(status, 'emph_plan_batch')
+    kept = columns[:, :segments.value]
+    return tuple(kept) + (bounds[:, :words.value],)
 
 
 def score_counts(alignments, lengths, batch_size=None):
@@ -407,37 +412,46 @@ class Plan:
             return cached
         if restarts is None:
             restarts = self.sum_restarts()
+        restarts = np.ascontiguousarray(restarts, dtype=np.int64)
+        views = {
+            'slot_map': np.empty(self.ld_frames, dtype=np.int32),
+            'first': np.empty(self.ld_words + 1, dtype=np.int32),
+            'lengths': np.empty(self.ld_words, dtype=np.int32),
+            # (two terms per part; a word has 1 + restarts-inside-it parts)
+            'terms': np.empty(4 * self.total_words + 2 * len(restarts) + 8,
+                              dtype=np.int32)}
+        count, slots = self._word_sums_into(restarts, views)
+        if count < 0:
+            views['terms'] = np.empty(-count, dtype=np.int32)
+            count, slots = self._word_sums_into(restarts, views)
+        tables = {
+            'slot_map': views['slot_map'], 'terms': views['terms'][:count].copy(),
+            'first': views['first'], 'lengths': views['lengths'],
+            'n_slots': slots}
+        self._tiles[key] = tables
+        return tables
+
+    def _word_sums_into(self, restarts, views):
+        """`emph_plan_word_sums` into the int32 arrays `views` (slot_map
+        [ld_frames], first [ld_words + 1], lengths [ld_words], terms);
+        returns (terms, slots), terms = -(needed) when `terms` is too small."""
         import ctypes
         lib = runtime.library()
-        restarts = np.ascontiguousarray(restarts, dtype=np.int64)
         frames = np.ascontiguousarray(self.frames, dtype=np.int64)
         frame_off = np.ascontiguousarray(self.frame_off, dtype=np.int64)
         words = np.ascontiguousarray(self.words, dtype=np.int64)
         columns = np.ascontiguousarray(self._columns, dtype=np.int64)
         bounds = np.ascontiguousarray(self.segment_bounds, dtype=np.int64)
-        slot_map = np.empty(self.ld_frames, dtype=np.int32)
-        first = np.empty(self.ld_words + 1, dtype=np.int32)
-        lengths = np.empty(self.ld_words, dtype=np.int32)
-        # (two terms per part; a word has 1 + restarts-inside-it parts)
-        terms = np.empty(4 * self.total_words + 2 * len(restarts) + 8,
-                         dtype=np.int32)
         slots = ctypes.c_int32(0)
-        for _ in range(2):
-            count = lib.emph_plan_word_sums(
-                frames.ctypes.data, frame_off.ctypes.data, words.ctypes.data,
-                len(frames), columns.ctypes.data, bounds.ctypes.data,
-                self.total_words, restarts.ctypes.data, len(restarts),
-                self.ld_frames, self.ld_words, slot_map.ctypes.data,
-                first.ctypes.data, lengths.ctypes.data, terms.ctypes.data,
-                terms.size, ctypes.byref(slots))
-            if count >= 0:
-                break
-            terms = np.empty(-count, dtype=np.int32)
-        tables = {
-            'slot_map': slot_map, 'terms': terms[:count].copy(),
-            'first': first, 'lengths': lengths, 'n_slots': int(slots.value)}
-        self._tiles[key] = tables
-        return tables
+        terms = views['terms']
+        count = lib.emph_plan_word_sums(
+            frames.ctypes.data, frame_off.ctypes.data, words.ctypes.data,
+            len(frames), columns.ctypes.data, bounds.ctypes.data,
+            self.total_words, restarts.ctypes.data, len(restarts),
+            self.ld_frames, self.ld_words, views['slot_map'].ctypes.data,
+            views['first'].ctypes.data, views['lengths'].ctypes.data,
+            terms.ctypes.data, terms.size, ctypes.byref(slots))
+        return int(count), int(slots.value)
 
     def pieces(self, method):
         """Layout for DOWNSAMPLE_LOCATION = 'input' (`model/core.py:41-87`,
@@ -452,37 +466,74 @@ class Plan:
         """Packed word-axis column of every word, in segment order."""
         return self._columns
 
+    def stack_restarts(self, step=64):
+        """`sum_restarts` of the plan's own span table (kept: the packer and the
+        engine both ask)."""
+        key = ('stack_restarts', step)
+        if key not in self._tiles:
+            self._tiles[key] = np.ascontiguousarray(
+                self.sum_restarts(self.conv_spans(), step=step), dtype=np.int64)
+        return self._tiles[key]
+
     def pack_metadata(self, tile_requests, word_sums=False, spans=False,
-                      sum_step=64):
+                      sum_step=64, _capacity=None):
         """All integer metadata as one int32 array plus the element offset of
         every piece (the int64 table first, so it stays 8-byte aligned;
         every piece starts on a 16-byte boundary).  `word_sums`: with the
         tables of `word_sum_tables()`; `spans`: with the span table of
-        `emph_conv1d_stack`, whose restarts the word sums then follow."""
+        `emph_conv1d_stack`, whose restarts the word sums then follow.
+        The word-sum tables - a row per packed frame column among them, the
+        largest piece by far - are built by the library straight into the
+        array (the terms, whose number is known afterwards, at its end)."""
         pieces = [('table', self.table.view(np.int32).ravel()),
                   ('bounds', self.bounds.ravel()),
                   ('word_segment', self.word_segment)]
         if spans:
             pieces.append(('conv_spans', self.conv_spans().ravel()))
-        if word_sums:
-            tables = self.word_sum_tables(
-                self.sum_restarts(self.conv_spans(), step=sum_step)
-                if spans else None)
-            pieces += [(('word_sums', name), tables[name])
-                       for name in ('slot_map', 'terms', 'first', 'lengths')]
         for request in tile_requests:
             pieces.append(
                 (('tiles',) + tuple(request), self.tiles(*request).ravel()))
-        # one output array, every piece copied once, 16-byte aligned starts
+        restarts = None
+        if word_sums:
+            restarts = self.stack_restarts(sum_step) if spans else \
+                np.ascontiguousarray(self.sum_restarts(), dtype=np.int64)
+            # (two terms per part; a word has 1 + restarts-inside-it parts)
+            capacity = _capacity or \
+                4 * self.total_words + 2 * len(restarts) + 8
+            pieces += [(('word_sums', 'slot_map'), self.ld_frames),
+                       (('word_sums', 'first'), self.ld_words + 1),
+                       (('word_sums', 'lengths'), self.ld_words),
+                       (('word_sums', 'terms'), capacity)]
+        # one output array, every piece copied (or built) once, 16-byte
+        # aligned starts
         offsets = {}
         cursor = 0
         for name, array in pieces:
-            offsets[name] = (cursor, array.size)
-            cursor += _round_up(max(array.size, 1), 4)
-        packed = np.zeros(cursor, dtype=np.int32)
+            size = array if isinstance(array, int) else array.size
+            offsets[name] = (cursor, size)
+            cursor += _round_up(max(size, 1), 4)
+        packed = np.empty(cursor, dtype=np.int32)
         for name, array in pieces:
             start, size = offsets[name]
-            packed[start:start + size] = array
+            if not isinstance(array, int):
+                packed[start:start + size] = array
+            packed[start + size:start + _round_up(max(size, 1), 4)] = 0
+        if word_sums:
+            views = {name: packed[offsets[('word_sums', name)][0]:][
+                :offsets[('word_sums', name)][1]]
+                for name in ('slot_map', 'first', 'lengths', 'terms')}
+            count, slots = self._word_sums_into(restarts, views)
+            if count < 0:       # (words that overlap: more parts than words)
+                return self.pack_metadata(
+                    tile_requests, word_sums, spans, sum_step, -count)
+            start, _ = offsets[('word_sums', 'terms')]
+            offsets[('word_sums', 'terms')] = (start, count)
+            packed = packed[:start + _round_up(max(count, 1), 4)]
+            packed[start + count:] = 0
+            self._tiles[('word_sums', restarts.tobytes())] = {
+                'slot_map': views['slot_map'], 'terms': packed[start:start + count],
+                'first': views['first'], 'lengths': views['lengths'],
+                'n_slots': slots}
         return packed, offsets
 
 

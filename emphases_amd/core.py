@@ -216,7 +216,7 @@ def from_file_to_file(text_file, audio_file, output_prefix=None,
 
 
 def files_to_scores(text_files, audio_files, session, batch_size=None,
-                    utterances_per_batch=512, deliver=None,
+                    utterances_per_batch=256, deliver=None,
                     deliver_batch=None):
     """The loop of `core.py:169-179` over ragged batches of
     `utterances_per_batch` files, two batches in flight.  A batch of files is
@@ -284,9 +284,6 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
             text_files[first:last], audio_files[first:last], open_threads)
         _stamp('open.parse', turn, start)
         begin = time.perf_counter_ns()
-        # (word-time tables, not alignment objects: nothing per file for the
-        # interpreter's collector to trace; `deliver` builds what it asks for)
-        alignments = opened.all_times()
         loaded = opened.all_audios()
         _stamp('open.objects', turn, begin)
         begin = time.perf_counter_ns()
@@ -296,7 +293,22 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
         _stamp('open.read', turn, begin)
         begin = time.perf_counter_ns()
         groups = []
-        for rate in sorted({rate for _, rate in loaded}):
+        rates = sorted({rate for _, rate in loaded})
+        if rates == [cfg.SAMPLE_RATE] and not opened.status.any() and \
+                bool(opened.native_audio().all()):
+            # every file read by the library, 16 kHz mono: the plan from the
+            # library's own table of word times (nothing per file here)
+            audios = [audio for audio, _ in loaded]
+            plan = engine.prepare(batch.plan_batch(
+                opened.all_times, opened.sizes[:, 10] // (opened.sizes[:, 8] // 8),
+                batch_size, tables=(opened.times, opened.sizes[:, 1])))
+            groups.append((cfg.SAMPLE_RATE, list(range(opened.count)), (),
+                           audios, plan))
+            rates = []
+        # (word-time tables, not alignment objects: nothing per file for the
+        # interpreter's collector to trace; `deliver` builds what it asks for)
+        alignments = opened.all_times() if rates else None
+        for rate in rates:
             chosen = [i for i, (_, r) in enumerate(loaded) if r == rate]
             picked = [alignments[i] for i in chosen]
             audios = [loaded[i][0] for i in chosen]
@@ -382,7 +394,7 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
 
 def from_files_to_files(text_files, audio_files, output_prefixes=None,
                         checkpoint=None, batch_size=None, gpu=None,
-                        utterances_per_batch=512, conv_tile=None):
+                        utterances_per_batch=256, conv_tile=None):
     """`core.py:115-179`, but the files are processed in ragged batches of
     `utterances_per_batch` instead of one at a time, two batches in flight,
     read, parsed and written by the library's host threads

@@ -1175,6 +1175,21 @@ int emph_files_write(const emph_file_batch* batch, const int32_t* which,
 // largest piece of host time of a call that brings a layout never seen before)
 // ---------------------------------------------------------------------------
 
+namespace {
+
+// Python's (and numpy's) float floor division a // b for b > 0 and quotients below
+// 2^52: the interpreter derives it from fmod (floatobject.c, float_divmod) and arrives
+// at the exact floor of the exact quotient.  So does this, without the fmod: a / b
+// rounded can only land ON the integer above the exact quotient, never beyond it, and
+// the sign of the fused a - q b says when it did.
+double plan_floor_divide(double a, double b) {
+    double quotient = floor(a / b);
+    if (fma(-quotient, b, a) < 0.0) quotient -= 1.0;
+    return quotient;
+}
+
+}  // namespace
+
 extern "C" {
 
 // Tile table int32 [n][4] = (segment, first position, segment's first column,
@@ -1199,6 +1214,76 @@ int64_t emph_plan_tiles(const int64_t* host_counts, const int64_t* host_offsets,
         }
     }
     return rows;
+}
+
+// The chunk of every utterance of a batch when no utterance needs more than one
+// (batch.plan_batch's vectorised pass; emphases/core.py:345-418 with the default
+// batch_size=None): utterance u has counts[u] words whose (start, end) seconds are the
+// next counts[u] rows of `times`, and lengths[u] samples.  Same float64 operations in
+// the same order as the numpy code (and the reference's Python floats).
+// Outputs, one row per utterance that yields a chunk (n_segments of them): utterance,
+// start_sample, length, frames, words; bounds int64 [2][capacity >= sum(counts)]: the
+// first *n_words columns are the chunk-relative (start, end) frames of those chunks'
+// words.  Returns 0, or 1 when the batch must be planned one utterance at a time (an
+// utterance that needs several chunks, a negative duration, a time that is not finite).
+int emph_plan_batch(const double* times, const int64_t* counts, const int64_t* lengths,
+                    int32_t n_utterances, int64_t sample_rate, int64_t hopsize,
+                    int64_t padding, int64_t num_fft, int64_t* utterance,
+                    int64_t* start_sample, int64_t* length, int64_t* frames, int64_t* words,
+                    int64_t* bounds, int64_t capacity, int64_t* n_segments,
+                    int64_t* n_words) {
+    EMPH_REQUIRE(counts && lengths && utterance && start_sample && length && frames && words &&
+                     bounds && n_segments && n_words,
+                 EMPH_EINVAL, "emph_plan_batch: null pointer");
+    const double rate = static_cast<double>(sample_rate), hop = static_cast<double>(hopsize);
+    int64_t total = 0;
+    for (int32_t u = 0; u < n_utterances; ++u) total += counts[u];
+    EMPH_REQUIRE(total == 0 || times, EMPH_EINVAL, "emph_plan_batch: null pointer");
+    EMPH_REQUIRE(capacity >= total, EMPH_ERANGE, "emph_plan_batch: bounds hold %lld of %lld words",
+                 static_cast<long long>(capacity), static_cast<long long>(total));
+    int64_t segments = 0, kept = 0, word = 0;
+    for (int32_t u = 0; u < n_utterances; word += counts[u], ++u) {
+        const int64_t count = counts[u];
+        if (count <= 0) continue;
+        const double* rows = times + 2 * word;
+        // the running frame count of the words in front of the last one against the
+        // frames of the padded audio (core.py:359,369-381)
+        double running = 0.0;
+        for (int64_t w = 0; w < count; ++w) {
+            const double start = rows[2 * w], end = rows[2 * w + 1];
+            if (!std::isfinite(start) || !std::isfinite(end)) return 1;
+            const double duration = plan_floor_divide((end - start) * rate, hop);
+            if (duration < 0.0) return 1;
+            if (w + 1 < count) running += duration;
+        }
+        const int64_t padded = lengths[u] + 2 * padding;
+        const int64_t limit = static_cast<int64_t>(static_cast<double>(padded) / hop);
+        if (static_cast<int64_t>(running) > limit) return 1;
+        int64_t first_sample =
+            static_cast<int64_t>(plan_floor_divide(rows[0] * rate, hop)) * hopsize;      // core.py:395
+        int64_t last_sample =
+            static_cast<int64_t>(plan_floor_divide(rows[2 * count - 1] * rate, hop)) * hopsize;
+        first_sample = std::min(std::max<int64_t>(first_sample, 0), padded);             // (slices clamp)
+        last_sample = std::min(std::max<int64_t>(last_sample, 0), padded);
+        const int64_t samples = std::max<int64_t>(0, last_sample - first_sample);
+        if (samples <= padding) continue;         // reflect padding needs more (mels.py:31-36)
+        const int64_t origin = static_cast<int64_t>(rows[0] * rate / hop);
+        for (int64_t w = 0; w < count; ++w) {
+            bounds[kept + w] = static_cast<int64_t>(rows[2 * w] * rate / hop) - origin;
+            bounds[capacity + kept + w] = static_cast<int64_t>(rows[2 * w + 1] * rate / hop) - origin;
+        }
+        utterance[segments] = u;
+        start_sample[segments] = first_sample;
+        length[segments] = samples;
+        // (floor division of a value that is positive here: samples > padding)
+        frames[segments] = 1 + (samples + 2 * padding - num_fft) / hopsize;
+        words[segments] = count;
+        kept += count;
+        ++segments;
+    }
+    *n_segments = segments;
+    *n_words = kept;
+    return 0;
 }
 
 // The tables of the folded per-word sum (batch.Plan.word_sum_tables):

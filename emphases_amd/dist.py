@@ -315,7 +315,7 @@ def from_alignments_and_audios(alignments, audios, sample_rate=16000,
 
 def from_files_to_files(text_files, audio_files, output_prefixes=None,
                         checkpoint=None, batch_size=None, config=None,
-                        group=None, utterances_per_batch=512,
+                        group=None, utterances_per_batch=256,
                         conv_tile=CONV_TILE, gather=True, compute=None):
     """`emphases.from_files_to_files` (`core.py:115-179`) over the ranks of a
     process group, one process per GPU.  No rank reads what it does not

@@ -529,14 +529,14 @@ class Engine:
             views[name] = (device_buffer[start:start + size], size)
         if fold:
             views['n_slots'] = plan.word_sum_tables(
-                plan.sum_restarts(plan.conv_spans(), step=self.sum_step)
+                plan.stack_restarts(self.sum_step)
                 if stack else None)['n_slots']
             views['word_sum_tables'] = runtime.WordSumTables(
                 *[views[('word_sums', name)][0].data_ptr() for name in (
                     'slot_map', 'terms', 'first', 'lengths')],
                 views['n_slots'])
         if self.config.downsample_location == 'input' and not nested and \
-                len(plan.segments):
+                len(plan):
             # every word is its own padded sequence: a second packed layout
             pieces = plan.pieces(self.config.downsample_method)
             piece_meta = self.upload(
@@ -692,7 +692,7 @@ class Engine:
         peak = None
         if config.loudness_feature:
             peak = torch.zeros(
-                len(plan.segments), dtype=torch.float32, device=self.device)
+                len(plan), dtype=torch.float32, device=self.device)
             with self._timed('frontend_peak'):
                 runtime.check(self.lib.emph_frontend_peak(
                     audio.data_ptr(), audio_format(audio), table.data_ptr(),
@@ -778,7 +778,7 @@ class Engine:
         if self.attention_pieces and config.channels // config.heads == 40 and \
                 any(tile_n == ATTENTION_GROUP for _, _, tile_n in launches):
             size = int(self.lib.emph_split_kv_bytes(
-                ld, len(plan.segments), channels, config.heads,
+                ld, len(plan), channels, config.heads,
                 self.attention_pieces))
             key = (tag + '_split_kv', (size,))
             split_images = self._workspace.get(key)
@@ -1080,7 +1080,7 @@ class Engine:
         if self.model is not None and stages is None and features is None \
                 and self.timers is None and not self.split_conv and \
                 block in ((64,) if self.quad else (32, 64)) and \
-                len(plan.segments):
+                len(plan):
             # the whole path behind one C call
             check_bounds(plan, config.downsample_method)
             logits = self._buffer('logits', ld_w)
@@ -1131,7 +1131,7 @@ class Engine:
                 runtime.check(self.lib.emph_gather_columns(
                     features.data_ptr(), ld_f, gathered.data_ptr(), ld_p,
                     config.num_features, piece_meta['gather'].data_ptr(),
-                    len(piece_plan.segments), runtime.stream()),
+                    len(piece_plan), runtime.stream()),
                     'emph_gather_columns')
             a = self._buffer('frames_a', channels, ld_p)
             b = self._buffer('frames_b', channels, ld_p)
@@ -1239,7 +1239,7 @@ class Engine:
         layers by emph_conv1d_stack, per-word sums folded, one-launch decoder)."""
         return (self.config.downsample_location != 'input' and
                 'conv_spans' in meta and 'word_sum_tables' in meta and
-                self.fused_words and len(plan.segments) > 0)
+                self.fused_words and len(plan) > 0)
 
     def forward_frames(self, audio, plan, meta):
         """The frame-rate half of forward(): features and the frame-rate layers,

@@ -305,13 +305,18 @@ class FileBatch:
         self.staging = staging
         return int(where[-1])
 
-    def audio_bytes(self):
-        """Bytes `read_all` needs (every file's samples, 4-byte aligned)."""
+    def native_audio(self):
+        """bool [count]: files whose samples the library reads itself (mono
+        16-bit PCM or float32; `all_audios` gives a `FileAudio` for them)."""
         sizes = self.sizes
-        native = ((sizes[:, 0] & 2) == 0) & (sizes[:, 6] == 1) & (
+        return ((sizes[:, 0] & 2) == 0) & (sizes[:, 6] == 1) & (
             ((sizes[:, 5] == 1) & (sizes[:, 8] == 16)) |
             ((sizes[:, 5] == 3) & (sizes[:, 8] == 32)))
-        return int(((sizes[native, 10] + 3) // 4 * 4).sum())
+
+    def audio_bytes(self):
+        """Bytes `read_all` needs (every file's samples, 4-byte aligned)."""
+        native = self.native_audio()
+        return int(((self.sizes[native, 10] + 3) // 4 * 4).sum())
 
     def read(self, indices, where, nbytes, destination):
         """Samples of files `indices` to host address `destination +

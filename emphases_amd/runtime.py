@@ -137,6 +137,9 @@ SIGNATURES = {
     'emph_files_write': (_c.c_int, [
         _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _i32]),
     'emph_plan_tiles': (_i64, [_ptr, _ptr, _i32, _i32, _i64, _i64, _ptr]),
+    'emph_plan_batch': (_c.c_int, [
+        _ptr, _ptr, _ptr, _i32, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr,
+        _ptr, _ptr, _i64, _ptr, _ptr]),
     'emph_plan_word_sums': (_i64, [
         _ptr, _ptr, _ptr, _i32, _ptr, _ptr, _i64, _ptr, _i64, _i64, _i64,
         _ptr, _ptr, _ptr, _ptr, _i64, _ptr]),

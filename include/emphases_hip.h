@@ -185,6 +185,24 @@ int emph_files_write(const emph_file_batch* batch, const int32_t* which,
 int64_t emph_plan_tiles(const int64_t* host_counts, const int64_t* host_offsets,
                         int32_t n_segments, int32_t block, int64_t least,
                         int64_t most, int32_t* host_tiles);
+/* emph_plan_batch: the chunk of every utterance of a batch when none needs more
+ * than one - emphases.preprocess (emphases/core.py:345-418) with the default
+ * batch_size=None, the reference's float64 operations in the reference's order.
+ * Utterance u: counts[u] words, whose (start, end) seconds are the next counts[u]
+ * rows of `times`, and lengths[u] samples at `sample_rate`.  One output row per
+ * utterance that yields a chunk (*n_segments; core.py:414-415 drops the others):
+ * utterance, start_sample, length, frames, words; bounds int64 [2][capacity]
+ * (capacity >= sum(counts)): the first *n_words columns are those chunks' words'
+ * chunk-relative (start, end) frames.  Returns 0; 1 when the batch has to be
+ * planned one utterance at a time (several chunks, a negative duration, a time
+ * that is not finite: nothing is written then); < 0 on bad arguments. */
+int emph_plan_batch(const double* times, const int64_t* counts,
+                    const int64_t* lengths, int32_t n_utterances,
+                    int64_t sample_rate, int64_t hopsize, int64_t padding,
+                    int64_t num_fft, int64_t* utterance, int64_t* start_sample,
+                    int64_t* length, int64_t* frames, int64_t* words,
+                    int64_t* bounds, int64_t capacity, int64_t* n_segments,
+                    int64_t* n_words);
 int64_t emph_plan_word_sums(const int64_t* frames, const int64_t* frame_off,
                             const int64_t* words, int32_t n_segments,
                             const int64_t* word_columns, const int64_t* bounds,

@@ -1,5 +1,5 @@
 """numpy restatements of the plan tables the library builds on the host
-(`emph_plan_tiles`, `emph_plan_word_sums`): TEST INFRASTRUCTURE - the product
+(`emph_plan_batch`, `emph_plan_tiles`, `emph_plan_word_sums`): TEST INFRASTRUCTURE - the product
 (`emphases_amd/batch.py`) calls the library; tests/test_host.py holds the two
 against each other bit for bit."""
 import numpy as np
@@ -76,3 +76,49 @@ def word_sum_tables(plan, restarts):
         'first': np.cumsum(per_column).astype(np.int32),
         'lengths': lengths, 'n_slots': int(len(marked))}
     return tables
+
+
+def plan_columns(times, counts, lengths):
+    """`emph_plan_batch` with numpy (`emphases/core.py:345-418` for batches in
+    which every utterance is one chunk; the vectorised pass `batch.plan_batch`
+    made before the library took it over): (utterance, start_sample, length,
+    frames, words, bounds [2, words]) or None for "plan slowly"."""
+    from emphases_amd import config as cfg
+    from emphases_amd import convert
+    times = np.asarray(times, dtype=np.float64).reshape(-1, 2)
+    counts = np.asarray(counts, dtype=np.int64)
+    lengths = np.asarray(lengths, dtype=np.int64)
+    keep = counts > 0
+    starts, ends = times[:, 0], times[:, 1]
+    if not np.all(np.isfinite(times)):
+        return None
+    word_frames = convert.seconds_to_frames(ends - starts)
+    first = (np.cumsum(counts) - counts)[keep]
+    last = first + counts[keep] - 1
+    # one chunk holds the whole utterance unless the running frame count of
+    # its words (the last one never counts, core.py:369-381) passes the limit
+    running = np.concatenate([[0.], np.cumsum(word_frames)])
+    padded = lengths[keep] + 2 * cfg.PADDING
+    limit = (padded / cfg.HOPSIZE).astype(np.int64)          # core.py:359
+    if np.any((running[last] - running[first]).astype(np.int64) > limit) or \
+            np.any(word_frames < 0):
+        return None
+    start_frames = (starts * cfg.SAMPLE_RATE / cfg.HOPSIZE).astype(np.int64)
+    end_frames = (ends * cfg.SAMPLE_RATE / cfg.HOPSIZE).astype(np.int64)
+    start_sample = convert.seconds_to_frames(starts[first]).astype(np.int64) \
+        * cfg.HOPSIZE                                            # core.py:395
+    end_sample = convert.seconds_to_frames(ends[last]).astype(np.int64) \
+        * cfg.HOPSIZE                                            # core.py:398
+    start_sample = np.clip(start_sample, 0, padded)
+    end_sample = np.clip(end_sample, 0, padded)                  # slice clamps
+    length = np.maximum(0, end_sample - start_sample)
+    # reflect padding needs more than PADDING samples (mels.py:31-36)
+    alive = length > cfg.PADDING
+    utterance = np.nonzero(keep)[0][alive]
+    words = counts[keep][alive]
+    selected = np.repeat(alive, counts[keep])
+    origin = np.repeat(start_frames[first], counts[keep])
+    bounds = np.stack([start_frames, end_frames]) - origin
+    frames = 1 + (length + 2 * cfg.PADDING - cfg.NUM_FFT) // cfg.HOPSIZE
+    return (utterance, start_sample[alive], length[alive], frames[alive],
+            words, bounds[:, selected])

@@ -1050,6 +1050,91 @@ def test_plan_tables_of_the_library_match_numpy():
     assert empty.word_sum_tables()['n_slots'] == 0
 
 
+def test_plan_batch_of_the_library_matches_numpy_and_the_chunker():
+    """emph_plan_batch (the chunk of every utterance of a batch, in the library)
+    against the numpy restatement in tests/plan_reference.py bit for bit, and
+    `batch.plan_batch` over it against the per-utterance chunker
+    (`chunk_utterance`, emphases/core.py:345-418): word times on and around the
+    hop grid (where x // 160 and floor(x / 160) part ways), empty alignments,
+    utterances too short for a chunk, words past the audio's end, gaps and
+    overlaps; "plan slowly" for several chunks, negative durations, NaN."""
+    import plan_reference
+    rng = np.random.default_rng(5)
+    tables, lengths = [], []
+    for index in range(300):
+        count = int(rng.integers(0, 40)) if index % 17 else 0
+        kind = index % 5
+        if kind == 0:       # a multiple of the hop, plus or minus an ulp
+            edges = np.sort(rng.integers(0, 1500, size=count + 1)) * 0.01
+            edges = np.nextafter(edges, rng.choice([-np.inf, np.inf], size=edges.shape))
+        elif kind == 1:     # the decimal times of a TextGrid
+            edges = np.round(np.sort(rng.uniform(0, 12, size=count + 1)), 2)
+        elif kind == 2:     # exactly on the hop grid
+            edges = np.sort(rng.integers(0, 1200, size=count + 1)) * 0.01
+        else:
+            edges = np.sort(rng.uniform(0, 10, size=count + 1))
+        times = np.stack([edges[:-1], edges[1:]], axis=1) if count else \
+            np.zeros((0, 2))
+        if kind == 3 and count > 2:     # a gap and an overlap
+            times[1, 1] -= min(0.004, (times[1, 1] - times[1, 0]) / 2)
+            times[2, 0] -= 0.008
+        if kind == 4 and count:         # too short for a chunk
+            times = times * 0.002
+        if kind == 2 and count:         # the last word runs past the audio
+            times[-1, 1] += 3.0
+        tables.append(np.ascontiguousarray(times, dtype=np.float64))
+        end = float(edges[-1]) * (0.002 if kind == 4 else 1.)
+        lengths.append(int(end * 16000) + int(rng.choice([0, 1, 159, 160, 433, 5000])))
+    lengths = np.array(lengths, dtype=np.int64)
+    counts = np.array([len(t) for t in tables], dtype=np.int64)
+    table = np.concatenate(tables)
+    want = plan_reference.plan_columns(table, counts, lengths)
+    got = batch._plan_columns(table, counts, lengths)
+    assert want is not None and got is not None
+    assert len(want[0]) > 200
+    for a, b in zip(got, want):
+        assert a.dtype == np.int64 and np.array_equal(a, b)
+    # the Plan over it is the Plan of the per-utterance chunker
+    fast = batch.plan_batch(tables, lengths)
+    also = batch.plan_batch(None, lengths, tables=(table, counts))
+    segments = []
+    for index, (times, length) in enumerate(zip(tables, lengths)):
+        segments.extend(batch.chunk_utterance(times, int(length), None, index))
+    slow = batch.Plan(segments, np.cumsum(lengths) - lengths, lengths)
+    for plan in (fast, also):
+        for name in ('utterance', 'start_word', 'frames', 'words', 'frame_off',
+                     'word_off', 'table', 'bounds', 'word_segment',
+                     'segment_bounds'):
+            assert np.array_equal(getattr(plan, name), getattr(slow, name)), name
+        assert (plan.ld_frames, plan.ld_words) == (slow.ld_frames, slow.ld_words)
+    # what the one pass must hand back to the chunker
+    for spoil in ('chunks', 'negative', 'nan'):
+        changed = [t.copy() for t in tables]
+        big = int(np.argmax(counts))
+        if spoil == 'chunks':       # words that outlast the audio's frames
+            changed[big][:, 1] += 30.0
+            changed[big][1:, 0] += 30.0
+        elif spoil == 'negative':
+            changed[big][3, 1] = changed[big][3, 0] - 0.5
+        else:
+            changed[big][2, 0] = np.nan
+        spoiled = np.concatenate(changed)
+        assert batch._plan_columns(spoiled, counts, lengths) is None
+        assert plan_reference.plan_columns(spoiled, counts, lengths) is None
+    with pytest.raises(ValueError, match='disagree'):
+        batch._plan_columns(table[:-1], counts, lengths)
+    # ... and pack_metadata's tables built in place are word_sum_tables' own
+    packed, offsets = fast.pack_metadata(
+        [(0, 64)], word_sums=True, spans=True, sum_step=32)
+    fresh = batch.plan_batch(tables, lengths)
+    alone = fresh.word_sum_tables(fresh.stack_restarts(32))
+    for name in ('slot_map', 'terms', 'first', 'lengths'):
+        start, size = offsets[('word_sums', name)]
+        assert np.array_equal(packed[start:start + size], alone[name]), name
+    assert packed.size == sum(
+        -(-max(size, 1) // 4) * 4 for _, size in offsets.values())
+
+
 def test_hand_scheduled_loads_are_not_touched_in_flight():
     """conv_stack.hip's loader waves issue their row loads from inline asm and wait with
     explicit s_waitcnt; hipcc does not know those registers are still being written.  The

@@ -17,7 +17,7 @@ from emphases_amd import load, synth  # noqa: E402
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     # (utterances_per_batch, threads of an open call, threads of a write call)
-    sizes = ((512, 8, 4), (512, 12, 4), (1024, 8, 4), (384, 8, 4))
+    sizes = ((512, 8, 4), (512, 6, 4), (1024, 8, 4), (384, 8, 4), (256, 8, 4))
     laps_per_size = 4
     directory = tempfile.mkdtemp(prefix='emph_bs_', dir='/dev/shm')
     try:
