@@ -36,7 +36,11 @@ def main():
             emphases_amd.Alignment.from_frames(synth.word_frames(3000 + index, 1000)).save(text)
             texts.append(text), waves.append(wave)
             prefixes.append(os.path.join(directory, f'o{index}'))
-        emphases_amd.from_files_to_files(texts[:512], waves[:512], prefixes[:512], gpu=0)
+        # (every pinned buffer of the session and every output file exists afterwards: the
+        # laps overwrite, bench.py's create)
+        emphases_amd.from_files_to_files(texts, waves, prefixes, gpu=0)
+        import gc
+        gc.collect()
         from emphases_amd import session as session_module
         openers = session_module.FILE_BUFFERS - 2
         if len(sys.argv) > 2 and sys.argv[2] == 'sweep':

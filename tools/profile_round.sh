@@ -30,7 +30,7 @@ done
 cd $repo
 python3 bench.py --config transformer --steps 50 --warmup 5 --no-cpu-baseline --no-side \
     > $out/${tag}_transformer_bench.json 2>> $out/${tag}_bench.err
-for precision in bf16x3 bf16x6; do
+for precision in bf16x3 bf16x3_fast bf16x6; do
     python3 bench.py --config transformer --precision $precision --steps 50 --warmup 5 --no-cpu-baseline --no-side \
         > $out/${tag}_transformer_$precision.json 2>> $out/${tag}_bench.err
 done
