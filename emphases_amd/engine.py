@@ -127,8 +127,6 @@ class Engine:
         self.precision = precision
         self.split_pieces, self.attention_pieces, self.linear_pieces = \
             PRECISIONS[precision]
-        if os.environ.get('EMPHASES_LINEAR_PIECES'):      # (experiments)
-            self.linear_pieces = int(os.environ['EMPHASES_LINEAR_PIECES'])
         self.winograd = winograd
         self.device = runtime.require_gpu(device)
         self.lib = runtime.library()
@@ -792,8 +790,7 @@ class Engine:
         # ... or the projection kernel writes the pieces itself (no fp32 K and V,
         # no second pass): when every segment of the axis is a long one
         projected_images = split_images is not None and \
-            all(tile_n == ATTENTION_GROUP for _, _, tile_n in launches) and \
-            os.environ.get('EMPHASES_SPLIT_IMAGES', '1') != '0'
+            all(tile_n == ATTENTION_GROUP for _, _, tile_n in launches)
 
         def attend(images_written):
             for tiles, count, tile_n in launches:

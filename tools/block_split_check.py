@@ -1,7 +1,7 @@
-"""configs[2] (Transformer) at f32 and bf16x3: ms per step, per-kernel us, and the
-worst score difference - the comparison the bf16x3 block / projection kernels
-(csrc/block_split.hip) are judged on.  EMPH_LINEAR_WAVES=4|8 picks the
-workgroup shape."""
+"""configs[2] (Transformer) at f32 and the opt-in precisions: ms per step, per-kernel us
+(eager, one stream) and the worst score difference - the comparison the split
+projection / block kernels (csrc/block_split.hip) are judged on.
+usage (GPU box): python tools/block_split_check.py [f32 bf16x3 bf16x3_fast bf16x6]"""
 import argparse
 import json
 import sys
