@@ -43,6 +43,22 @@ constexpr int kLinearWaves = 4;
 constexpr int kLinearThreads = 64 * kLinearWaves;
 constexpr int linear_pack_bytes(int pieces) { return kLinearSteps * kLinearMTiles * pieces * 1024; }
 
+// A lane's column of channel-major rows: the row's address is wave-uniform (scalar
+// registers), what varies with the lane - its column and its half's four channels - is
+// ONE 32-bit offset, so that eighty loads of a tile hold no eighty addresses in vector
+// registers (the entry points keep 5 ld below 2^32).
+__device__ __forceinline__ uint32_t linear_lane_offset(int64_t ld, int64_t column, int half) {
+    return static_cast<uint32_t>(column) + static_cast<uint32_t>(4 * half) * static_cast<uint32_t>(ld);
+}
+__device__ __forceinline__ const float& linear_at(const float* base, int64_t ld, int channel,
+                                                  uint32_t lane_offset) {
+    return (base + static_cast<int64_t>(channel) * ld)[lane_offset];
+}
+__device__ __forceinline__ float& linear_at(float* base, int64_t ld, int channel,
+                                            uint32_t lane_offset) {
+    return (base + static_cast<int64_t>(channel) * ld)[lane_offset];
+}
+
 // register r of m-tile m holds channel 32 m + 8 (r / 4) + 4 half + r % 4; the third
 // m-tile's registers 8 .. 15 are rows 80 .. 95 (nothing)
 #define EMPH_LINEAR_VALID(m, r) (32 * (m) + 8 * ((r) >> 2) < kLinearChannels)
@@ -192,20 +208,19 @@ __global__ __launch_bounds__(kLinearThreads) void transformer_block_split_kernel
     // the accumulator layout (columns beyond the segment read its last one)
     auto request = [&](int tile, float (&operand)[kLinearSteps][8], f32x16 (&residual)[kLinearMTiles]) {
         const Tile span = load_tile(tiles, tile);
-        const int64_t column = span.offset + min(span.first + col, span.count - 1);
+        const uint32_t at = linear_lane_offset(
+            ld, span.offset + min(span.first + col, span.count - 1), half);
 #pragma unroll
         for (int j = 0; j < kLinearSteps; ++j)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                operand[j][e] = attended[static_cast<int64_t>(16 * j + 8 * (e >> 2) + 4 * half +
-                                                              (e & 3)) * ld + column];
+                operand[j][e] = linear_at(attended, ld, 16 * j + 8 * (e >> 2) + (e & 3), at);
 #pragma unroll
         for (int m = 0; m < kLinearMTiles; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 residual[m][r] = EMPH_LINEAR_VALID(m, r)
-                                     ? x[static_cast<int64_t>(32 * m + 8 * (r >> 2) + 4 * half + (r & 3)) * ld +
-                                         column]
+                                     ? linear_at(x, ld, 32 * m + 8 * (r >> 2) + (r & 3), at)
                                      : 0.f;
     };
 
@@ -266,8 +281,8 @@ __global__ __launch_bounds__(kLinearThreads) void transformer_block_split_kernel
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (EMPH_LINEAR_VALID(m, r))
-                        x[static_cast<int64_t>(32 * m + 8 * (r >> 2) + 4 * half + (r & 3)) * ld + column] =
-                            y[m][r];
+                        linear_at(x, ld, 32 * m + 8 * (r >> 2) + (r & 3),
+                                  linear_lane_offset(ld, column, half)) = y[m][r];
         }
     }
 }
@@ -297,13 +312,13 @@ __global__ __launch_bounds__(kLinearThreads) void qkv_split_kernel(
 
     auto request = [&](int tile, float (&operand)[kLinearSteps][8]) {
         const Tile span = load_tile(tiles, tile);
-        const int64_t column = span.offset + min(span.first + col, span.count - 1);
+        const uint32_t at = linear_lane_offset(
+            ld, span.offset + min(span.first + col, span.count - 1), half);
 #pragma unroll
         for (int j = 0; j < kLinearSteps; ++j)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
-                operand[j][e] = x[static_cast<int64_t>(16 * j + 8 * (e >> 2) + 4 * half + (e & 3)) * ld +
-                                  column];
+                operand[j][e] = linear_at(x, ld, 16 * j + 8 * (e >> 2) + (e & 3), at);
     };
     const int stride = gridDim.x * kLinearWaves;
     int tile = blockIdx.x * kLinearWaves + wave;
@@ -355,8 +370,8 @@ __global__ __launch_bounds__(kLinearThreads) void qkv_split_kernel(
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             if (EMPH_LINEAR_VALID(m, r))
-                                qk[static_cast<int64_t>(part * C + 32 * m + 8 * (r >> 2) + 4 * half +
-                                                        (r & 3)) * ld + column] = acc[m][r];
+                                linear_at(qk, ld, part * C + 32 * m + 8 * (r >> 2) + (r & 3),
+                                          linear_lane_offset(ld, column, half)) = acc[m][r];
                     } else {
 #pragma unroll
                         for (int b = 0; b < 4; ++b)
@@ -535,6 +550,9 @@ int emph_transformer_block_split(const float* attended, float* x, int64_t ld, in
                  channels, tile_n);
     EMPH_REQUIRE(pieces == 2 || pieces == 3, EMPH_ERANGE,
                  "emph_transformer_block_split: %d pieces (2 or 3)", pieces);
+    EMPH_REQUIRE(ld > 0 && ld < (int64_t{1} << 29), EMPH_ERANGE,
+                 "emph_transformer_block_split: ld %lld outside the 32-bit lane offsets",
+                 static_cast<long long>(ld));
     EMPH_REQUIRE(activation == EMPH_ACT_RELU || activation == EMPH_ACT_NONE, EMPH_ERANGE,
                  "emph_transformer_block_split: activation %d", activation);
     EMPH_REQUIRE((reinterpret_cast<uintptr_t>(packs) & 15) == 0, EMPH_EINVAL,
@@ -586,6 +604,9 @@ int emph_qkv_projection_split(const float* x, int64_t ld, float* qk, float* v, i
                  channels, tile_n);
     EMPH_REQUIRE(pieces == 2 || pieces == 3, EMPH_ERANGE,
                  "emph_qkv_projection_split: %d pieces (2 or 3)", pieces);
+    EMPH_REQUIRE(ld > 0 && ld < (int64_t{1} << 29), EMPH_ERANGE,
+                 "emph_qkv_projection_split: ld %lld outside the 32-bit lane offsets",
+                 static_cast<long long>(ld));
     EMPH_REQUIRE((reinterpret_cast<uintptr_t>(packs) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(v) & 15) == 0,
                  EMPH_EINVAL, "emph_qkv_projection_split: packs and v must be 16-byte aligned");
@@ -615,6 +636,9 @@ int emph_qkv_projection_split_images(const float* x, int64_t ld, float* qk, void
                  "for 80, 2 and 32)", channels, heads, tile_n);
     EMPH_REQUIRE(pieces == 2 || pieces == 3, EMPH_ERANGE,
                  "emph_qkv_projection_split_images: %d pieces (2 or 3)", pieces);
+    EMPH_REQUIRE(ld > 0 && ld < (int64_t{1} << 29), EMPH_ERANGE,
+                 "emph_qkv_projection_split_images: ld %lld outside the 32-bit lane offsets",
+                 static_cast<long long>(ld));
     EMPH_REQUIRE(attention_pieces == 2 || attention_pieces == 3 || attention_pieces == 32,
                  EMPH_ERANGE, "emph_qkv_projection_split_images: attention pieces %d (2, 3 or 32)",
                  attention_pieces);
