@@ -46,6 +46,13 @@ def test_chunk_plans_match_reference(chunk_goldens):
             want_words.tolist(), name
         np.testing.assert_array_equal(
             np.concatenate([s.bounds for s in segments], axis=1), want_bounds)
+        if batch_size is None:
+            # ... and the library's one pass over a batch (emph_plan_batch), here a
+            # batch of this utterance three times over
+            plan = batch.plan_batch([words] * 3, [samples] * 3)
+            assert plan.frames.tolist() == want_frames.tolist() * 3, name
+            np.testing.assert_array_equal(
+                plan.segment_bounds, np.concatenate([want_bounds] * 3, axis=1))
 
         # oracle
         kept = [c for c in oracle.chunks(seconds(bounds), samples, batch_size)
