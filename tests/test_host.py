@@ -1128,6 +1128,17 @@ def test_plan_batch_of_the_library_matches_numpy_and_the_chunker():
         spoiled = np.concatenate(changed)
         assert batch._plan_columns(spoiled, counts, lengths) is None
         assert plan_reference.plan_columns(spoiled, counts, lengths) is None
+        if spoil == 'chunks':
+            # the caller that holds one table gets the chunker's plan all the same:
+            # the list of alignments is built only now (`files.FileBatch.all_times`)
+            asked = []
+            lazily = batch.plan_batch(
+                lambda: asked.append(1) or changed, lengths,
+                tables=(spoiled, counts))
+            listed = batch.plan_batch(changed, lengths)
+            assert asked == [1] and len(lazily) == len(listed)
+            assert np.array_equal(lazily.table, listed.table)
+            assert np.array_equal(lazily.bounds, listed.bounds)
     with pytest.raises(ValueError, match='disagree'):
         batch._plan_columns(table[:-1], counts, lengths)
     # ... and pack_metadata's tables built in place are word_sum_tables' own
