@@ -277,6 +277,8 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
     from . import session as session_module
     engine = session.engine
     open_threads, write_threads = files.stage_threads(session_module.FILE_BUFFERS - 2)
+    # (the pitch tracker wants every utterance's samples on the host)
+    tracked = engine.config.pitch_feature or engine.config.periodicity_feature
 
     def open_batch(first, last, turn):
         start = time.perf_counter_ns()
@@ -284,6 +286,25 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
             text_files[first:last], audio_files[first:last], open_threads)
         _stamp('open.parse', turn, start)
         begin = time.perf_counter_ns()
+        dtype = None if tracked else opened.staged_format(cfg.SAMPLE_RATE)
+        if dtype is not None:
+            # every file read by the library, 16 kHz mono, one sample format:
+            # samples, plan and tables without an object per file - the samples
+            # straight into one of the session's pinned buffers, the plan from
+            # the library's own table of word times
+            with torch.cuda.device(session.engine.device):
+                staging = session.file_buffer(turn, opened.audio_bytes())
+            where, lengths = opened.read_staged(staging)
+            _stamp('open.read', turn, begin)
+            begin = time.perf_counter_ns()
+            plan = engine.prepare(batch.plan_batch(
+                opened.all_times, lengths, batch_size,
+                tables=(opened.times, opened.sizes[:, 1])))
+            _stamp('open.plan', turn, begin)
+            _stamp('open', turn, start)
+            return opened, [(cfg.SAMPLE_RATE, range(opened.count), (),
+                             session_module.Staged(
+                                 staging, where, lengths, dtype), plan)]
         loaded = opened.all_audios()
         _stamp('open.objects', turn, begin)
         begin = time.perf_counter_ns()
@@ -294,20 +315,9 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
         begin = time.perf_counter_ns()
         groups = []
         rates = sorted({rate for _, rate in loaded})
-        if rates == [cfg.SAMPLE_RATE] and not opened.status.any() and \
-                bool(opened.native_audio().all()):
-            # every file read by the library, 16 kHz mono: the plan from the
-            # library's own table of word times (nothing per file here)
-            audios = [audio for audio, _ in loaded]
-            plan = engine.prepare(batch.plan_batch(
-                opened.all_times, opened.sizes[:, 10] // (opened.sizes[:, 8] // 8),
-                batch_size, tables=(opened.times, opened.sizes[:, 1])))
-            groups.append((cfg.SAMPLE_RATE, list(range(opened.count)), (),
-                           audios, plan))
-            rates = []
         # (word-time tables, not alignment objects: nothing per file for the
         # interpreter's collector to trace; `deliver` builds what it asks for)
-        alignments = opened.all_times() if rates else None
+        alignments = opened.all_times()
         for rate in rates:
             chosen = [i for i, (_, r) in enumerate(loaded) if r == rate]
             picked = [alignments[i] for i in chosen]
@@ -366,9 +376,12 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
             if position + ahead < len(starts):
                 opening.append(ask(position + ahead))
             start = time.perf_counter_ns()
-            jobs = [(position, session.submit(
-                picked, audios, rate, batch_size, plan=plan),
-                     opened, chosen, [first + i for i in chosen])
+            jobs = [(position,
+                     session.submit_staged(plan, audios)
+                     if type(audios) is session_module.Staged else
+                     session.submit(picked, audios, rate, batch_size, plan=plan),
+                     opened, chosen, range(first + chosen[0], first + chosen[-1] + 1)
+                     if type(chosen) is range else [first + i for i in chosen])
                     for rate, chosen, picked, audios, plan in groups]
             _stamp('submit', position, start)
             previous, in_flight = in_flight, jobs

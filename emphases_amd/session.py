@@ -221,13 +221,16 @@ class _Lane:
                     [lengths[i] * item for i in members], base)
             if tensors:
                 sources = [host_contiguous(audios[i]) for i in tensors]
+                # (named: an array that is only a temporary of the argument
+                # list is freed before the call reads it)
+                pointers = np.array(
+                    [a.data_ptr() for a in sources], dtype=np.int64)
+                sizes = np.array(
+                    [lengths[i] * item for i in tensors], dtype=np.int64)
+                where = np.array(
+                    [int(offsets[i]) * item for i in tensors], dtype=np.int64)
                 runtime.check(runtime.library().emph_host_gather(
-                    np.array([a.data_ptr() for a in sources],
-                             dtype=np.int64).ctypes.data,
-                    np.array([lengths[i] * item for i in tensors],
-                             dtype=np.int64).ctypes.data,
-                    np.array([int(offsets[i]) * item for i in tensors],
-                             dtype=np.int64).ctypes.data,
+                    pointers.ctypes.data, sizes.ctypes.data, where.ctypes.data,
                     len(tensors), base, COPY_THREADS), 'emph_host_gather')
             start, stop = int(offsets[lo]), int(offsets[hi])
             device_view[start:stop].copy_(
@@ -237,6 +240,24 @@ class _Lane:
                 device_view[offsets[i]:offsets[i + 1]].copy_(
                     audio, non_blocking=True)
         return device_view
+
+
+class Staged:
+    """A batch of 16 kHz mono utterances whose samples already sit in a pinned
+    buffer (`files.FileBatch.read_staged`): utterance u's `lengths[u]` samples
+    of `dtype` (int16 = 16-bit PCM, or float32) start at byte `where[u]` of
+    `buffer`.  What `Session.submit_staged` takes in place of one object per
+    utterance."""
+    __slots__ = ('buffer', 'where', 'lengths', 'dtype')
+
+    def __init__(self, buffer, where, lengths, dtype):
+        self.buffer = buffer
+        self.where = np.asarray(where, dtype=np.int64)
+        self.lengths = np.asarray(lengths, dtype=np.int64)
+        self.dtype = dtype
+
+    def __len__(self):
+        return len(self.lengths)
 
 
 class _Layout:
@@ -480,6 +501,69 @@ class Session:
                     lane.layouts.clear()
                     lane.pending = None
                     raise
+
+    def submit_staged(self, plan, staged, on_device=False):
+        """`submit` of a batch that is planned (`batch.plan_batch` of its
+        alignments and lengths, maybe `Engine.prepare`d) and whose samples are
+        in a pinned buffer already (`Staged`): the DMA of every run of
+        utterances that lie back to back there, the kernels, the scores' way
+        back.  Nothing here is per utterance."""
+        if self.engine.config.pitch_feature or \
+                self.engine.config.periodicity_feature:
+            raise ValueError(
+                'submit_staged: pitch / periodicity features need the samples '
+                'on the host (use submit)')
+        with self._lock:
+            lane = self.lanes[self._cursor % len(self.lanes)]
+            self._cursor += 1
+            with lane.lock:
+                if lane.pending is not None:
+                    lane.pending.result()
+                try:
+                    return self._enqueue_staged(lane, plan, staged, on_device)
+                except BaseException:
+                    try:
+                        lane.stream.synchronize()
+                    except Exception:     # noqa: BLE001
+                        pass
+                    lane.layouts.clear()
+                    lane.pending = None
+                    raise
+
+    def _enqueue_staged(self, lane, plan, staged, on_device):
+        count = len(staged)
+        pending = Pending(
+            lane, plan, count, on_device,
+            plan.ld_words if plan is not None else 0)
+        if plan is None or not len(plan):
+            return pending
+        dtype = staged.dtype
+        item = 2 if dtype == torch.int16 else 4
+        offsets = np.concatenate([[0], np.cumsum(staged.lengths)])
+        total = int(offsets[-1])
+        lane._reserve(total * item, plan.ld_words)
+        # runs of utterances that lie back to back in the pinned buffer
+        nbytes = staged.lengths * item
+        cuts = np.nonzero(
+            staged.where[1:] != staged.where[:-1] + nbytes[:-1])[0] + 1
+        first = np.concatenate([[0], cuts]).tolist()
+        last = np.concatenate([cuts, [count]]).tolist()
+        with torch.cuda.device(lane.device), torch.cuda.stream(lane.stream):
+            packed = lane.audio[:max(total, 1) * item].view(dtype)[:total]
+            for lo, hi in zip(first, last):
+                start, stop = int(offsets[lo]), int(offsets[hi])
+                source = int(staged.where[lo])
+                packed[start:stop].copy_(
+                    staged.buffer[source:source + (stop - start) * item]
+                    .view(dtype), non_blocking=True)
+            scores, _ = lane.engine.forward(packed, plan)
+            if on_device:
+                pending._scores = scores.clone()
+            else:
+                lane.result[:plan.ld_words].copy_(scores, non_blocking=True)
+            lane.done.record(lane.stream)
+        lane.pending = pending
+        return pending
 
     def _enqueue(self, lane, alignments, audios, sample_rate, batch_size,
                  on_device, pitch_tracker, ready=None):

@@ -886,6 +886,56 @@ def test_file_api_and_cli(tmp_path, cases):
     assert torch.equal(torch.load(tmp_path / 'cli.pt'), scores)
 
 
+def test_file_api_staged_batches(tmp_path):
+    """`from_files_to_files` without an object per file (`files.FileBatch.
+    read_staged` + `Session.submit_staged`): batches of 16-bit PCM files whose odd
+    sample counts leave gaps in the pinned buffer (several DMA runs), a batch of
+    float32 files, and a batch that mixes the two formats (which takes the
+    per-file path) - every file's scores are bit for bit `from_file`'s."""
+    import struct
+    from emphases_amd import files as files_module, load
+
+    def save_float32(file, audio):
+        body = np.asarray(audio, dtype='<f4').tobytes()
+        header = b'RIFF' + struct.pack('<I', 36 + len(body)) + b'WAVEfmt ' + \
+            struct.pack('<IHHIIHH', 16, 3, 1, 16000, 64000, 4, 32) + \
+            b'data' + struct.pack('<I', len(body))
+        with open(file, 'wb') as handle:
+            handle.write(header + body)
+
+    texts, waves = [], []
+    for index, samples in enumerate(
+            [160000, 48001, 31999, 80003, 16000, 64007, 33333, 100000]):
+        frames = samples // 160
+        emphases_amd.Alignment.from_frames(
+            synth.word_frames(index, frames, 3, 40)).save(
+                tmp_path / f'u{index}.TextGrid')
+        audio = synth.audio(index, frames + 1)[:samples]
+        for kind in ('pcm', 'f32'):
+            wave = tmp_path / f'u{index}_{kind}.wav'
+            if kind == 'pcm':
+                load.save_wav(wave, audio)
+            else:
+                save_float32(wave, audio)
+        texts.append(tmp_path / f'u{index}.TextGrid')
+        waves.append(index)
+    pcm = [tmp_path / f'u{i}_pcm.wav' for i in waves]
+    f32 = [tmp_path / f'u{i}_f32.wav' for i in waves]
+    mixed = [pcm[i] if i % 2 else f32[i] for i in waves]
+    opened = files_module.FileBatch(texts, pcm)
+    assert opened.staged_format(16000) == torch.int16
+    assert opened.staged_format(8000) is None
+    assert files_module.FileBatch(texts, f32).staged_format(16000) == torch.float32
+    assert files_module.FileBatch(texts, mixed).staged_format(16000) is None
+    for name, audio_files in (('pcm', pcm), ('f32', f32), ('mixed', mixed)):
+        prefixes = [tmp_path / f'{name}{i}' for i in waves]
+        emphases_amd.from_files_to_files(
+            texts, audio_files, prefixes, gpu=0, utterances_per_batch=5)
+        for text, wave, prefix in zip(texts, audio_files, prefixes):
+            want = emphases_amd.from_file(text, wave, gpu=0).cpu()
+            assert torch.equal(torch.load(str(prefix) + '.pt'), want), (name, wave)
+
+
 def test_api_leaves_torch_threads_alone(tmp_path, monkeypatch):
     """No public entry point touches torch's process-global thread settings
     (round 4 flipped `torch.set_num_threads(1)` around every call): a second

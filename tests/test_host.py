@@ -1015,6 +1015,44 @@ def test_textgrid_numbers_do_not_follow_the_locale_or_overflow(tmp_path):
     assert files.FileBatch([plus], [tmp_path / 'good.wav']).status.tolist() == [0]
 
 
+def test_file_batch_reads_a_whole_batch_without_an_object_per_file(tmp_path):
+    """`FileBatch.staged_format` / `read_staged`: when every file is 16 kHz mono
+    in one sample format, the samples of all of them go back to back (4-byte
+    aligned) into one buffer and come with (byte offsets, sample counts) - the
+    bytes are `load.wav`'s."""
+    import torch
+    from emphases_amd import files, load
+    texts, waves, counts = [], [], [16000, 4801, 3199, 8003, 1600]
+    for index, samples in enumerate(counts):
+        emphases_amd.Alignment.from_frames(
+            synth.word_frames(index, samples // 160, 3, 20)).save(
+                tmp_path / f'u{index}.TextGrid')
+        audio = np.resize(synth.audio(index, 100), samples)
+        load.save_wav(tmp_path / f'u{index}.wav', audio)
+        texts.append(tmp_path / f'u{index}.TextGrid')
+        waves.append(tmp_path / f'u{index}.wav')
+    opened = files.FileBatch(texts, waves, 2)
+    assert opened.staged_format(16000) == torch.int16
+    assert opened.staged_format(22050) is None
+    staging = torch.zeros(opened.audio_bytes() + 64, dtype=torch.uint8)
+    where, lengths = opened.read_staged(staging)
+    assert lengths.tolist() == counts
+    assert np.all(where % 4 == 0) and where[0] == 0
+    assert where.tolist() == np.concatenate(
+        [[0], np.cumsum([(2 * n + 3) // 4 * 4 for n in counts])[:-1]]).tolist()
+    for index, (start, n) in enumerate(zip(where.tolist(), counts)):
+        got = staging[start:start + 2 * n].view(torch.int16)
+        want, rate = load.wav(waves[index], raw=True)
+        assert rate == 16000 and torch.equal(got, want[0])
+    with pytest.raises(ValueError, match='too small'):
+        opened.read_staged(torch.zeros(100, dtype=torch.uint8))
+    # a stereo file, or one the library does not vouch for: not this way
+    load.save_wav(tmp_path / 'stereo.wav', np.zeros((2, 800), dtype=np.float32))
+    assert files.FileBatch(
+        texts[:2], [waves[0], tmp_path / 'stereo.wav']).staged_format(16000) is None
+    assert files.FileBatch([], []).staged_format(16000) is None
+
+
 def test_plan_tables_of_the_library_match_numpy():
     """emph_plan_tiles / emph_plan_word_sums (host arithmetic in the library,
     what `batch.Plan` calls) against the numpy restatement in
