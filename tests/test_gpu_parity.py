@@ -934,6 +934,14 @@ def test_file_api_staged_batches(tmp_path):
         for text, wave, prefix in zip(texts, audio_files, prefixes):
             want = emphases_amd.from_file(text, wave, gpu=0).cpu()
             assert torch.equal(torch.load(str(prefix) + '.pt'), want), (name, wave)
+    # ... and with the reference's chunking (`batch_size` frames per chunk): the one
+    # table of word times goes to the per-utterance chunker
+    prefixes = [tmp_path / f'chunked{i}' for i in waves]
+    emphases_amd.from_files_to_files(
+        texts, pcm, prefixes, gpu=0, batch_size=150, utterances_per_batch=5)
+    for text, wave, prefix in zip(texts, pcm, prefixes):
+        want = emphases_amd.from_file(text, wave, batch_size=150, gpu=0).cpu()
+        assert torch.equal(torch.load(str(prefix) + '.pt'), want), wave
 
 
 def test_api_leaves_torch_threads_alone(tmp_path, monkeypatch):
