@@ -348,10 +348,18 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
     ends = [min(first + utterances_per_batch, len(text_files))
             for first in starts]
     ahead = session_module.FILE_BUFFERS - 2
+    # the stages' threads (these two pools and the library's file pool: ours, not
+    # the caller's) next to the GPU: what they copy into pinned memory its DMA
+    # engine reads
+    near = files.cpus_near(engine.device.index)
+    settle = None
+    if near is not None:
+        files.pool_near(near)
+        settle = lambda: os.sched_setaffinity(0, near)   # noqa: E731 (this thread only)
     opener = concurrent.futures.ThreadPoolExecutor(
-        ahead, thread_name_prefix='emphases-open')
+        ahead, thread_name_prefix='emphases-open', initializer=settle)
     writer = concurrent.futures.ThreadPoolExecutor(
-        1, thread_name_prefix='emphases-write')
+        1, thread_name_prefix='emphases-write', initializer=settle)
     writes, in_flight, failure = [], [], None
 
     def finish(jobs, drain=2):

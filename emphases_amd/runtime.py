@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -125,6 +125,7 @@ SIGNATURES = {
     'emph_prominence_forward': (_c.c_int, [
         _ptr, _ptr, _i32, _ptr, _ptr, _i32, _ptr, _i32, _i32, _ptr, _i32, _ptr,
         _ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i32, _ptr]),
+    'emph_files_affinity': (_c.c_int, [_ptr, _i32]),
     'emph_files_open': (_c.c_int, [_ptr, _ptr, _i32, _i32, _ptr]),
     'emph_files_close': (None, [_ptr]),
     'emph_files_error': (_c.c_char_p, [_ptr, _i32]),

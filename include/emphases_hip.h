@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 26
+#define EMPH_ABI_VERSION 27
 
 /* Segment-table fields */
 enum {
@@ -131,6 +131,10 @@ int emph_host_gather(const void* const* host_sources, const int64_t* host_bytes,
  * are written in parallel.  Same grammar, same gap filling, same walker and
  * the same written bytes as emphases_amd/alignment.py / load.py. */
 typedef struct emph_file_batch emph_file_batch;
+
+/* The file pool's own threads onto the given CPUs (those next to the GPU whose
+ * DMA engine reads what they copy); the caller's threads are not touched. */
+int emph_files_affinity(const int32_t* cpus, int32_t count);
 
 /* Parse text_paths[i] (.TextGrid) and walk the headers of audio_paths[i]
  * (.wav), i < count.  A file that fails is reported per file (emph_files_sizes

@@ -957,6 +957,7 @@ def test_api_leaves_torch_threads_alone(tmp_path, monkeypatch):
         torch, 'set_num_threads',
         lambda n: (calls.append(n), real(n))[1])
     before = torch.get_num_threads()
+    affinity = os.sched_getaffinity(0)
     seen, stop = set(), threading.Event()
 
     def watch():
@@ -990,6 +991,9 @@ def test_api_leaves_torch_threads_alone(tmp_path, monkeypatch):
     assert calls == [], calls
     assert seen == {before}, (seen, before)
     assert torch.get_num_threads() == before
+    # ... nor where the caller's thread may run (the file API moves ITS threads
+    # next to the GPU, `files.cpus_near`)
+    assert os.sched_getaffinity(0) == affinity
 
 
 def test_file_api_failure_keeps_the_outputs_in_front_of_it(tmp_path):

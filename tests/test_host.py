@@ -1053,6 +1053,51 @@ def test_file_batch_reads_a_whole_batch_without_an_object_per_file(tmp_path):
     assert files.FileBatch([], []).staged_format(16000) is None
 
 
+def test_file_pool_threads_can_be_moved_next_to_the_gpu(tmp_path):
+    """emph_files_affinity moves the library's OWN pool threads (the ones there are
+    and the ones to come), never the caller: what `core.files_to_scores` does with
+    the CPUs of the GPU's NUMA node (`files.cpus_near`, None without a GPU)."""
+    from emphases_amd import files, load
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 3:
+        pytest.skip('needs three CPUs')
+    assert files.cpus_near(0) is None            # (no GPU here: nothing to be near)
+    texts, waves = [], []
+    for index in range(12):
+        emphases_amd.Alignment.from_frames(
+            synth.word_frames(index, 50, 3, 20)).save(tmp_path / f'u{index}.TextGrid')
+        load.save_wav(tmp_path / f'u{index}.wav', synth.audio(index, 50))
+        texts.append(tmp_path / f'u{index}.TextGrid')
+        waves.append(tmp_path / f'u{index}.wav')
+
+    def affinities():
+        result = {}
+        for task in os.listdir('/proc/self/task'):
+            try:
+                result[int(task)] = sorted(os.sched_getaffinity(int(task)))
+            except OSError:
+                pass
+        return result
+
+    files.FileBatch(texts, waves, 4).close()              # the pool has threads now
+    before = affinities()
+    try:
+        files.pool_near(allowed[:2])
+        files.FileBatch(texts, waves, 6).close()          # ... and grows pinned
+        after = affinities()
+        moved = [task for task, cpus in after.items() if cpus == allowed[:2]]
+        assert len(moved) >= 5                            # helpers: 3 old + 2 new
+        assert after[os.getpid()] == allowed              # the caller stays
+        assert all(after[task] == cpus for task, cpus in before.items()
+                   if task in after and task not in moved)
+        with pytest.raises(runtime.LibraryError):
+            files.pool_near([])
+        with pytest.raises(runtime.LibraryError):
+            files.pool_near([1 << 20])
+    finally:
+        files.pool_near(allowed)
+
+
 def test_plan_tables_of_the_library_match_numpy():
     """emph_plan_tiles / emph_plan_word_sums (host arithmetic in the library,
     what `batch.Plan` calls) against the numpy restatement in
