@@ -355,7 +355,12 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
     settle = None
     if near is not None:
         files.pool_near(near)
-        settle = lambda: os.sched_setaffinity(0, near)   # noqa: E731 (this thread only)
+
+        def settle():
+            try:
+                os.sched_setaffinity(0, near)       # (pid 0: this thread only)
+            except OSError:
+                pass                                # (a cpuset that changed: stay)
     opener = concurrent.futures.ThreadPoolExecutor(
         ahead, thread_name_prefix='emphases-open', initializer=settle)
     writer = concurrent.futures.ThreadPoolExecutor(
