@@ -354,8 +354,11 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
     near = files.cpus_near(engine.device.index)
     settle = None
     if near is not None:
-        files.pool_near(near)
-
+        try:
+            files.pool_near(near)
+        except runtime.LibraryError:
+            near = None                             # (placement is a nicety)
+    if near is not None:
         def settle():
             try:
                 os.sched_setaffinity(0, near)       # (pid 0: this thread only)
