@@ -63,7 +63,7 @@ PEAK_HBM = 8.0e12             # B/s, same guide
 # compulsory traffic and algorithmic flops of the conv path
 BYTES_PER_FRAME = 641.
 FLOPS_PER_FRAME, FLOPS_PER_WORD = 0.2968e6, 0.2309e6
-PROFILE_TAGS = ('r5', 'r4', 'r3', 'r2', 'r1')
+PROFILE_TAGS = ('r6', 'r5', 'r4', 'r3', 'r2', 'r1')
 # kernel name in `Engine.timers` -> substring of the rocprofv3 kernel name
 ROCPROF_NAMES = {
     'conv1d_winograd4_frames_80x80_k3': 'conv1d_winograd4_kernel',
@@ -73,6 +73,8 @@ ROCPROF_NAMES = {
     'frontend_logmel': 'frontend_kernel',
     'segment_reduce': 'segment_reduce_kernel',
     'word_decoder': 'word_decoder_kernel'}
+# ... under an opt-in precision
+SPLIT_ROCPROF_NAMES = {'attention_frames': 'attention_split_kernel'}
 
 
 def parse_args():
@@ -121,6 +123,14 @@ def parse_args():
                         help='launch kernel by kernel instead of replaying '
                              'the captured HIP graph')
     parser.add_argument('--no-preroll', action='store_true')
+    parser.add_argument('--side-records', default=None, metavar='PATH',
+                        help='where the FULL record goes (every side '
+                             'measurement, notes, per-kernel tables); the '
+                             'line on stdout stays under 10 KB and names this '
+                             'file and its sha256.  Default: bench_side.json '
+                             'next to this script (bench_side_<workload / '
+                             'config / precision>.json for the non-default '
+                             'commands)')
     parser.add_argument('--cpu-worker', type=float, default=None,
                         help=argparse.SUPPRESS)
     return parser.parse_args()
@@ -411,24 +421,37 @@ class Runner:
         return scores
 
     def kernel_times(self, passes=20):
-        """Per-kernel HIP-event durations on the launch stream (eager)."""
+        """Per-kernel durations of eager launches on the launch stream:
+        `kernels[name]` = [regions, seconds by recorded HIP events (dispatch
+        included), flops, seconds kernel-exact, kernels launched].  Kernel-exact
+        = `runtime.LaunchTimer`: events bound to each kernel's own dispatch
+        packet, the begin -> end rocprofv3 reads; a named region may hold more
+        than one kernel (attention over long and short segments, say)."""
+        from emphases_amd import runtime
         engine = self.engine
         engine.timers = []
-        for _ in range(passes):
-            engine.forward(self.packed, self.plan, self.meta)
-        # the dispatch alone: the same events around an empty kernel
-        from emphases_amd import runtime
-        for _ in range(4 * passes):
-            with engine._timed('launch_probe'):
-                runtime.check(engine.lib.emph_launch_probe(runtime.stream()),
-                              'emph_launch_probe')
-        torch.cuda.synchronize()
+        # (one untimed pass: every pass below finds its buffers in place)
+        engine.forward(self.packed, self.plan, self.meta)
+        with runtime.LaunchTimer(1 << 16) as exact:
+            engine.timers = []
+            for _ in range(passes):
+                engine.forward(self.packed, self.plan, self.meta)
+            # the empty kernel: what a recorded pair measures around nothing
+            for _ in range(4 * passes):
+                with engine._timed('launch_probe'):
+                    runtime.check(
+                        engine.lib.emph_launch_probe(runtime.stream()),
+                        'emph_launch_probe')
+            torch.cuda.synchronize()
+        assert exact.launches <= exact.capacity, exact.launches
         kernels = {}
-        for name, flops, begin, end in engine.timers:
-            entry = kernels.setdefault(name, [0, 0., 0.])
+        for name, flops, begin, end, first, last in engine.timers:
+            entry = kernels.setdefault(name, [0, 0., 0., 0., 0])
             entry[0] += 1
             entry[1] += begin.elapsed_time(end) * 1e-3
             entry[2] += flops
+            entry[3] += float(exact.microseconds[first:last].sum()) * 1e-6
+            entry[4] += last - first
         engine.timers = None
         return kernels, passes
 
@@ -496,13 +519,23 @@ def profile_file(name):
     return None
 
 
-def from_profiles(config, dominant):
-    """What the committed rocprofv3 runs of this same command say about the
-    dominant kernel (NOT measured in this run; `profiles/README.md`)."""
+def stats_file(config, precision='f32', streams=1):
+    """The committed rocprofv3 kernel statistics of this command."""
+    stem = 'bench' if config == 'conv' else 'transformer'
+    if precision != 'f32':
+        stem = f'{config}_{precision}'
+    return profile_file(f'{stem}_kernel_stats_{streams}stream.csv')
+
+
+def from_profiles(config, dominant, precision='f32'):
+    """What the committed rocprofv3 runs of this same command (same
+    `--config`, same `--precision`) say about the dominant kernel - NOT
+    measured in this run (`profiles/README.md`)."""
     result = {}
-    stats = profile_file('bench_kernel_stats_1stream.csv' if config == 'conv'
-                         else 'transformer_kernel_stats_1stream.csv')
+    stats = stats_file(config, precision)
     pattern = ROCPROF_NAMES.get(dominant)
+    if precision != 'f32':
+        pattern = SPLIT_ROCPROF_NAMES.get(dominant, pattern)
     if stats and pattern:
         # (every instantiation of the kernel: the fused conv launches are
         # conv1d_stack_kernel<false> twice and <true> once per step)
@@ -516,29 +549,29 @@ def from_profiles(config, dominant):
             result['rocprof_avg_launch_us'] = total / calls * 1e-3
             result['rocprof_calls'] = calls
             result['kernel_stats_file'] = os.path.relpath(stats, ROOT)
-        # the empty kernel of `emph_launch_probe` in the same trace: what an event
-        # pair around it measures beyond this is the dispatch
-        with open(stats) as file:
-            for row in csv.DictReader(file):
-                if 'launch_probe_kernel' in row['Name']:
-                    result['rocprof_probe_kernel_us'] = \
-                        float(row['AverageNs']) * 1e-3
+    key = dominant if precision == 'f32' else f'{dominant}@{precision}'
     summary = profile_file('pmc_summary.json' if config == 'conv'
                            else 'transformer_pmc_summary.json')
     if summary:
         with open(summary) as file:
-            entry = json.load(file).get(dominant, {})
-        result['traffic'] = entry.get('traffic_bytes')
-        result['traffic_raw'] = entry.get('traffic_bytes_raw')
-        result['algorithmic_bytes'] = entry.get('algorithmic_bytes')
-        result['pmc_file'] = os.path.relpath(summary, ROOT)
+            entry = json.load(file).get(key, {})
+        if entry:
+            result['traffic'] = entry.get('traffic_bytes')
+            result['traffic_raw'] = entry.get('traffic_bytes_raw')
+            result['algorithmic_bytes'] = entry.get('algorithmic_bytes')
+            result['pmc_file'] = os.path.relpath(summary, ROOT)
     utilisation = profile_file('pmc_utilisation.json')
     if utilisation:
         with open(utilisation) as file:
-            entry = json.load(file).get(dominant, {})
-        result['mfma_pipe_busy'] = entry.get('mfma_pipe_busy')
-        result['sq_insts_mfma_per_launch'] = entry.get('sq_insts_mfma_per_launch')
-        result['mfma_pipe_busy_file'] = os.path.relpath(utilisation, ROOT)
+            entry = json.load(file).get(key, {})
+        if entry:
+            result['mfma_pipe_busy'] = entry.get('mfma_pipe_busy')
+            result['sq_insts_mfma_per_launch'] = \
+                entry.get('sq_insts_mfma_per_launch')
+            result['mfma_pipe_busy_file'] = os.path.relpath(utilisation, ROOT)
+            if result.get('traffic') is None and entry.get('traffic_bytes'):
+                result['traffic'] = entry['traffic_bytes']
+                result['pmc_file'] = os.path.relpath(utilisation, ROOT)
     return result
 
 
@@ -549,9 +582,7 @@ def rocprof_kernels(config):
     batches in flight."""
     result = {}
     for streams in (1, 2):
-        path = profile_file(
-            f'bench_kernel_stats_{streams}stream.csv' if config == 'conv' else
-            f'transformer_kernel_stats_{streams}stream.csv')
+        path = stats_file(config, 'f32', streams)
         if not path:
             continue
         rows = {}
@@ -605,117 +636,123 @@ def executed_matrix_flops(dominant, launches_per_step, committed, spans=None,
 
 
 PEAK_BF16_MFMA = 2500.        # TFLOP/s dense, same guide
-# 32 x 32 tiles of the split attention: (3 k-steps x terms of the scores + 4 x terms of
-# the values) v_mfma_f32_32x32x16_bf16 (the head dimension padded 40 -> 48, the value rows
-# 41 -> 64) per 2 x 2 x 32 x 32 x 40 flops; 'bf16x3': six products for the scores, three
-# for the values
+# flops of one v_mfma_f32_32x32x16_bf16
+SPLIT_MFMA_FLOPS = 2 * 32 * 32 * 16
+# Without a committed PMC count: 32 x 32 tiles of the split attention execute
+# (3 k-steps x terms of the scores + 4 x terms of the values) bf16 MFMAs (head
+# dimension 40 -> 48, value rows 41 -> 64) per 2 x 2 x 32 x 32 x 40 flops
 SPLIT_EXECUTED = {'bf16x3': (3 * 6 + 4 * 3) * 32768 / 163840.,
                   'bf16x3_fast': (3 * 6 + 4 * 3) * 32768 / 163840.,
                   'bf16x6': 7 * 6 * 32768 / 163840.}
 
+# What the fields of `roofline` are (kept out of the line: the side-records
+# file carries this once).
+ROOFLINE_NOTES = {
+    'frac': 'EXECUTED matrix flops (MFMA instructions counted by PMC in the '
+            'committed pass of this command x flops per instruction) per '
+            'second of kernel time over the dense MFMA peak of the pipe the '
+            'kernel runs on (fp32: 157.3 TF; the opt-in split kernels: bf16, '
+            '2 500 TF). At most 1. The vector work of an f32 kernel runs on '
+            'the same multipliers and is not counted (profiles/r5_coexec.txt).',
+    'avg_launch_us': 'this run, kernel-exact: events bound to each kernel\'s '
+                     'own dispatch packet (emph_launch_timer_*, '
+                     'hipExtLaunchKernel) on the launch stream, eager '
+                     'launches, one batch in flight - the begin -> end '
+                     'rocprofv3 reads, so `rocprof_avg_launch_us` (committed '
+                     'trace) must agree',
+    'avg_launch_us_events': 'the same launches between two RECORDED HIP '
+                            'events: includes the command processor\'s '
+                            'dispatch (probe_events_us around an empty kernel '
+                            'whose own duration is probe_kernel_us)',
+    'useful_tflops': 'algorithmic flops (SURVEY 8d: direct form, fp32 '
+                     'problem; no Winograd saving, no split products, no '
+                     'padding) per second of kernel time; frac_algorithmic = '
+                     'that over the fp32 MFMA peak: above 1 is work the '
+                     'kernel avoided or a faster pipe, not a faster fp32 pipe',
+    'frac_pmc_pipe_busy': 'SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) '
+                          'of the committed PMC pass: the pipe\'s share of '
+                          'cycles, independent of the clock',
+    'traffic': 'HBM bytes per launch by PMC (separate FETCH_SIZE / '
+               'WRITE_SIZE passes, FETCH doubled per the guide), committed '
+               'profile of this command'}
+
 
 def roofline(kernels, passes, ms_per_step, config, spans=None, layers=None,
              precision='f32'):
-    """`frac` = matrix flops the dominant kernel EXECUTES (its MFMA
-    instructions, counted by PMC) per second of kernel time, over the dense
-    fp32 MFMA peak: a fraction of the pipe, at most 1.  The direct-form figure
-    SURVEY 8(d) counts (F(4,3) executes about half of it) is
-    `frac_algorithmic`, which says how fast the layer is computed and can
-    exceed 1."""
+    """The dominant kernel against the matrix pipe it runs on.  `frac` =
+    matrix flops it EXECUTES (MFMA instructions counted by PMC) per second of
+    kernel time (kernel-exact, this run) over the dense peak; `useful_tflops`
+    / `frac_algorithmic` = the fp32 problem's direct-form flops per second,
+    which says how fast the layer is computed and can exceed the fp32 peak."""
     probe = kernels.pop('launch_probe', None)
-    dominant = max(kernels, key=lambda name: kernels[name][1])
-    launches, seconds, flops = kernels[dominant]
-    committed = from_profiles(config, dominant)
-    launches_per_step = launches / passes
-    # HIP events around a launch bracket the command processor's dispatch as
-    # well as the kernel.  The same events around an EMPTY kernel
-    # (emph_launch_probe) measure dispatch + that kernel; what the empty kernel
-    # itself takes is in the committed rocprofv3 trace of this command - the
-    # difference is the dispatch, which comes off the live duration.
-    raw_us = seconds / launches * 1e6
-    probe_us = probe[1] / probe[0] * 1e6 if probe else None
-    empty_us = committed.get('rocprof_probe_kernel_us')
-    dispatch_us = probe_us - empty_us \
-        if probe_us is not None and empty_us is not None else 0.
-    kernel_us = raw_us - dispatch_us
-    executed = executed_matrix_flops(
-        dominant, launches_per_step, committed, spans, layers)
-    executed_flops = executed.get('flops')
-    peak = PEAK_FP32_MFMA
-    if precision != 'f32' and dominant.startswith('attention'):
-        # the split kernel's bf16 instructions, against the bf16 peak (the time
-        # includes the emph_split_kv launch that prepares the pieces)
-        executed = {'flops': flops / launches * SPLIT_EXECUTED[precision],
-                    'mfma_instructions_source':
-                        'algorithmic flops x 7 x terms x 32768 / 163840 '
-                        '(32 x 32 tiles, head dimension 40 -> 48, value rows '
-                        '41 -> 64; tile edges not counted)'}
-        executed_flops = executed['flops']
-        peak = PEAK_BF16_MFMA
-        committed = dict(committed, mfma_pipe_busy=None)
-    if dominant.startswith('conv1d_split'):
-        # direct form on the bf16 pipe: three products per term, 96 rows for 80
-        # channels, 256 computed positions per 250 owned
-        executed = {'flops': flops / launches * 3. * 96. / 80. * 256. / 250.,
-                    'mfma_instructions_source':
-                        'algorithmic (direct-form) flops x 3 products x 96 / 80 '
-                        'rows x 256 / 250 positions'}
-        executed_flops = executed['flops']
-        peak = PEAK_BF16_MFMA
-        committed = dict(committed, mfma_pipe_busy=None)
-    if executed_flops is None:         # (a kernel without a Winograd saving)
-        executed_flops = flops / launches
+    exact = all(value[3] > 0. for value in kernels.values())
+    clock = 3 if exact else 1
+    dominant = max(kernels, key=lambda name: kernels[name][clock])
+    regions, by_events, flops, by_kernel, launched = kernels[dominant]
+    committed = from_profiles(config, dominant, precision)
+    launches_per_step = regions / passes
+    events_us = by_events / regions * 1e6
+    kernel_us = by_kernel / regions * 1e6 if exact else events_us
+    algorithmic_flops = flops / regions
+    split = precision != 'f32' and (dominant.startswith('attention') or
+                                    dominant.startswith('conv1d_split'))
+    peak = PEAK_BF16_MFMA if split else PEAK_FP32_MFMA
+    counted = committed.get('sq_insts_mfma_per_launch')
+    if split:
+        executed = {}
+        if counted:
+            executed = {'flops': counted * SPLIT_MFMA_FLOPS,
+                        'mfma_instructions_per_launch': counted,
+                        'mfma_instructions_source':
+                            committed.get('mfma_pipe_busy_file')}
+        elif dominant.startswith('attention'):
+            executed = {'flops': algorithmic_flops * SPLIT_EXECUTED[precision],
+                        'mfma_instructions_source':
+                            'formula (no committed PMC pass): 30 / 42 MFMAs '
+                            'per 32 x 32 scores, tile edges not counted'}
+        else:
+            # direct form, three products per term, 96 rows for 80 channels,
+            # 256 computed positions per 250 owned
+            executed = {'flops': algorithmic_flops * 3. * 96. / 80. * 256. / 250.,
+                        'mfma_instructions_source':
+                            'formula (no committed PMC pass): direct-form '
+                            'flops x 3 products x 96 / 80 rows x 256 / 250'}
+    else:
+        executed = executed_matrix_flops(
+            dominant, launches_per_step, committed, spans, layers)
+    executed_flops = executed.get('flops') or algorithmic_flops
     achieved = executed_flops / (kernel_us * 1e-6) / 1e12
-    algorithmic = flops / launches / (kernel_us * 1e-6) / 1e12
+    useful = algorithmic_flops / (kernel_us * 1e-6) / 1e12
     result = {
         'bound': 'mfma', 'kernel': dominant,
-        'achieved': achieved, 'peak': peak,
-        'unit': 'TFLOP/s', 'frac': achieved / peak,
-        'frac_is': 'EXECUTED matrix flops (MFMA instructions by PMC x flops '
-                   'per instruction) per second of kernel time over the dense '
-                   'fp32 MFMA peak; the vector work of the kernel (Winograd '
-                   'transforms) runs on the same multipliers and is not '
-                   'counted (profiles/r5_coexec.txt)',
+        'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+        'frac': achieved / peak,
+        # HBM bytes per launch by PMC: the committed profile of this command
+        'traffic': committed.get('traffic'),
+        'traffic_source': committed.get('pmc_file'),
         'avg_launch_us': kernel_us,
-        'avg_launch_us_is': 'HIP events around each launch on the launch '
-                            'stream, this run, minus the dispatch (the same '
-                            'events around an empty kernel, less that '
-                            'kernel\'s own duration in the committed '
-                            'rocprofv3 trace)' if dispatch_us else
-                            'HIP events around each launch on the launch '
-                            'stream, this run (includes the dispatch: no '
-                            'committed trace of the empty kernel yet)',
-        'avg_launch_us_raw': raw_us,
-        'launch_probe_us': probe_us,
-        'launch_probe_kernel_us_rocprof': empty_us,
-        'dispatch_us': dispatch_us,
+        'avg_launch_us_source': 'kernel-exact events, this run' if exact else
+        'recorded events, this run (dispatch included)',
+        'avg_launch_us_events': events_us,
+        'kernels_per_launch': launched / regions,
+        'probe_events_us': probe[1] / probe[0] * 1e6 if probe else None,
+        'probe_kernel_us': probe[3] / probe[0] * 1e6 if probe else None,
         'launches_per_step': launches_per_step,
         'share_of_step': None if not ms_per_step else
         kernel_us * 1e-6 * launches_per_step / (ms_per_step * 1e-3),
         'executed_mfma_flops_per_launch': executed_flops,
         'executed': executed,
-        'algorithmic_flops_per_launch': flops / launches,
-        'achieved_algorithmic': algorithmic,
-        'frac_algorithmic': algorithmic / PEAK_FP32_MFMA,
-        'frac_algorithmic_is': 'direct-form flops (SURVEY 8d: 2 x 80 x 240 per '
-                               'frame and layer) over the same peak: above 1 '
-                               'is Winograd\'s saving, not a faster pipe',
-        # HBM bytes per launch by PMC: from the committed profile of this
-        # command (see `from_profiles`), not collected in this run
-        'traffic': committed.get('traffic'),
-        'traffic_source': committed.get('pmc_file')}
+        'algorithmic_flops_per_launch': algorithmic_flops,
+        'useful_tflops': useful,
+        'frac_algorithmic': useful / PEAK_FP32_MFMA}
     if committed.get('mfma_pipe_busy') is not None:
         result['frac_pmc_pipe_busy'] = committed['mfma_pipe_busy']
-        result['frac_pmc_pipe_busy_is'] = (
-            'SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) of the '
-            'committed PMC pass: the same quantity in cycles, independent of '
-            'the clock')
     if committed.get('rocprof_avg_launch_us'):
         average = committed['rocprof_avg_launch_us']
         result['rocprof_avg_launch_us'] = average
-        if precision == 'f32' and not dominant.startswith('conv1d_split'):
-            result['frac_at_rocprof_avg'] = \
-                executed_flops / (average * 1e-6) / 1e12 / PEAK_FP32_MFMA
+        result['rocprof_file'] = committed.get('kernel_stats_file')
+        result['frac_at_rocprof_avg'] = \
+            executed_flops / (average * 1e-6) / 1e12 / peak
     return result, committed
 
 
@@ -862,7 +899,7 @@ def side_transformer(device, audios, alignments, args, precision='f32',
             UTTERANCES / line['ms_per_step'] * 1e3,
         'roofline': roof, 'from_profiles': committed,
         'kernels_us_per_step': {
-            name: value[1] / passes * 1e6 for name, value in kernels.items()},
+            name: value[3] / passes * 1e6 for name, value in kernels.items()},
         'preroll': ramp})
     del runner
     torch.cuda.empty_cache()
@@ -893,11 +930,66 @@ def side_conv_split(device, audios, alignments, args, baseline):
         'max_abs_dscore_vs_f32': float((kept - baseline).abs().max()),
         'words_compared': int(kept.numel()),
         'kernels_us_per_step': {
-            name: value[1] / passes * 1e6 for name, value in kernels.items()},
+            name: value[3] / passes * 1e6 for name, value in kernels.items()},
         'preroll': ramp})
     del runner
     torch.cuda.empty_cache()
     return line
+
+
+def single_utterance_api(audios, alignments, host=None, rounds=300):
+    """BASELINE configs[0]'s counterpart (the reference's only mode,
+    `emphases/core.py:223-265`): the latency of ONE `from_alignment_and_audio`
+    call on a 10 s host tensor - planning, staging, H2D, kernels, D2H - as
+    shipped (`default`: kernels chosen by configuration, scores bitwise those
+    of any batch) and with `conv_tile='auto'` (lowest-latency kernels for a
+    small batch); beside the oracle's one-core latency on this box and the
+    survey's figure for the reference itself."""
+    audio, alignment = torch.from_numpy(audios[0]), alignments[0]
+    result = {'workload': (
+        'one emphases_amd.from_alignment_and_audio call on one 10 s 16 kHz '
+        'utterance, float32 host tensor in, scores on the host out '
+        '(BASELINE.json configs[0] on the GPU)')}
+
+    def clock(call):
+        for _ in range(20):
+            scores = call()
+        torch.cuda.synchronize()
+        laps = []
+        for _ in range(rounds):
+            start = time.perf_counter()
+            scores = call()
+            laps.append(time.perf_counter() - start)
+        laps = np.asarray(laps) * 1e3
+        return {'ms_p50': float(np.median(laps)),
+                'ms_p90': float(np.percentile(laps, 90)),
+                'ms_p99': float(np.percentile(laps, 99)),
+                'ms_worst': float(laps.max()), 'laps': rounds,
+                'scores': int(scores.numel()),
+                'checksum': float(scores.double().sum())}
+    result['default'] = clock(lambda: emphases_amd.from_alignment_and_audio(
+        alignment, audio, 16000))
+    result['conv_tile_auto'] = clock(
+        lambda: emphases_amd.from_alignments_and_audios(
+            [alignment], [audio], 16000, conv_tile='auto')[0])
+    # the kernels alone: the same utterance resident, graph replay
+    engine = emphases_amd.get_engine(None, 0)
+    with engine.lock:
+        seconds, *_ = replay_time(
+            engine, audio.reshape(-1).to(engine.device), [alignment],
+            [int(audio.shape[-1])], None, least=0.1)
+    result['device_only_ms'] = seconds * 1e3
+    one_thread = dig(host or {}, 'threads', '1')
+    if one_thread:
+        result['oracle_1_core_ms'] = 1e3 / one_thread
+        result['oracle_1_core_is'] = (
+            'oracle/prominence.py (fp32, B=1) on one core of this box: the '
+            'cpu_baseline leg at 1 torch thread')
+    result['reference_survey_ms_1_thread'] = 18.8
+    result['reference_survey_is'] = (
+        'the reference as shipped (bf16 autocast), survey container, 8 vCPU '
+        'Xeon 2.1 GHz, 1 torch thread (BASELINE.md)')
+    return result
 
 
 def replay_time(engine, packed, alignments, lengths, batch_size, least=0.25):
@@ -1085,7 +1177,8 @@ def side_files_api(device, count=4096):
             prefixes.append(os.path.join(directory, f'out{index}'))
         # warm-up on files of their own, then every lap on files (alignments)
         # nobody has seen: no cached plan, no captured graph - what a corpus is
-        # (four batches: every pinned buffer of the session exists afterwards)
+        # (eight batches of 256: every pinned buffer of the session exists
+        # afterwards)
         warm = slice(laps_wanted * count,
                      laps_wanted * count + min(count, 2048))
         emphases_amd.from_files_to_files(
@@ -1114,7 +1207,7 @@ def side_files_api(device, count=4096):
                 '.TextGrid files in /dev/shm through '
                 'emphases_amd.from_files_to_files (emphases/core.py:115-179): '
                 'read + parse + plan + stage + H2D + kernels + D2H + write '
-                '.TextGrid and .pt per file; batches of 512 files, two in '
+                '.TextGrid and .pt per file; batches of 256 files, two in '
                 'flight; every lap on alignments never seen before'),
             'files': count, 'seconds': seconds, 'laps_s': laps,
             'files_per_s': count / seconds,
@@ -1371,10 +1464,180 @@ def spawn_workers(args):
 LINE_OUT = None
 
 
-def emit(result):
-    """The run's one line, on the process's original stdout."""
+LINE_LIMIT = 10000            # bytes; the driver parsed 12 KB, not 25 KB
+LINE_KEYS = (
+    'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step',
+    'ms_per_step_min', 'ms_per_step_max', 'timed_region_s', 'regions',
+    'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config',
+    'frames_per_s_per_gpu', 'checksum')
+ROOFLINE_KEYS = (
+    'bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic',
+    'avg_launch_us', 'avg_launch_us_source', 'avg_launch_us_events',
+    'launches_per_step', 'share_of_step', 'executed_mfma_flops_per_launch',
+    'algorithmic_flops_per_launch', 'useful_tflops', 'frac_algorithmic',
+    'frac_pmc_pipe_busy', 'rocprof_avg_launch_us', 'rocprof_file',
+    'frac_at_rocprof_avg', 'traffic_source')
+JOB_KEYS = ('utterances', 'frames', 'scores', 'checksum', 'frames_per_rank',
+            'lpt_imbalance', 'frames_per_s', 'compute_only_ms_per_rank',
+            'collectives_and_reorder_ms', 'memory_allocated_GB')
+CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'sample', 'cpu',
+            'cgroup_cpu_quota', 'physical_cores')
+
+
+def dig(record, *path):
+    """`record[path[0]][path[1]]...` or None (side measurements may have
+    failed: `guarded` leaves {'error': ...} in their place)."""
+    for key in path:
+        if not isinstance(record, dict) or key not in record:
+            return None
+        record = record[key]
+    return record
+
+
+def rounded(value, digits=6):
+    """Significant digits enough for a report; the side file keeps them all."""
+    if isinstance(value, float):
+        return float(f'{value:.{digits}g}')
+    if isinstance(value, dict):
+        return {key: rounded(item, digits) for key, item in value.items()}
+    if isinstance(value, (list, tuple)):
+        return [rounded(item, digits) for item in value]
+    return value
+
+
+def compact_line(result):
+    """The contract's ONE line from the full record: the headline, `roofline`
+    and `cpu_baseline` as objects, every side measurement as a scalar."""
+    line = {key: result[key] for key in LINE_KEYS if key in result}
+    if 'roofline' in result:
+        line['roofline'] = rounded({
+            key: result['roofline'][key] for key in ROOFLINE_KEYS
+            if result['roofline'].get(key) is not None or key == 'traffic'})
+    if 'cpu_baseline' in result:
+        host = result['cpu_baseline']
+        line['cpu_baseline'] = rounded({
+            key: host[key] for key in CPU_KEYS if key in host}) \
+            if 'error' not in host else host
+    if 'job' in result:         # (--workload corpus | longform)
+        line['job'] = {key: result['job'][key] for key in JOB_KEYS
+                       if key in result['job']}
+    scalars = {
+        # opt-in precision on the headline workload (configs[1])
+        'bf16x3_ms_per_step': ('configs_1_conv_bf16x3', 'ms_per_step'),
+        'bf16x3_utterances_per_s':
+            ('configs_1_conv_bf16x3', 'utterances_per_s'),
+        'bf16x3_max_abs_dscore':
+            ('configs_1_conv_bf16x3', 'max_abs_dscore_vs_f32'),
+        # BASELINE configs[2]
+        'configs_2_f32_ms_per_step': ('configs_2_transformer', 'ms_per_step'),
+        'configs_2_f32_roofline_frac':
+            ('configs_2_transformer', 'roofline', 'frac'),
+        'configs_2_bf16x3_ms_per_step':
+            ('configs_2_transformer_bf16x3', 'ms_per_step'),
+        'configs_2_bf16x3_max_abs_dscore':
+            ('configs_2_transformer_bf16x3', 'max_abs_dscore_vs_f32'),
+        'configs_2_bf16x3_useful_tflops':
+            ('configs_2_transformer_bf16x3', 'roofline', 'useful_tflops'),
+        'configs_2_bf16x3_fast_ms_per_step':
+            ('configs_2_transformer_bf16x3_fast', 'ms_per_step'),
+        'configs_2_bf16x3_fast_max_abs_dscore':
+            ('configs_2_transformer_bf16x3_fast', 'max_abs_dscore_vs_f32'),
+        'configs_2_bf16x6_ms_per_step':
+            ('configs_2_transformer_bf16x6', 'ms_per_step'),
+        'configs_2_bf16x6_max_abs_dscore':
+            ('configs_2_transformer_bf16x6', 'max_abs_dscore_vs_f32'),
+        # BASELINE configs[3] / [4] on one GPU
+        'configs_3_shard_utterances_per_s':
+            ('configs_3_corpus', 'rank0_of_8_device_only', 'utterances_per_s'),
+        'configs_3_shard_frames_per_s':
+            ('configs_3_corpus', 'rank0_of_8_device_only', 'frames_per_s'),
+        'configs_3_whole_corpus_utterances_per_s':
+            ('configs_3_corpus', 'whole_corpus_device_only',
+             'utterances_per_s'),
+        'configs_4_frames_per_s':
+            ('configs_4_longform', 'device_only', 'frames_per_s'),
+        'configs_4_api_pcm16_frames_per_s':
+            ('configs_4_longform', 'api_pcm16', 'frames_per_s'),
+        # ... strong-scaled over the ranks (N > 1)
+        'configs_3_sharded_utterances_per_s':
+            ('configs_3_corpus_sharded', 'utterances_per_s'),
+        'configs_3_sharded_ms_per_job':
+            ('configs_3_corpus_sharded', 'ms_per_step'),
+        'configs_4_sharded_utterances_per_s':
+            ('configs_4_longform_sharded', 'utterances_per_s'),
+        'configs_4_sharded_ms_per_job':
+            ('configs_4_longform_sharded', 'ms_per_step'),
+        # the public API, PCIe included (never `value`)
+        'api_float32_utterances_per_s':
+            ('end_to_end_api', 'float32', 'utterances_per_s_pipelined'),
+        'api_pcm16_utterances_per_s':
+            ('end_to_end_api', 'pcm16', 'utterances_per_s_pipelined'),
+        'files_api_files_per_s': ('files_api', 'files_per_s'),
+        # BASELINE configs[0]'s counterpart: ONE from_alignment_and_audio call
+        'single_utterance_ms_p50':
+            ('single_utterance_api', 'default', 'ms_p50'),
+        'single_utterance_ms_p99':
+            ('single_utterance_api', 'default', 'ms_p99'),
+        'single_utterance_tile_auto_ms_p50':
+            ('single_utterance_api', 'conv_tile_auto', 'ms_p50'),
+        'single_utterance_oracle_1_core_ms':
+            ('single_utterance_api', 'oracle_1_core_ms'),
+        'end_to_end_mfma_frac': ('end_to_end', 'mfma_frac'),
+        'end_to_end_hbm_frac_compulsory':
+            ('end_to_end', 'hbm_frac_compulsory')}
+    side = {}
+    for name, path in scalars.items():
+        value = dig(result, *path)
+        if value is not None:
+            side[name] = value
+    failed = sorted(key for key, value in result.items()
+                    if isinstance(value, dict) and 'error' in value)
+    if failed:
+        side['failed'] = failed
+    if side:
+        line['side'] = rounded(side)
+    return line
+
+
+def side_path(args):
+    if args.side_records:
+        return args.side_records
+    parts = [part for part, default in (
+        (args.workload, 'batch'), (args.config, 'conv'),
+        (args.precision, 'f32')) if part != default]
+    if args.gpus > 1:
+        parts.append(f'{args.gpus}gpus')
+    name = '_'.join(['bench_side'] + parts) + '.json'
+    return os.path.join(ROOT, name)
+
+
+def emit(result, args):
+    """The full record to the side-records file; the run's ONE line - under
+    `LINE_LIMIT` bytes whatever the side measurements held - on the process's
+    original stdout."""
+    import hashlib
+    result = dict(result, notes={'roofline': ROOFLINE_NOTES,
+                                 'line': 'stdout carries LINE_KEYS, roofline, '
+                                         'cpu_baseline and one scalar per '
+                                         'side measurement of this record'})
+    line = compact_line(result)
+    path = side_path(args)
+    text = json.dumps(result, indent=1, default=repr)
+    try:
+        with open(path, 'w') as file:
+            file.write(text + '\n')
+        line['side_records'] = {
+            'file': os.path.relpath(path, ROOT), 'bytes': len(text) + 1,
+            'sha256': hashlib.sha256((text + '\n').encode()).hexdigest()}
+    except OSError as error:
+        line['side_records'] = {'error': repr(error)}
+    text = json.dumps(line)
+    if len(text) >= LINE_LIMIT:       # (cannot happen with the keys above)
+        line.pop('side', None)
+        text = json.dumps(line)
+    assert len(text) < LINE_LIMIT, len(text)
     out = LINE_OUT or sys.stdout
-    out.write(json.dumps(result) + '\n')
+    out.write(text + '\n')
     out.flush()
 
 
@@ -1468,7 +1731,7 @@ def run_sharded(args, rank, world, device, host):
         'job': line}
     if host is not None:
         result['cpu_baseline'] = host
-    emit(result)
+    emit(result, args)
 
 
 def run_batch(args, rank, world, device, host):
@@ -1607,12 +1870,16 @@ def run_batch(args, rank, world, device, host):
             # gap), while the step replays a graph with two batches in
             # flight, whose kernels overlap - the sum is larger than the step.
             'kernels_us_per_step': {
+                name: value[3] / passes * 1e6
+                for name, value in kernels.items()},
+            'kernels_us_per_step_events': {
                 name: value[1] / passes * 1e6
                 for name, value in kernels.items()},
             'kernels_us_per_step_is': (
-                'eager launches, one stream, HIP events around each launch '
-                '(incl. dispatch gap); sums to more than ms_per_step, which '
-                'is a two-lane graph replay with overlapping kernels'),
+                'eager launches, one stream: kernel-exact (emph_launch_timer) '
+                'and between recorded HIP events (incl. dispatch gap); the '
+                'step itself is a two-lane graph replay with overlapping '
+                'kernels'),
             'kernels_us_rocprof': rocprof_kernels(args.config),
         }
         result['checksum'] = checksum
@@ -1623,6 +1890,8 @@ def run_batch(args, rank, world, device, host):
             if not args.no_api:
                 result['end_to_end_api'] = guarded(
                     end_to_end_api, audios, alignments)
+                result['single_utterance_api'] = guarded(
+                    single_utterance_api, audios, alignments, host)
             if not args.no_side:
                 result['configs_1_conv_bf16x3'] = guarded(
                     side_conv_split, device, audios, alignments, args,
@@ -1640,7 +1909,7 @@ def run_batch(args, rank, world, device, host):
                     result[f'configs_2_transformer_{precision}'] = entry
                 result['configs_4_longform'] = guarded(side_longform, device)
                 result['configs_3_corpus'] = guarded(side_corpus, device)
-        emit(result)
+        emit(result, args)
 
 
 if __name__ == '__main__':

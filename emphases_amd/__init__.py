@@ -23,7 +23,9 @@ from .core import (  # noqa: F401
     Model, active_config, configure, downsample, from_alignment_and_audio,
     from_alignments_and_audios, from_file, from_file_to_file,
     from_files_to_files, from_text_and_audio, get_engine, get_session, infer,
-    inference_context, postprocess, preprocess, resample)
+    inference_context, postprocess, preprocess, resample, segment)
 # the torch.library operator seams (torch.ops.emphases_amd.*): registration
 # only, nothing runs at import
 from . import ops  # noqa: F401,E402
+# emphases.data.preprocess.{from_audio, mels.from_audio, loudness.from_audio}
+from . import data  # noqa: F401,E402

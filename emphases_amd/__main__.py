@@ -34,6 +34,13 @@ def parse_args():
         help='The maximum number of frames per batch')
     parser.add_argument(
         '--gpu', type=int, help='The index of the gpu to run inference on')
+    # (an addition to the reference's flags)
+    parser.add_argument(
+        '--precision', default='f32',
+        choices=sorted(emphases_amd.engine.PRECISIONS),
+        help='f32 (default), or an opt-in precision: fp32 operands split '
+             'into bf16 pieces on the bf16 matrix pipe, fp32 accumulation '
+             '(scores within 1e-5 of f32)')
     return parser.parse_args()
 
 

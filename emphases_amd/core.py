@@ -157,7 +157,7 @@ def from_alignments_and_audios(alignments, audios, sample_rate=cfg.SAMPLE_RATE,
 
 
 def from_alignment_and_audio(alignment, audio, sample_rate, checkpoint=None,
-                             batch_size=None, gpu=None):
+                             batch_size=None, gpu=None, precision='f32'):
     """Produce emphasis scores for each word (`core.py:223-265`).
 
     alignment: object with `len()`, `[i]` -> word with `.start()/.end()/
@@ -166,10 +166,13 @@ def from_alignment_and_audio(alignment, audio, sample_rate, checkpoint=None,
     audio: float tensor [1, S] (only channel 0 is featurised, `mels.py:48`)
     sample_rate, checkpoint, batch_size (max frames per chunk), gpu: as in
         the reference.
+    precision: 'f32' (default), or one of the opt-in split-bf16 names of
+        `engine.PRECISIONS` (an addition; every entry point below takes it).
     Returns float32 scores [1, W]; words of chunks the reference drops
     (`core.py:414-415`) have no score, as there."""
     return from_alignments_and_audios(
-        [alignment], [audio], sample_rate, checkpoint, batch_size, gpu)[0]
+        [alignment], [audio], sample_rate, checkpoint, batch_size, gpu,
+        precision=precision)[0]
 
 
 def from_text_and_audio(text, audio, sample_rate, checkpoint=None,
@@ -183,7 +186,7 @@ def from_text_and_audio(text, audio, sample_rate, checkpoint=None,
 
 
 def from_file(text_file, audio_file, checkpoint=None, batch_size=None,
-              gpu=None):
+              gpu=None, precision='f32'):
     """`core.py:23-73`: scores for an alignment file (.TextGrid / .json) and
     an audio file."""
     if not str(text_file).endswith(('.TextGrid', '.json')):
@@ -196,7 +199,7 @@ def from_file(text_file, audio_file, checkpoint=None, batch_size=None,
     samples, rate = load.wav(audio_file, raw=True)
     return from_alignment_and_audio(
         alignment_module.Alignment(text_file), samples, rate, checkpoint,
-        batch_size, gpu)
+        batch_size, gpu, precision)
 
 
 def _save(alignment, scores, output_prefix):
@@ -206,12 +209,14 @@ def _save(alignment, scores, output_prefix):
 
 
 def from_file_to_file(text_file, audio_file, output_prefix=None,
-                      checkpoint=None, batch_size=None, gpu=None):
+                      checkpoint=None, batch_size=None, gpu=None,
+                      precision='f32'):
     """`core.py:76-112`"""
     from pathlib import Path
     if output_prefix is None:
         output_prefix = Path(text_file).stem
-    scores = from_file(text_file, audio_file, checkpoint, batch_size, gpu)
+    scores = from_file(text_file, audio_file, checkpoint, batch_size, gpu,
+                       precision)
     _save(alignment_module.Alignment(text_file), scores, output_prefix)
 
 
@@ -351,13 +356,20 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
     # the stages' threads (these two pools and the library's file pool: ours, not
     # the caller's) next to the GPU: what they copy into pinned memory its DMA
     # engine reads
+    # - when that node has room for them: the pools are sized from the whole CPU
+    # budget (`files.stage_threads`), and packed onto a few near CPUs they would
+    # lose more than the far socket costs.  The library's pool is shared by the
+    # process: it goes back to every allowed CPU when the call ends.
     near = files.cpus_near(engine.device.index)
-    settle = None
+    if near is not None and len(near) < open_threads + write_threads + 2:
+        near = None
+    settle, everywhere = None, None
     if near is not None:
         try:
+            everywhere = sorted(os.sched_getaffinity(0))
             files.pool_near(near)
-        except runtime.LibraryError:
-            near = None                             # (placement is a nicety)
+        except (runtime.LibraryError, OSError):
+            near = everywhere = None                # (placement is a nicety)
     if near is not None:
         def settle():
             try:
@@ -417,23 +429,31 @@ def _files_to_scores(text_files, audio_files, session, batch_size,
             failure = failure or error
     opener.shutdown(wait=True, cancel_futures=True)
     writer.shutdown(wait=True)
+    if everywhere is not None:
+        try:
+            files.pool_near(everywhere)
+        except runtime.LibraryError:
+            pass
     if failure is not None:
         raise failure
 
 
 def from_files_to_files(text_files, audio_files, output_prefixes=None,
                         checkpoint=None, batch_size=None, gpu=None,
-                        utterances_per_batch=256, conv_tile=None):
+                        utterances_per_batch=256, conv_tile=None,
+                        precision='f32'):
     """`core.py:115-179`, but the files are processed in ragged batches of
     `utterances_per_batch` instead of one at a time, two batches in flight,
     read, parsed and written by the library's host threads
-    (`files_to_scores`).  On several GPUs: `dist.from_files_to_files`."""
+    (`files_to_scores`).  On several GPUs: `dist.from_files_to_files`.
+    `precision`: 'f32' or an opt-in name of `engine.PRECISIONS`; the scores
+    of a file are bitwise those of the tensor API at the same precision."""
     from pathlib import Path
     text_files, audio_files = list(text_files), list(audio_files)
     if output_prefixes is None:
         output_prefixes = [Path(file).stem for file in text_files]
     output_prefixes = list(output_prefixes)
-    session = get_session(checkpoint, gpu, None, conv_tile)
+    session = get_session(checkpoint, gpu, None, conv_tile, precision)
     files_to_scores(
         text_files, audio_files, session, batch_size, utterances_per_batch,
         deliver_batch=lambda opened, chosen, indices, scores: opened.write(
@@ -535,6 +555,58 @@ def downsample(xs, word_bounds, word_lengths, config=None):
     for index, (off, count) in enumerate(zip(plan.word_off, plan.words)):
         result[index, :, :count] = out[:, off:off + count]
     return result if xs.is_cuda else result.cpu()
+
+
+def segment(xs, word_bounds, word_lengths):
+    """Convert acoustic features to word segments (`core.py:552-586`): xs
+    [B, C, T], word_bounds [B, 2, W], word_lengths [B] -> (segments
+    [B * W, C, L] zero-padded to the longest word L of the batch, bounds
+    int64 [B * W, 2, 1] = (0, frames), lengths int64 [B * W]).  Column j >=
+    word_lengths[i] of item i repeats the item's last word, as the reference's
+    `min(j, words - 1)` does.  One `emph_gather_columns` launch."""
+    device = runtime.require_gpu(xs.device if xs.is_cuda else None)
+    items, channels, frames = (int(n) for n in xs.shape)
+    width = int(word_bounds.shape[2])
+    bounds = np.asarray(word_bounds.cpu(), dtype=np.int64)
+    spans = bounds[:, 1] - bounds[:, 0]
+    longest = int(spans.max()) if spans.size else 0
+    count = items * width
+    pieces = np.zeros((count, 4), dtype=np.int64)
+    lengths = np.zeros(count, dtype=np.int64)
+    for item in range(items):
+        words = int(word_lengths[item])
+        for column in range(width):
+            # (Python's negative index when an item has no word at all)
+            chosen = min(column, words - 1) % width
+            start, end = bounds[item, 0, chosen], bounds[item, 1, chosen]
+            if start < 0 or end > frames or end < start:
+                # the reference's slice assignment raises on these too
+                raise ValueError(
+                    f'word bounds ({start}, {end}) outside the {frames} frames')
+            index = item * width + column
+            pieces[index] = (item * frames + start, end - start,
+                             index * longest, longest)
+            lengths[index] = end - start
+    result_bounds = torch.zeros((count, 2, 1), dtype=torch.long)
+    result_bounds[:, 1, 0] = torch.from_numpy(lengths)
+    result_lengths = torch.from_numpy(lengths)
+    with torch.cuda.device(device):
+        # channel-major with the items side by side: a piece is a run of columns
+        packed = xs.to(device, torch.float32).permute(1, 0, 2).reshape(
+            channels, items * frames).contiguous()
+        out = torch.zeros((channels, max(count * longest, 1)),
+                          dtype=torch.float32, device=device)
+        if count and longest:
+            table = torch.from_numpy(pieces).to(device)
+            runtime.check(runtime.library().emph_gather_columns(
+                packed.data_ptr(), packed.shape[1], out.data_ptr(),
+                out.shape[1], channels, table.data_ptr(), count,
+                runtime.stream()), 'emph_gather_columns')
+        result = out[:, :count * longest].reshape(
+            channels, count, longest).permute(1, 0, 2).contiguous().to(xs.dtype)
+    if xs.is_cuda:
+        return result, result_bounds.to(device), result_lengths.to(device)
+    return result.cpu(), result_bounds, result_lengths
 
 
 class Model:

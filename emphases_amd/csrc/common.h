@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -23,10 +24,33 @@ void set_error(const char* format, ...);
 // Launch + check_launch report errors of THIS launch only: hipGetLastError is a
 // per-thread sticky slot that other users of the runtime in the same process
 // (torch probing a host pointer, say) may leave set.
-#define EMPH_LAUNCH(...)                 \
-    do {                                 \
-        (void)hipGetLastError();         \
-        hipLaunchKernelGGL(__VA_ARGS__); \
+//
+// Launch timer (emph_launch_timer_*, measurement only): while the calling
+// thread has one armed, every launch carries its own pair of events, bound to
+// the kernel's dispatch packet itself (hipExtLaunchKernel), so that their
+// distance is the kernel's own begin -> end - the timestamps rocprofv3 reads -
+// and not the command processor's dispatch around it, which a pair of recorded
+// events brackets as well.
+struct LaunchTimer {
+    hipEvent_t* begin;
+    hipEvent_t* end;
+    int capacity;
+    int count;        // launches seen (those beyond `capacity` are not timed)
+};
+extern thread_local LaunchTimer* t_launch_timer;    // host.hip
+
+#define EMPH_LAUNCH(kernel, grid, block, lds, stream, ...)                               \
+    do {                                                                                 \
+        (void)hipGetLastError();                                                         \
+        ::emph::LaunchTimer* timer_ = ::emph::t_launch_timer;                            \
+        if (timer_ == nullptr || timer_->count >= timer_->capacity) {                    \
+            if (timer_ != nullptr) ++timer_->count;                                      \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, ##__VA_ARGS__);         \
+        } else {                                                                         \
+            const int slot_ = timer_->count++;                                           \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, timer_->begin[slot_], \
+                                  timer_->end[slot_], 0, ##__VA_ARGS__);                 \
+        }                                                                                \
     } while (0)
 
 inline int check_launch(const char* what) {

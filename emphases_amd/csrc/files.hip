@@ -1256,6 +1256,8 @@ int64_t emph_plan_tiles(const int64_t* host_counts, const int64_t* host_offsets,
 // first *n_words columns are the chunk-relative (start, end) frames of those chunks'
 // words.  Returns 0, or 1 when the batch must be planned one utterance at a time (an
 // utterance that needs several chunks, a negative duration, a time that is not finite).
+constexpr double kPlanExact = 4503599627370496.0;      // 2^52
+
 int emph_plan_batch(const double* times, const int64_t* counts, const int64_t* lengths,
                     int32_t n_utterances, int64_t sample_rate, int64_t hopsize,
                     int64_t padding, int64_t num_fft, int64_t* utterance,
@@ -1282,6 +1284,12 @@ int emph_plan_batch(const double* times, const int64_t* counts, const int64_t* l
         for (int64_t w = 0; w < count; ++w) {
             const double start = rows[2 * w], end = rows[2 * w + 1];
             if (!std::isfinite(start) || !std::isfinite(end)) return 1;
+            // a time whose frame index leaves the exactly representable integers (a
+            // corrupt file: 1e300 s) would overflow the casts below - undefined in C++;
+            // the one-utterance-at-a-time path reports it the way Python does
+            if (std::fabs(start * rate / hop) >= kPlanExact ||
+                std::fabs(end * rate / hop) >= kPlanExact)
+                return 1;
             const double duration = plan_floor_divide((end - start) * rate, hop);
             if (duration < 0.0) return 1;
             if (w + 1 < count) running += duration;

@@ -168,7 +168,70 @@ const int g_atfork = pthread_atfork(nullptr, nullptr, forget_pool_in_child);
 
 }  // namespace
 
+namespace emph {
+thread_local LaunchTimer* t_launch_timer = nullptr;
+}  // namespace emph
+
+namespace {
+void release_timer(emph::LaunchTimer* timer) {
+    for (int i = 0; i < timer->capacity; ++i) {
+        if (timer->begin[i]) (void)hipEventDestroy(timer->begin[i]);
+        if (timer->end[i]) (void)hipEventDestroy(timer->end[i]);
+    }
+    delete[] timer->begin;
+    delete[] timer->end;
+    delete timer;
+}
+}  // namespace
+
 extern "C" {
+
+int emph_launch_timer_begin(int32_t capacity) {
+    EMPH_REQUIRE(capacity >= 1 && capacity <= (1 << 20), EMPH_EINVAL,
+                 "emph_launch_timer_begin: capacity %d (1 .. 2^20)", capacity);
+    EMPH_REQUIRE(emph::t_launch_timer == nullptr, EMPH_EINVAL,
+                 "emph_launch_timer_begin: this thread's timer is already armed");
+    auto* timer = new emph::LaunchTimer{new hipEvent_t[capacity](), new hipEvent_t[capacity](),
+                                        capacity, 0};
+    for (int i = 0; i < capacity; ++i) {
+        hipError_t status = hipEventCreate(&timer->begin[i]);
+        if (status == hipSuccess) status = hipEventCreate(&timer->end[i]);
+        if (status != hipSuccess) {
+            release_timer(timer);
+            emph::set_error("emph_launch_timer_begin: %s", hipGetErrorString(status));
+            return static_cast<int>(status);
+        }
+    }
+    emph::t_launch_timer = timer;
+    return EMPH_OK;
+}
+
+int32_t emph_launch_timer_count(void) {
+    return emph::t_launch_timer ? emph::t_launch_timer->count : -1;
+}
+
+int emph_launch_timer_end(float* host_microseconds, int32_t capacity, int32_t* host_count) {
+    emph::LaunchTimer* timer = emph::t_launch_timer;
+    EMPH_REQUIRE(timer != nullptr, EMPH_EINVAL,
+                 "emph_launch_timer_end: no timer armed on this thread");
+    emph::t_launch_timer = nullptr;
+    const int timed = timer->count < timer->capacity ? timer->count : timer->capacity;
+    if (host_count) *host_count = timer->count;
+    int result = EMPH_OK;
+    for (int i = 0; i < timed && i < capacity && host_microseconds; ++i) {
+        float ms = 0.f;
+        hipError_t status = hipEventSynchronize(timer->end[i]);
+        if (status == hipSuccess) status = hipEventElapsedTime(&ms, timer->begin[i], timer->end[i]);
+        if (status != hipSuccess) {
+            emph::set_error("emph_launch_timer_end: launch %d: %s", i, hipGetErrorString(status));
+            result = static_cast<int>(status);
+            break;
+        }
+        host_microseconds[i] = ms * 1e3f;
+    }
+    release_timer(timer);
+    return result;
+}
 
 int emph_host_gather(const void* const* host_sources, const int64_t* host_bytes,
                      const int64_t* host_offsets, int32_t count, void* host_destination,

@@ -261,7 +261,8 @@ def bind_device(group=None, compute=None):
 
 def from_alignments_and_audios(alignments, audios, sample_rate=16000,
                                checkpoint=None, batch_size=None, config=None,
-                               compute=None, group=None, conv_tile=CONV_TILE):
+                               compute=None, group=None, conv_tile=CONV_TILE,
+                               precision='f32'):
     """Sharded version of `core.from_alignments_and_audios`: every rank passes
     the SAME full lists (tensors already in memory; for a corpus on disk use
     `from_files_to_files`, which loads only the shard); each computes its LPT
@@ -270,7 +271,8 @@ def from_alignments_and_audios(alignments, audios, sample_rate=16000,
     all scores in input order (on the collective's device: the GPU for
     nccl/RCCL, the CPU for gloo).  The kernel family does not depend on the
     batch (`Engine.frame_tile`), so the result is bitwise the same for every
-    world size, 1 included.  A rank that
+    world size, 1 included - at every `precision` ('f32', or an opt-in name
+    of `engine.PRECISIONS`).  A rank that
     fails still joins both collectives and every rank raises `RankFailure`.
 
     `compute(alignments, audios) -> list of [1, W] tensors` can replace the
@@ -290,7 +292,8 @@ def from_alignments_and_audios(alignments, audios, sample_rate=16000,
         def compute(shard_alignments, shard_audios):
             return core.from_alignments_and_audios(
                 shard_alignments, shard_audios, sample_rate, checkpoint,
-                batch_size, gpu, config, conv_tile=conv_tile)
+                batch_size, gpu, config, conv_tile=conv_tile,
+                precision=precision)
     counts, failure = [], None
     try:
         lengths = [length_at_16k(audios[i].shape[-1], sample_rate)
@@ -316,7 +319,8 @@ def from_alignments_and_audios(alignments, audios, sample_rate=16000,
 def from_files_to_files(text_files, audio_files, output_prefixes=None,
                         checkpoint=None, batch_size=None, config=None,
                         group=None, utterances_per_batch=256,
-                        conv_tile=CONV_TILE, gather=True, compute=None):
+                        conv_tile=CONV_TILE, gather=True, compute=None,
+                        precision='f32'):
     """`emphases.from_files_to_files` (`core.py:115-179`) over the ranks of a
     process group, one process per GPU.  No rank reads what it does not
     compute:
@@ -402,7 +406,8 @@ def from_files_to_files(text_files, audio_files, output_prefixes=None,
             compute(own_text, own_audio, deliver)
         elif mine:
             from . import core
-            session = core.get_session(checkpoint, gpu, config, conv_tile)
+            session = core.get_session(
+                checkpoint, gpu, config, conv_tile, precision)
             def deliver_batch(opened, chosen, indices, scores):
                 opened.write(
                     chosen, [output_prefixes[mine[i]] for i in indices],

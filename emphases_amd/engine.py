@@ -568,10 +568,14 @@ class Engine:
             return
         begin = torch.cuda.Event(enable_timing=True)
         end = torch.cuda.Event(enable_timing=True)
+        # (with a `runtime.LaunchTimer` armed around the pass: the indices of
+        # this region's launches among the timer's kernel-exact durations)
+        first = self.lib.emph_launch_timer_count()
         begin.record()
         yield
         end.record()
-        self.timers.append((name, flops, begin, end))
+        self.timers.append((name, flops, begin, end, first,
+                            self.lib.emph_launch_timer_count()))
 
     def _buffer(self, name, *shape):
         """Reusable float32 scratch tensor.  Contents are undefined: every
@@ -652,15 +656,16 @@ class Engine:
                 runtime.stream()), 'emph_conv1d')
         return False
 
-    def features(self, audio, plan, meta, tracks=None):
+    def features(self, audio, plan, meta, tracks=None, config=None):
         """Feature matrix [num_features, ld_frames] of every segment
         (`data/preprocess/core.py:71-125`).  The pitch tracker (`penn`, a
         third-party neural network) runs outside the library: `tracks` =
         float32 device tensor [2, ld_frames] with its per-frame pitch (Hz) and
         periodicity on the packed frame axis (`batch.pack_tracks`); the
         log2 / normalisation / row placement of core.py:94-106,123 happens
-        on the device."""
-        config = self.config
+        on the device.  `config`: another configuration's feature switches
+        (`data.preprocess.mels.from_audio` asks for the mel rows alone)."""
+        config = config or self.config
         rows = config.num_features
         out = self._buffer('features', rows, plan.ld_frames)
         mel_row = 0 if config.mel_feature else -1

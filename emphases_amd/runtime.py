@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -42,6 +42,9 @@ SIGNATURES = {
     'emph_abi_version': (_c.c_int, []),
     'emph_last_error': (_c.c_char_p, []),
     'emph_launch_probe': (_c.c_int, [_ptr]),
+    'emph_launch_timer_begin': (_c.c_int, [_i32]),
+    'emph_launch_timer_count': (_i32, []),
+    'emph_launch_timer_end': (_c.c_int, [_ptr, _i32, _ptr]),
     'emph_frontend_table_size': (_i64, []),
     'emph_frontend_table_fill': (_c.c_int, [_ptr]),
     'emph_frontend_block': (_i32, []),
@@ -258,6 +261,39 @@ def stream():
 ###############################################################################
 # Host helpers (no GPU needed)
 ###############################################################################
+
+
+class LaunchTimer:
+    """Kernel-exact durations of the launches the library makes from this
+    thread inside the `with` block (`emph_launch_timer_*`: events bound to each
+    kernel's own dispatch packet - the kernel's begin -> end as rocprofv3 sees
+    it, without the dispatch a pair of recorded events brackets too).
+    `microseconds` (float32 array, launch order) and `launches` are valid after
+    the block; `count()` inside it.  Measurement only."""
+
+    def __init__(self, capacity=4096):
+        self.capacity = int(capacity)
+        self.microseconds = np.zeros(0, dtype=np.float32)
+        self.launches = 0
+
+    def __enter__(self):
+        check(library().emph_launch_timer_begin(self.capacity),
+              'emph_launch_timer_begin')
+        return self
+
+    def count(self):
+        return int(library().emph_launch_timer_count())
+
+    def __exit__(self, kind, value, trace):
+        durations = np.zeros(self.capacity, dtype=np.float32)
+        seen = _i32(0)
+        status = library().emph_launch_timer_end(
+            durations.ctypes.data, self.capacity, _c.byref(seen))
+        if kind is None:
+            check(status, 'emph_launch_timer_end')
+        self.launches = int(seen.value)
+        self.microseconds = durations[:min(self.launches, self.capacity)]
+        return False
 
 
 def frontend_table():

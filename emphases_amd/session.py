@@ -39,7 +39,8 @@ COPY_THREADS = min(64, max(1, int(os.environ.get('EMPHASES_COPY_THREADS', 16))))
 SPLIT_BYTES = int(os.environ.get('EMPHASES_SPLIT_BYTES', 256 << 20))
 # pinned buffers the file API's openers rotate through (`core.files_to_scores`
 # keeps FILE_BUFFERS - 2 batches being opened ahead of the one in flight)
-FILE_BUFFERS = int(os.environ.get("EMPHASES_FILE_BUFFERS", 4))
+# (at least three: the batch in flight, the one finishing, one being opened)
+FILE_BUFFERS = max(3, int(os.environ.get("EMPHASES_FILE_BUFFERS", 4)))
 
 
 def host_float32(audio):

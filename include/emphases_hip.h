@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 27
+#define EMPH_ABI_VERSION 28
 
 /* Segment-table fields */
 enum {
@@ -199,7 +199,8 @@ int64_t emph_plan_tiles(const int64_t* host_counts, const int64_t* host_offsets,
  * (capacity >= sum(counts)): the first *n_words columns are those chunks' words'
  * chunk-relative (start, end) frames.  Returns 0; 1 when the batch has to be
  * planned one utterance at a time (several chunks, a negative duration, a time
- * that is not finite: nothing is written then); < 0 on bad arguments. */
+ * that is not finite or whose frame index reaches 2^52: nothing is written
+ * then); < 0 on bad arguments. */
 int emph_plan_batch(const double* times, const int64_t* counts,
                     const int64_t* lengths, int32_t n_utterances,
                     int64_t sample_rate, int64_t hopsize, int64_t padding,
@@ -919,6 +920,23 @@ int emph_prominence_forward(const emph_conv_model* model, const void* audio,
  * the kernel itself).  No reference counterpart: the reference measures
  * nothing per kernel. */
 int emph_launch_probe(void* stream);
+
+/* Kernel-exact launch timer of the CALLING thread (measurement only; not to be
+ * armed while a stream is being captured).  Between `begin` and `end` every
+ * kernel this library launches from the thread carries its own pair of events
+ * bound to the kernel's dispatch packet (hipExtLaunchKernel): their distance is
+ * the kernel's own begin -> end, the timestamps rocprofv3's kernel trace reads,
+ * without the command processor's dispatch that a pair of RECORDED events
+ * brackets as well.  `emph_launch_timer_count` = launches since `begin` (-1:
+ * no timer armed); `emph_launch_timer_end` waits for the timed launches and
+ * writes their durations in microseconds, in launch order, to
+ * `host_microseconds[0 .. min(count, capacity))`, the number of launches seen
+ * to `host_count`, and disarms.  Launches beyond `capacity` run untimed.  This
+ * is what `bench.py`'s `roofline.avg_launch_us` is measured with.  No
+ * reference counterpart. */
+int emph_launch_timer_begin(int32_t capacity);
+int32_t emph_launch_timer_count(void);
+int emph_launch_timer_end(float* host_microseconds, int32_t capacity, int32_t* host_count);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,11 @@ def variants():
     return np.load(os.path.join(GOLDEN, 'variants.npz'))
 
 
+@pytest.fixture(scope='session')
+def seams():
+    return np.load(os.path.join(GOLDEN, 'seams.npz'))
+
+
 def case_names(archive):
     return sorted({key.split('/')[0] for key in archive.files if '/' in key})
 

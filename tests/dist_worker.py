@@ -17,6 +17,9 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+# (tests/test_gpu_dist.py: the opt-in precisions under N > 1 ranks)
+PRECISION = os.environ.get('EMPHASES_TEST_PRECISION', 'f32')
+
 
 def corpus(count, low, high):
     import emphases_amd
@@ -79,8 +82,10 @@ def files_main(backend, directory, count, out):
             read.extend(os.path.basename(self.audio_files[i]) for i in indices)
             return original_read(self, indices, where, nbytes, destination)
         files.FileBatch.read = tracking_read
-        texts, audios, prefixes = file_lists(directory, count, f'w{world}')
-        scores = edist.from_files_to_files(texts, audios, prefixes)
+        tag = f'w{world}' if PRECISION == 'f32' else f'w{world}_{PRECISION}'
+        texts, audios, prefixes = file_lists(directory, count, tag)
+        scores = edist.from_files_to_files(
+            texts, audios, prefixes, precision=PRECISION)
         torch.save({'scores': [s.cpu() for s in scores], 'read': sorted(read)},
                    out)
     finally:
@@ -107,7 +112,8 @@ def main():
         backend, rank=rank, world_size=world, device_id=device_id)
     try:
         aligns, audios = corpus(int(count), int(low), int(high))
-        scores = edist.from_alignments_and_audios(aligns, audios)
+        scores = edist.from_alignments_and_audios(
+            aligns, audios, precision=PRECISION)
         from emphases_amd import runtime
         runtime.library()          # the native library is what ran
         torch.save({

@@ -14,6 +14,9 @@ Outputs (committed; data only, no reference source):
   tests/golden/variants.npz    config-variant matrix with seeded weights
   tests/golden/metrics.npz     the reference's own evaluate.metrics on seeded
                                ragged batches (`generate.py metrics` = only this)
+  tests/golden/seams.npz       `emphases.segment` and `data.preprocess.from_audio`
+                               / `mels.from_audio` / `loudness.from_audio` on whole
+                               audios (`generate.py seams` = only this)
   emphases_amd/assets/checkpoint.npz   the reference's trained weights
 The GPU box never runs this script; it only reads the .npz files.
 """
@@ -475,11 +478,91 @@ def capture_metrics(out):
 
 
 ###############################################################################
+# The reference-named seams: segment, data.preprocess.from_audio, mels.from_audio
+###############################################################################
+
+
+def capture_seams(out):
+    """`emphases.segment` (core.py:552-586) on seeded padded batches (columns
+    beyond an item's word count repeat its last word, one item's words are
+    one frame long), and `emphases.data.preprocess.from_audio` /
+    `mels.from_audio` / `loudness.from_audio` (data/preprocess/core.py:71-125,
+    mels.py:16-59, loudness.py:84-120) on WHOLE audios - no zero-pad-and-slice
+    in front, unlike `emphases.preprocess` - under the default feature
+    switches, with NORMALIZE, and with the loudness row."""
+    generator = np.random.default_rng(2024)
+    shapes = [(1, 3, 40, [5]), (3, 8, 120, [7, 2, 4]), (2, 80, 300, [12, 1])]
+    for index, (items, channels, frames, words) in enumerate(shapes):
+        width = max(words)
+        xs = generator.normal(0., 1., (items, channels, frames)).astype(np.float32)
+        bounds = np.zeros((items, 2, width), dtype=np.int64)
+        for item, count in enumerate(words):
+            if item == 1:       # one-frame words
+                starts = np.sort(generator.choice(frames - 1, count, replace=False))
+                ends = starts + 1
+            else:
+                edges = np.sort(generator.choice(
+                    np.arange(1, frames), count, replace=False))
+                starts = np.concatenate([[0], edges[:-1]])
+                ends = edges
+            bounds[item, 0, :count], bounds[item, 1, :count] = starts, ends
+        result, result_bounds, result_lengths = emphases.segment(
+            torch.from_numpy(xs), torch.from_numpy(bounds),
+            torch.tensor(words))
+        out[f'segment/{index}/xs'] = xs
+        out[f'segment/{index}/word_bounds'] = bounds
+        out[f'segment/{index}/word_lengths'] = np.array(words, dtype=np.int64)
+        out[f'segment/{index}/result'] = result.numpy()
+        out[f'segment/{index}/result_bounds'] = result_bounds.numpy()
+        out[f'segment/{index}/result_lengths'] = result_lengths.numpy()
+    out['segment/count'] = np.int64(len(shapes))
+    audios = {
+        'noise_1p3s': synth.audio(31, 130)[:, :20731],      # not a multiple of 160
+        'utt_4s': synth.audio(32, 400),
+        'short_433': synth.audio(33, 10)[:, :433]}          # the least reflect padding takes
+    switches = {
+        'default': dict(MEL_FEATURE=True, LOUDNESS_FEATURE=False, NORMALIZE=False),
+        'normalized': dict(MEL_FEATURE=True, LOUDNESS_FEATURE=False, NORMALIZE=True),
+        'mel_loudness': dict(MEL_FEATURE=True, LOUDNESS_FEATURE=True, NORMALIZE=False),
+        'loudness_normalized': dict(
+            MEL_FEATURE=False, LOUDNESS_FEATURE=True, NORMALIZE=True)}
+    saved = {name: getattr(emphases, name)
+             for name in ('MEL_FEATURE', 'LOUDNESS_FEATURE', 'NORMALIZE')}
+    try:
+        for name, audio in audios.items():
+            out[f'audio/{name}'] = audio
+            tensor = torch.from_numpy(audio)
+            for tag, values in switches.items():
+                for key, value in values.items():
+                    setattr(emphases, key, value)
+                out[f'from_audio/{name}/{tag}'] = \
+                    emphases.data.preprocess.from_audio(tensor).numpy()
+                if tag in ('default', 'normalized'):
+                    out[f'mels/{name}/{tag}'] = \
+                        emphases.data.preprocess.mels.from_audio(tensor).numpy()
+                if tag == 'mel_loudness':
+                    out[f'loudness/{name}'] = \
+                        emphases.data.preprocess.loudness.from_audio(
+                            tensor, emphases.SAMPLE_RATE).numpy()
+    finally:
+        for key, value in saved.items():
+            setattr(emphases, key, value)
+    out['audio/names'] = np.array(sorted(audios))
+    out['from_audio/tags'] = np.array(sorted(switches))
+    print('seams:', {k: v.shape for k, v in out.items() if k.startswith('from_audio/')})
+
+
+###############################################################################
 # Entry point
 ###############################################################################
 
 
 def main():
+    seams = {}
+    capture_seams(seams)
+    np.savez_compressed(os.path.join(HERE, 'seams.npz'), **seams)
+    if sys.argv[1:] == ['seams']:
+        return
     measures = {}
     capture_metrics(measures)
     np.savez_compressed(os.path.join(HERE, 'metrics.npz'), **measures)

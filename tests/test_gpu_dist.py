@@ -28,14 +28,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(backend, world, tmp_path, count=COUNT, files=None):
+def _launch(backend, world, tmp_path, count=COUNT, files=None,
+            precision='f32'):
     port = _free_port()
     children = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank),
                    WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
-        out = tmp_path / f'{backend}_{world}_{rank}.pt'
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0',
+                   EMPHASES_TEST_PRECISION=precision)
+        out = tmp_path / f'{backend}_{world}_{rank}_{precision}.pt'
         arguments = [backend, str(count), str(LOW), str(HIGH), str(out)] \
             if files is None else \
             [backend, 'files', str(files), str(count), str(out)]
@@ -246,3 +248,82 @@ def test_sharded_file_api(tmp_path):
     assert all(child.wait(timeout=600) == 0 for child in children)
     for index in range(few):
         assert torch.equal(torch.load(directory / f'cli_{index}.pt'), want[index])
+
+
+@pytest.mark.timeout(1500)
+def test_opt_in_precision_reaches_every_entry_point(tmp_path):
+    """`precision='bf16x3'` through the reference's own entry points
+    (`emphases/core.py:23-179`, `__main__.py:12-46`): the file API's scores are
+    BITWISE the tensor API's at the same precision; two gloo ranks (tensors
+    and files) are bitwise one process; the command line takes `--precision`;
+    and on a slice of BASELINE configs[3] (2-30 s utterances) and a configs[4]
+    long-form utterance (5 minutes, batch_size 3000) the scores stay within
+    1e-5 of the f32 engine's."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import dist_worker
+    from emphases_amd import synth
+    precision, count = 'bf16x3', 60
+    aligns, audios = dist_worker.corpus(count, LOW, HIGH)
+    plain = emphases_amd.from_alignments_and_audios(aligns, audios, gpu=0)
+    want = emphases_amd.from_alignments_and_audios(
+        aligns, audios, gpu=0, precision=precision)
+    worst = max(float((a - b).abs().max()) for a, b in zip(plain, want))
+    assert 0. < worst < 1e-5, worst
+    # one utterance through from_alignment_and_audio: the same bits
+    alone = emphases_amd.from_alignment_and_audio(
+        aligns[7], audios[7], 16000, gpu=0, precision=precision)
+    assert torch.equal(alone, want[7])
+    # configs[4]: 5 minutes chunked at 3000 frames
+    long_audio = torch.from_numpy(synth.audio(7100, 30000))
+    long_words = emphases_amd.Alignment.from_frames(
+        synth.word_frames(9000, 30000))
+    a = emphases_amd.from_alignment_and_audio(
+        long_words, long_audio, 16000, batch_size=3000, gpu=0)
+    b = emphases_amd.from_alignment_and_audio(
+        long_words, long_audio, 16000, batch_size=3000, gpu=0,
+        precision=precision)
+    assert a.shape == b.shape and 0. < float((a - b).abs().max()) < 1e-5
+    # two ranks, tensors in memory
+    results = _launch('gloo', 2, tmp_path, count=count, precision=precision)
+    for result in results:
+        for got, expect in zip(result['scores'], want):
+            assert torch.equal(got, expect.cpu())
+    # files: one process == from_file per file == two ranks == the command line
+    directory = tmp_path / 'corpus'
+    directory.mkdir()
+    dist_worker.write_files(str(directory), count)
+    texts, waves, prefixes = dist_worker.file_lists(
+        str(directory), count, 'single')
+    emphases_amd.from_files_to_files(
+        texts, waves, prefixes, gpu=0, precision=precision)
+    saved = [torch.load(f'{prefix}.pt') for prefix in prefixes]
+    for index in (0, 3, 5, 16, count - 1):      # 16 kHz, 8 kHz, 22.05 kHz files
+        one = emphases_amd.from_file(
+            texts[index], waves[index], gpu=0, precision=precision)
+        assert torch.equal(one.cpu(), saved[index])
+    emphases_amd.from_file_to_file(
+        texts[1], waves[1], str(directory / 'one'), gpu=0, precision=precision)
+    assert torch.equal(torch.load(directory / 'one.pt'), saved[1])
+    f32_prefixes = [str(directory / f'f32_{i}') for i in range(count)]
+    emphases_amd.from_files_to_files(texts, waves, f32_prefixes, gpu=0)
+    differences = [float((torch.load(f'{p}.pt') - s).abs().max())
+                   for p, s in zip(f32_prefixes, saved)]
+    assert 0. < max(differences) < 1e-5
+    results = _launch('gloo', 2, tmp_path, count=count, files=directory,
+                      precision=precision)
+    for result in results:
+        for got, expect in zip(result['scores'], saved):
+            assert torch.equal(got, expect)
+    for index in range(count):
+        assert torch.equal(
+            torch.load(directory / f'w2_{precision}_{index}.pt'), saved[index])
+    few = 12
+    child = subprocess.run(
+        [sys.executable, '-m', 'emphases_amd', '--text_files', *texts[:few],
+         '--audio_files', *waves[:few], '--output_prefixes',
+         *[str(directory / f'cli_{i}') for i in range(few)], '--gpu', '0',
+         '--precision', precision], cwd=ROOT, timeout=600)
+    assert child.returncode == 0
+    for index in range(few):
+        assert torch.equal(
+            torch.load(directory / f'cli_{index}.pt'), saved[index])

@@ -1361,3 +1361,90 @@ def test_one_resampler_for_every_entry_point(rate):
     from emphases_amd import load
     assert 'conv1d' not in inspect.getsource(load)
     assert not hasattr(load, 'resample')
+
+
+###############################################################################
+# The reference-named seams: segment, data.preprocess.from_audio, mels.from_audio
+###############################################################################
+
+
+def test_segment_matches_reference(seams):
+    """`emphases.segment` (core.py:552-586) run by tests/golden/generate.py:
+    bit for bit (a gather), device tensors in -> device tensors out, host in ->
+    host out; columns beyond an item's words repeat its last word."""
+    import emphases_amd as emphases
+    for index in range(int(seams['segment/count'])):
+        xs = torch.from_numpy(seams[f'segment/{index}/xs'])
+        bounds = torch.from_numpy(seams[f'segment/{index}/word_bounds'])
+        lengths = torch.from_numpy(seams[f'segment/{index}/word_lengths'])
+        for device in ('cpu', 'cuda'):
+            result, result_bounds, result_lengths = emphases.segment(
+                xs.to(device), bounds.to(device), lengths.to(device))
+            assert result.device.type == device
+            assert result_bounds.device.type == device
+            assert result.dtype == torch.float32
+            assert result_bounds.dtype == result_lengths.dtype == torch.long
+            assert np.array_equal(
+                result.cpu().numpy(), seams[f'segment/{index}/result'])
+            assert np.array_equal(
+                result_bounds.cpu().numpy(),
+                seams[f'segment/{index}/result_bounds'])
+            assert np.array_equal(
+                result_lengths.cpu().numpy(),
+                seams[f'segment/{index}/result_lengths'])
+    with pytest.raises(ValueError, match='outside'):
+        emphases.segment(torch.zeros(1, 2, 10),
+                         torch.tensor([[[0], [11]]]), torch.tensor([1]))
+
+
+def test_preprocess_from_audio_matches_reference(seams):
+    """`emphases.data.preprocess.from_audio(audio, gpu)` -> [1, NF, F],
+    `.mels.from_audio(audio)` -> [80, F] and `.loudness.from_audio(audio)` ->
+    [1, F] on whole audios, under the reference's feature switches
+    (data/preprocess/core.py:71-125, mels.py:16-59, loudness.py:84-120),
+    against reference-run goldens and against the oracle's `features` (what
+    `oracle.forward` takes at the `input` location)."""
+    import emphases_amd as emphases
+    switches = {
+        'default': {}, 'normalized': {'normalize': True},
+        'mel_loudness': {'loudness_feature': True},
+        'loudness_normalized': {'mel_feature': False, 'loudness_feature': True,
+                                'normalize': True}}
+    try:
+        for name in seams['audio/names']:
+            audio = torch.from_numpy(seams[f'audio/{name}'])
+            for tag, overrides in switches.items():
+                emphases.configure(**overrides)
+                want = seams[f'from_audio/{name}/{tag}']
+                got = emphases.data.preprocess.from_audio(audio)
+                assert got.device.type == 'cpu' and got.dtype == torch.float32
+                on_device = emphases.data.preprocess.from_audio(audio, gpu=0)
+                assert on_device.device.type == 'cuda'
+                assert torch.equal(on_device.cpu(), got)
+                assert tuple(got.shape) == want.shape
+                mels = 80 if overrides.get('mel_feature', True) else 0
+                reference = oracle.features(audio, overrides).numpy()
+                for other in (want, reference):
+                    np.testing.assert_allclose(
+                        got.numpy()[:, :mels], other[:, :mels], rtol=0,
+                        atol=2e-5)
+                    if overrides.get('loudness_feature'):
+                        tolerance = 2e-5 if overrides.get('normalize') else 1e-3
+                        np.testing.assert_allclose(
+                            got.numpy()[:, -1], other[:, -1], rtol=0,
+                            atol=tolerance)
+                if mels:
+                    mel = emphases.data.preprocess.mels.from_audio(audio)
+                    assert tuple(mel.shape) == (80, want.shape[2])
+                    assert torch.equal(mel, got[0, :80])
+                    assert emphases.data.preprocess.mels.from_audio(
+                        audio.cuda()).is_cuda
+                if overrides.get('loudness_feature'):
+                    loud = emphases.data.preprocess.loudness.from_audio(
+                        audio, emphases.SAMPLE_RATE)
+                    assert torch.equal(loud, got[0, -1:])
+    finally:
+        emphases.configure(emphases.DEFAULT)
+    # reflect padding of 432 needs more than 432 samples (mels.py:31-36)
+    with pytest.raises(RuntimeError, match='432'):
+        emphases.data.preprocess.mels.from_audio(torch.zeros(1, 432))

@@ -1198,9 +1198,16 @@ def test_plan_batch_of_the_library_matches_numpy_and_the_chunker():
             assert np.array_equal(getattr(plan, name), getattr(slow, name)), name
         assert (plan.ld_frames, plan.ld_words) == (slow.ld_frames, slow.ld_words)
     # what the one pass must hand back to the chunker
-    for spoil in ('chunks', 'negative', 'nan'):
+    for spoil in ('chunks', 'negative', 'nan', 'huge'):
         changed = [t.copy() for t in tables]
         big = int(np.argmax(counts))
+        if spoil == 'huge':
+            # finite, but its frame index is beyond 2^52 (a corrupt TextGrid): the
+            # library must not cast it (undefined behaviour; UBSan float-cast-overflow)
+            changed[big][-1, 1] = 1e300
+            spoiled = np.concatenate(changed)
+            assert batch._plan_columns(spoiled, counts, lengths) is None
+            continue
         if spoil == 'chunks':       # words that outlast the audio's frames
             changed[big][:, 1] += 30.0
             changed[big][1:, 0] += 30.0
@@ -1448,3 +1455,108 @@ def test_split_kv_scratch_sizes_and_piece_codes():
             slots * 2 * (pk * key + pv * value)
     assert lib.emph_split_kv_bytes(ld, segments, 80, 2, 4) == -1      # no such split
     assert lib.emph_split_kv_bytes(ld, segments, 64, 2, 2) == -1      # head dimension 32
+
+
+def test_bench_line_stays_under_the_driver_limit(tmp_path, monkeypatch):
+    """The contract's ONE line: whatever the side measurements hold (every
+    record present, each far larger than life), `bench.compact_line` + `emit`
+    stay under 10 KB - round 5's 25 KB line was not parsed by the driver - and
+    the full record goes to the side-records file the line names (sha256)."""
+    import io
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    fat = {f'field_{i}': 'x' * 200 for i in range(40)}
+    roof = {key: 0.123456789012345 for key in bench.ROOFLINE_KEYS}
+    roof.update(bound='mfma', kernel='conv1d_stack_frames_80x80_k3',
+                unit='TFLOP/s', traffic=50049626, executed=fat,
+                avg_launch_us_source='kernel-exact events, this run',
+                rocprof_file='profiles/r6_bench_kernel_stats_1stream.csv',
+                traffic_source='profiles/r6_pmc_summary.json')
+    entry = dict(fat, ms_per_step=1.234567890123, utterances_per_s=1e5,
+                 max_abs_dscore_vs_f32=1e-6, roofline=dict(roof))
+    result = {
+        'metric': 'utterances/s (10 s @16 kHz) whole-node',
+        'value': 436123.4567890123, 'unit': 'utterances/s', 'n_gpus': 1,
+        'steps': 200, 'warmup': 20, 'ms_per_step': 0.14712345678901,
+        'ms_per_step_min': 0.1461234567890, 'ms_per_step_max': 0.1491234567,
+        'timed_region_s': 0.0293456789012, 'regions': 9, 'timing': 'x' * 300,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'w' * 200, 'utterances_per_gpu': 64,
+                   'parallelism': 'utterance-sharded x1', 'exchange': 'e' * 120},
+        'frames_per_s_per_gpu': 4.36e8, 'checksum': 123.456,
+        'roofline': roof, 'from_profiles': fat, 'kernels_us_rocprof': fat,
+        'end_to_end': {'mfma_frac': 0.5, 'hbm_frac_compulsory': 0.03},
+        'cpu_baseline': dict(fat, value=2098.5, unit='utterances/s', cores=16,
+                             kind='port', sample='s' * 300, cpu='c' * 40,
+                             cgroup_cpu_quota=16.0, physical_cores=128,
+                             threads={'1': 185.5}),
+        'end_to_end_api': {'float32': dict(fat, utterances_per_s_pipelined=7e4),
+                           'pcm16': dict(fat, utterances_per_s_pipelined=1e5)},
+        'single_utterance_api': {'default': {'ms_p50': 0.4, 'ms_p99': 0.6},
+                                 'conv_tile_auto': {'ms_p50': 0.3},
+                                 'oracle_1_core_ms': 5.4},
+        'files_api': dict(fat, files_per_s=8e4),
+        'configs_1_conv_bf16x3': entry, 'configs_2_transformer': entry,
+        'configs_2_transformer_bf16x3': entry,
+        'configs_2_transformer_bf16x3_fast': entry,
+        'configs_2_transformer_bf16x6': {'error': 'RuntimeError("boom")'},
+        'configs_3_corpus': {
+            'rank0_of_8_device_only': dict(fat, utterances_per_s=2e5,
+                                           frames_per_s=4e8),
+            'whole_corpus_device_only': dict(fat, utterances_per_s=2e5)},
+        'configs_4_longform': {'device_only': dict(fat, frames_per_s=4e8),
+                               'api_pcm16': dict(fat, frames_per_s=1e8)},
+        'configs_3_corpus_sharded': dict(fat, utterances_per_s=1e6,
+                                         ms_per_step=9.),
+        'configs_4_longform_sharded': dict(fat, utterances_per_s=1e4,
+                                           ms_per_step=6.),
+        'job': dict(fat, utterances=10000, frames=16000000, scores=480000,
+                    checksum=1.5, frames_per_rank=[2000000] * 8,
+                    lpt_imbalance=1.0001,
+                    compute_only_ms_per_rank=[4.777123456789] * 8)}
+    assert len(json.dumps(result)) > 50000
+    line = bench.compact_line(result)
+    assert len(json.dumps(line)) < 7000
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup',
+                'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline',
+                'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in line, key
+    assert line['value'] == result['value']             # (not rounded)
+    for key in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert key in line['roofline'], key
+    for key in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert key in line['cpu_baseline'], key
+    side = line['side']
+    assert side['bf16x3_ms_per_step'] == 1.23457
+    assert side['single_utterance_ms_p50'] == 0.4
+    assert side['configs_3_sharded_utterances_per_s'] == 1e6
+    assert side['failed'] == ['configs_2_transformer_bf16x6']
+    assert len(line['job']['frames_per_rank']) == 8
+    # ... and through emit(): one line, the side file it names
+    out = io.StringIO()
+    monkeypatch.setattr(bench, 'LINE_OUT', out)
+    monkeypatch.setattr(sys, 'argv', [
+        'bench.py', '--side-records', str(tmp_path / 'side.json')])
+    args = bench.parse_args()
+    bench.emit(result, args)
+    text = out.getvalue()
+    assert text.count('\n') == 1 and len(text) < bench.LINE_LIMIT
+    printed = json.loads(text)
+    with open(tmp_path / 'side.json', 'rb') as file:
+        data = file.read()
+    assert printed['side_records']['sha256'] == hashlib.sha256(data).hexdigest()
+    assert printed['side_records']['bytes'] == len(data)
+    full = json.loads(data)
+    assert full['files_api']['field_3'] == 'x' * 200
+    assert 'frac' in full['notes']['roofline']
+    # the default name of the file follows the command
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--config', 'transformer',
+                                      '--precision', 'bf16x3'])
+    assert os.path.basename(bench.side_path(bench.parse_args())) == \
+        'bench_side_transformer_bf16x3.json'
+    monkeypatch.setattr(sys, 'argv', ['bench.py'])
+    assert bench.side_path(bench.parse_args()) == \
+        os.path.join(ROOT, 'bench_side.json')

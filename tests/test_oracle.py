@@ -288,3 +288,32 @@ def test_metrics_restatement_matches_reference(loss):
     np.testing.assert_allclose(
         [got['pearson_correlation'], got['bce'], got['mse']],
         golden[f'{loss}/result'], rtol=2e-6, atol=1e-7)
+
+
+def test_whole_audio_features_match_reference(seams):
+    """`data.preprocess.from_audio` / `mels.from_audio` / `loudness.from_audio`
+    of the reference on WHOLE audios (tests/golden/generate.py seams; no
+    zero-pad-and-slice in front) against the oracle's restatement."""
+    switches = {
+        'default': {}, 'normalized': {'normalize': True},
+        'mel_loudness': {'loudness_feature': True},
+        'loudness_normalized': {'mel_feature': False, 'loudness_feature': True,
+                                'normalize': True}}
+    for name in seams['audio/names']:
+        audio = torch.from_numpy(seams[f'audio/{name}'])
+        for tag, overrides in switches.items():
+            want = seams[f'from_audio/{name}/{tag}']
+            got = oracle.features(audio, overrides).numpy()
+            assert got.shape == want.shape
+            mels = 80 if overrides.get('mel_feature', True) else 0
+            np.testing.assert_allclose(
+                got[:, :mels], want[:, :mels], rtol=0, atol=1e-5)
+            if overrides.get('loudness_feature'):
+                tolerance = 2e-5 if overrides.get('normalize') else 1e-3
+                np.testing.assert_allclose(
+                    got[:, -1], want[:, -1], rtol=0, atol=tolerance)
+        np.testing.assert_array_equal(
+            seams[f'mels/{name}/default'], seams[f'from_audio/{name}/default'][0])
+        np.testing.assert_array_equal(
+            seams[f'loudness/{name}'],
+            seams[f'from_audio/{name}/mel_loudness'][0, 80:])
