@@ -825,12 +825,13 @@ class Engine:
         if ('tiles', axis, 32) + select in meta:
             split_tiles = meta[('tiles', axis, 32) + select]
         projected_ahead = False     # this layer's Q, K, V came out of the last block
-        for layer in layers:
+        images_ahead = False        # ... its K and V as the attention's split images
+        for index, layer in enumerate(layers):
             split = layer['block_split'] is not None and \
                 split_tiles is not None and block <= 32
             images_written = False
             if projected_ahead:
-                pass
+                images_written = images_ahead
             elif split:
                 packs, bias = layer['qkv_split']
                 tiles, size = split_tiles
@@ -871,6 +872,28 @@ class Engine:
             projected_ahead = False
             with self._timed(f'attention_{tag}', attention_flops):
                 attend(images_written)
+            following = layers[index + 1] if index + 1 < len(layers) else None
+            if split and following is not None and self.fuse_qkv and \
+                    following['block_split'] is not None:
+                # ... and the NEXT layer's projections in the same launch (attention
+                # has consumed qk / v / the images: the next layer's go there)
+                packs, vectors = layer['block_split']
+                next_packs, next_bias = following['qkv_split']
+                tiles, size = split_tiles
+                with self._timed(f'transformer_block_qkv_split_{tag}', 12. *
+                                 channels * channels * meta['positions'][axis]):
+                    runtime.check(self.lib.emph_transformer_block_qkv_split(
+                        attended.data_ptr(), x.data_ptr(), ld, channels,
+                        config.heads, packs.data_ptr(), next_packs.data_ptr(),
+                        self.linear_pieces, self.attention_pieces,
+                        vectors.data_ptr(), next_bias.data_ptr(),
+                        config.layer_norm_eps, runtime.ACTIVATIONS['relu'],
+                        tiles.data_ptr(), size // runtime.TILE_FIELDS, 32,
+                        qk.data_ptr(), v.data_ptr(),
+                        split_images.data_ptr() if projected_images else None,
+                        runtime.stream()), 'emph_transformer_block_qkv_split')
+                projected_ahead, images_ahead = True, projected_images
+                continue
             if split:
                 packs, vectors = layer['block_split']
                 tiles, size = split_tiles

@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -117,6 +117,9 @@ SIGNATURES = {
     'emph_transformer_block_split': (_c.c_int, [
         _ptr, _ptr, _i64, _i32, _ptr, _i32, _ptr, _c.c_float, _i32, _ptr, _i32,
         _i32, _ptr]),
+    'emph_transformer_block_qkv_split': (_c.c_int, [
+        _ptr, _ptr, _i64, _i32, _i32, _ptr, _ptr, _i32, _i32, _ptr, _ptr,
+        _c.c_float, _i32, _ptr, _i32, _i32, _ptr, _ptr, _ptr, _ptr]),
     'emph_qkv_projection_split': (_c.c_int, [
         _ptr, _i64, _ptr, _ptr, _i32, _ptr, _i32, _ptr, _ptr, _i32, _i32,
         _ptr]),

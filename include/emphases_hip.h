@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 28
+#define EMPH_ABI_VERSION 29
 
 /* Segment-table fields */
 enum {
@@ -747,6 +747,26 @@ int emph_qkv_projection_split(const float* x, int64_t ld, float* qk, float* v,
                               int32_t pieces, const float* bias,
                               const int32_t* tiles, int32_t n_tiles,
                               int32_t tile_n, void* stream);
+/* emph_transformer_block_split and the NEXT layer's emph_qkv_projection_split
+ * (images == NULL: qk and v) or emph_qkv_projection_split_images (images != NULL: Q
+ * into qk's first 80 rows and the K / V images for `attention_pieces`, v unused) as
+ * ONE launch - the split counterpart of emph_transformer_block_qkv.  The layer's
+ * output is split in the registers it is normalised in: x is written (the next
+ * block's residual) but not read again; the six weight packs stream through a ring
+ * of three LDS slots.  Results are bit for bit those of the two entries in a row.
+ * Replaces the tail of one nn.TransformerEncoderLayer and the in_proj of the next
+ * (emphases/model/layers/transformer.py:18-30).
+ *   block_packs / vectors   as emph_transformer_block_split
+ *   qkv_packs / qkv_bias    the next layer's, as emph_qkv_projection_split */
+int emph_transformer_block_qkv_split(const float* attended, float* x, int64_t ld,
+                                     int32_t channels, int32_t heads,
+                                     const void* block_packs, const void* qkv_packs,
+                                     int32_t pieces, int32_t attention_pieces,
+                                     const float* vectors, const float* qkv_bias,
+                                     float eps, int32_t activation,
+                                     const int32_t* tiles, int32_t n_tiles,
+                                     int32_t tile_n, float* qk, float* v,
+                                     void* images, void* stream);
 /* ... with K and V written straight as the images emph_attention_split stages
  * (what emph_split_kv would make of qk / v: no fp32 K and V, no second pass): Q
  * into qk's first 80 rows (the K rows are left alone), `images` sized by

@@ -1116,6 +1116,114 @@ def test_qkv_projection_split_images(pieces, attention_pieces):
             assert np.abs(a - b).max() < 2e-6
 
 
+@pytest.mark.parametrize('pieces,attention_pieces', [
+    (3, 32), (2, 32), (3, 3), (2, 2), (3, None), (2, None)])
+def test_transformer_block_qkv_split(pieces, attention_pieces):
+    """emph_transformer_block_qkv_split = emph_transformer_block_split followed by
+    the next layer's emph_qkv_projection_split (attention_pieces None) or
+    emph_qkv_projection_split_images, BIT FOR BIT: x, Q, K, V / the images - on a
+    ragged axis with more tiles than one round of the grid's waves, segments ending
+    anywhere in a stage, NaN between the segments."""
+    lib = runtime.library()
+    channels, heads, tile = 80, 2, 32
+    plan = ragged_plan([200, 1, 17, 33, 700, 64, 32, 96, 321] + [1000] * 40)
+    axis = runtime.AXIS_FRAMES
+    meta = Meta(plan, [(axis, tile)])
+    ld = plan.ld_frames
+    x = random_packed(channels, plan, axis, 21)
+    attended = random_packed(channels, plan, axis, 22)
+    padding = torch.ones(ld, dtype=torch.bool)
+    for off, count in spans(plan, axis):
+        padding[off:off + count] = False
+    x[:, padding] = float('nan')
+    names = ['out', 'l1', 'l2']
+    weight = {n: torch.from_numpy(synth.weights(30 + i, (channels, channels), 0.3))
+              for i, n in enumerate(names)}
+    order = ['b_o', 'g1', 'be1', 'b_1', 'b_2', 'g2', 'be2']
+    vector = {n: torch.from_numpy(synth.weights(40 + i, (channels,), 0.5))
+              for i, n in enumerate(order)}
+    vector['g1'] += 1.
+    vector['g2'] += 1.
+    block_packs = torch.from_numpy(np.concatenate([
+        runtime.linear_split_pack(weight[n].numpy(), pieces)
+        for n in names])).to(DEVICE)
+    vectors = torch.cat([vector[n] for n in order]).to(DEVICE)
+    in_proj = torch.from_numpy(synth.weights(6, (3 * channels, channels), 0.3))
+    bias = torch.from_numpy(synth.weights(7, (3 * channels,), 0.5)).to(DEVICE)
+    qkv_packs = torch.from_numpy(np.concatenate([
+        runtime.linear_split_pack(
+            in_proj[part * channels:(part + 1) * channels].numpy(), pieces)
+        for part in range(3)])).to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    attended_dev = attended.to(DEVICE)
+    image_bytes = 0 if attention_pieces is None else lib.emph_split_kv_bytes(
+        ld, len(plan.segments), channels, heads, attention_pieces)
+
+    def buffers():
+        return (x.to(DEVICE), torch.full((2 * channels, ld), 7.0, device=DEVICE),
+                torch.full((ld, channels), 7.0, device=DEVICE),
+                torch.full((max(image_bytes // 2, 8),), 0x5555, dtype=torch.int16,
+                           device=DEVICE))
+    # two launches
+    x_two, qk_two, v_two, images_two = buffers()
+    runtime.check(lib.emph_transformer_block_split(
+        attended_dev.data_ptr(), x_two.data_ptr(), ld, channels,
+        block_packs.data_ptr(), pieces, vectors.data_ptr(), 1e-5, 1,
+        tiles.data_ptr(), size // 4, tile, None), 'emph_transformer_block_split')
+    if attention_pieces is None:
+        runtime.check(lib.emph_qkv_projection_split(
+            x_two.data_ptr(), ld, qk_two.data_ptr(), v_two.data_ptr(), channels,
+            qkv_packs.data_ptr(), pieces, bias.data_ptr(), tiles.data_ptr(),
+            size // 4, tile, None), 'emph_qkv_projection_split')
+    else:
+        runtime.check(lib.emph_qkv_projection_split_images(
+            x_two.data_ptr(), ld, qk_two.data_ptr(), images_two.data_ptr(),
+            channels, heads, qkv_packs.data_ptr(), pieces, attention_pieces,
+            bias.data_ptr(), tiles.data_ptr(), size // 4, tile, None),
+            'emph_qkv_projection_split_images')
+    # one launch
+    x_one, qk_one, v_one, images_one = buffers()
+    runtime.check(lib.emph_transformer_block_qkv_split(
+        attended_dev.data_ptr(), x_one.data_ptr(), ld, channels, heads,
+        block_packs.data_ptr(), qkv_packs.data_ptr(), pieces,
+        attention_pieces or 0, vectors.data_ptr(), bias.data_ptr(), 1e-5, 1,
+        tiles.data_ptr(), size // 4, tile, qk_one.data_ptr(), v_one.data_ptr(),
+        None if attention_pieces is None else images_one.data_ptr(), None),
+        'emph_transformer_block_qkv_split')
+    torch.cuda.synchronize()
+    live = ~padding
+    assert torch.equal(x_one.cpu()[:, live], x_two.cpu()[:, live])
+    assert torch.isnan(x_one.cpu()[:, padding]).all()      # padding untouched
+    assert torch.equal(qk_one, qk_two)
+    assert torch.equal(v_one, v_two)
+    assert torch.equal(images_one, images_two)
+    assert not torch.isnan(qk_one[:channels].cpu()[:, live]).any()
+    if attention_pieces is None:
+        assert float(v_one.cpu()[live].min()) != 7.0
+    else:
+        assert float(qk_one[channels:].min()) == 7.0       # K's rows: not touched
+        assert float(v_one.min()) == 7.0
+    # a handful of tiles (fewer than the waves of one workgroup) and none at all
+    few = 3
+    x_few, qk_few, v_few, images_few = buffers()
+    runtime.check(lib.emph_transformer_block_qkv_split(
+        attended_dev.data_ptr(), x_few.data_ptr(), ld, channels, heads,
+        block_packs.data_ptr(), qkv_packs.data_ptr(), pieces,
+        attention_pieces or 0, vectors.data_ptr(), bias.data_ptr(), 1e-5, 1,
+        tiles.data_ptr(), few, tile, qk_few.data_ptr(), v_few.data_ptr(),
+        None if attention_pieces is None else images_few.data_ptr(), None),
+        'emph_transformer_block_qkv_split')
+    first = plan.frame_off[0]
+    assert torch.equal(x_few[:, first:first + 96], x_one[:, first:first + 96])
+    assert torch.equal(qk_few[:channels, first:first + 96],
+                       qk_one[:channels, first:first + 96])
+    assert lib.emph_transformer_block_qkv_split(
+        attended_dev.data_ptr(), x_few.data_ptr(), ld, channels, heads,
+        block_packs.data_ptr(), qkv_packs.data_ptr(), pieces, 0,
+        vectors.data_ptr(), bias.data_ptr(), 1e-5, 1, tiles.data_ptr(), 0, tile,
+        qk_few.data_ptr(), v_few.data_ptr(), None, None) == 0
+
+
 ###############################################################################
 # feature rows
 ###############################################################################

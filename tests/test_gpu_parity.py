@@ -1436,7 +1436,12 @@ def test_preprocess_from_audio_matches_reference(seams):
                 if mels:
                     mel = emphases.data.preprocess.mels.from_audio(audio)
                     assert tuple(mel.shape) == (80, want.shape[2])
-                    assert torch.equal(mel, got[0, :80])
+                    # (the same kernel; with the loudness row beside them the mel
+                    # rows come out of another instantiation of it)
+                    gap = float((mel - got[0, :80]).abs().max())
+                    assert gap == 0. or (
+                        overrides.get('loudness_feature') and gap < 2e-6), \
+                        (name, tag, gap)
                     assert emphases.data.preprocess.mels.from_audio(
                         audio.cuda()).is_cuda
                 if overrides.get('loudness_feature'):
