@@ -155,8 +155,9 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
     constexpr int UNITS = Images::kStageBytes / 16;       // 16-byte units of a stage
     constexpr int PASSES = (UNITS + THREADS - 1) / THREADS;
     static_assert(PASSES >= 3 && PASSES <= 5, "the s_waitcnt below count the requests");
-    static_assert(D % 8 == 0 && D % 16 != 0 && D > 32 && D <= 62,
-                  "two m-tiles of 32 rows, a spare row for the ones, a spare d for the reference");
+    static_assert(D % 8 == 0 && D % 16 != 0 && D > 32 && D + 2 <= 48,
+                  "an m-tile of 32 rows and a tail of 16 with a spare row for the ones, a spare d "
+                  "for the reference");
     extern __shared__ __align__(16) unsigned char split_lds[];
 
     const int tid = threadIdx.x;
@@ -246,11 +247,13 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
         for (int piece = 0; piece < PK; ++piece)
             if (half == (D % 16) / 8) bq[KSTEPS - 1][piece][(D % 8) / 2] = parts[piece];
     };
-    f32x16 o[2];
+    // O^T: rows 0 .. 31 in the 32 x 32 layout; rows 32 .. 47 as two 16 x 16 tiles (queries
+    // 0 .. 15 and 16 .. 31 of the wave: lane l holds query 16 q + l % 16, rows 32 + 4 (l / 16) + i)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x16 o;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[m][r] = 0.f;
+    for (int r = 0; r < 16; ++r) o[r] = 0.f;
+    f32x4 o_tail[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     float reference = 0.f;
 
     // S^T - reference of one block of 32 keys: A fragments of K (lane = key, half), the
@@ -270,25 +273,33 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
         }
         return s16;
     };
-    // V fragments of a block: rows 32 m + column, the eight keys 16 ks + 8 half ..
-    auto values = [&](int buffer, int local, u32x4 (&av)[2][2][PV]) {
+    // V fragments of a block.  Rows 0 .. 31 of V^T: row `column`, the eight keys 16 ks +
+    // 8 half .. of k-step ks (v_mfma_f32_32x32x16_bf16).  Rows 32 .. 47 - d 32 .. D - 1, the
+    // row of ones, the shared row of zeros - are ONE 16-row tile of v_mfma_f32_16x16x32_bf16
+    // (all 32 keys of the block per instruction, 16 queries): lane (row 32 + l % 16, group
+    // g = l / 16) reads the eight keys of (k-step g % 2, half g / 2), which is where the
+    // swapped probabilities of `attend` put them.
+    auto values = [&](int buffer, int local, u32x4 (&av)[2][PV], u32x4 (&tail)[PV]) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int row = min(32 * m + column, D + 1);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int piece = 0; piece < PV; ++piece)
+                av[ks][piece] = *reinterpret_cast<const u32x4*>(
+                    value_image(buffer, piece) +
+                    (((local >> 3) + 2 * ks + half) * Images::kRows + column) * 16);
+        const int group = lane >> 4;
+        const int row = min(32 + (lane & 15), D + 1);
 #pragma unroll
-                for (int piece = 0; piece < PV; ++piece)
-                    av[m][ks][piece] = *reinterpret_cast<const u32x4*>(
-                        value_image(buffer, piece) +
-                        (((local >> 3) + 2 * ks + half) * Images::kRows + row) * 16);
-        }
+        for (int piece = 0; piece < PV; ++piece)
+            tail[piece] = *reinterpret_cast<const u32x4*>(
+                value_image(buffer, piece) +
+                (((local >> 3) + 2 * (group & 1) + (group >> 1)) * Images::kRows + row) * 16);
     };
     // softmax numerators of a block's scores and their product with the values
     // (`pending`: the scores of the NEXT block, already issued against the reference as
     // it stands - when the reference moves they move with it)
-    auto attend = [&](f32x16 s16, f32x16& pending, const u32x4 (&av)[2][2][PV], int key0,
-                      bool masked) {
+    auto attend = [&](f32x16 s16, f32x16& pending, const u32x4 (&av)[2][PV],
+                      const u32x4 (&tail)[PV], int key0, bool masked) {
         SPLIT_STAMP(1);
         if (masked) {                     // wave-uniform: a segment's last block only
             asm volatile("" ::: "memory");
@@ -307,9 +318,14 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
             const float shift = fmaxf(fmaxf(top, __shfl_xor(top, 32)), 0.f);
             const float alpha = __builtin_amdgcn_exp2f(-shift);
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+            // (the tail tiles hold other queries than the lane's own: 16 q + lane % 16)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
+            for (int q = 0; q < 2; ++q) {
+                const float alpha_q = __shfl(alpha, 16 * q + (lane & 15));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o_tail[q][i] *= alpha_q;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) s16[r] -= shift;
 #pragma unroll
@@ -327,9 +343,30 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
         }
         SPLIT_STAMP(3);                   // probabilities split
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks) o = split_product<PV>(av[ks], bp[ks], o);
+        // the tail tile's B operands: v_permlane16_swap trades lanes 16 .. 31 (48 .. 63) of
+        // k-step 0's fragment with lanes 0 .. 15 (32 .. 47) of k-step 1's - afterwards the
+        // first holds queries 0 .. 15, the second queries 16 .. 31, each with the keys of
+        // (k-step g % 2, half g / 2) in lane group g
+        u32x4 bt[2][PV];
 #pragma unroll
-            for (int m = 0; m < 2; ++m) o[m] = split_product<PV>(av[m][ks], bp[ks], o[m]);
+        for (int piece = 0; piece < PV; ++piece)
+#pragma unroll
+            for (int word = 0; word < 4; ++word) {
+                const auto pair = __builtin_amdgcn_permlane16_swap(bp[0][piece][word],
+                                                                   bp[1][piece][word], false, false);
+                bt[0][piece][word] = pair[0];
+                bt[1][piece][word] = pair[1];
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int order = PV - 1; order >= 0; --order)       // the smallest products first
+#pragma unroll
+                for (int i = 0; i <= order; ++i)
+                    o_tail[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, tail[i]),
+                        __builtin_bit_cast(bf16x8, bt[q][order - i]), o_tail[q], 0, 0, 0);
         SPLIT_STAMP(4);                   // O^T issued
     };
     // the next stage for every wave: this wave's share has landed (all but the newest
@@ -390,8 +427,8 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
         const int keys = min(STAGE, length - key_base);
         {
             SPLIT_STAMP(0);
-            u32x4 av[2][2][PV];
-            values(buffer, 0, av);
+            u32x4 av[2][PV], tail[PV];
+            values(buffer, 0, av, tail);
             f32x16 next = current;
             if (keys > 32) {
                 next = scores(buffer, 32);
@@ -399,19 +436,19 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
                 next_stage();
                 next = scores(following, 0);
             }
-            attend(current, next, av, key_base, keys < 32);
+            attend(current, next, av, tail, key_base, keys < 32);
             current = next;
         }
         if (keys > 32) {
             SPLIT_STAMP(0);
-            u32x4 av[2][2][PV];
-            values(buffer, 32, av);
+            u32x4 av[2][PV], tail[PV];
+            values(buffer, 32, av, tail);
             f32x16 next = current;
             if (more) {
                 next_stage();
                 next = scores(following, 0);
             }
-            attend(current, next, av, key_base + 32, keys < 64);
+            attend(current, next, av, tail, key_base + 32, keys < 64);
             current = next;
         }
     }
@@ -423,19 +460,33 @@ void attention_split_kernel(const float* __restrict__ qk, const unsigned char* _
     if (!working) return;
     float* o_rows = out + static_cast<int64_t>(head * D) * ld + span.offset;
     const int query = q0 + column;
-    // the denominator: output row D = row D - 32 of the second tile, held by the lanes
-    // of half (D % 8) / 4 in register 4 ((D - 32) / 8) + D % 4
-    constexpr int kSumRegister = 4 * ((D - 32) / 8) + D % 4;
-    const float total_p = __shfl(o[1][kSumRegister], 32 * ((D % 8) / 4) + column);
-    if (query >= queries) return;
-    const float inverse = length > 0 ? 1.f / total_p : NAN;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
+    // the denominator: output row D = row D - 32 of the tail tiles, register (D - 32) % 4
+    // of lane group (D - 32) / 4: query 16 q + n's is in lane 16 ((D - 32) / 4) + n of tile q
+    constexpr int kSumGroup = (D - 32) / 4, kSumRegister = (D - 32) % 4;
+    const float total_low = __shfl(o_tail[0][kSumRegister], 16 * kSumGroup + (lane & 15));
+    const float total_high = __shfl(o_tail[1][kSumRegister], 16 * kSumGroup + (lane & 15));
+    // rows 0 .. 31: the lane's query is `column`
+    if (query < queries) {
+        const float total_p = column < 16 ? total_low : total_high;
+        const float inverse = length > 0 ? 1.f / total_p : NAN;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int d = 32 * m + 8 * (r >> 2) + 4 * half + (r & 3);
-            if (d < D) o_rows[static_cast<int64_t>(d) * ld + query] = o[m][r] * inverse;
+            const int d = 8 * (r >> 2) + 4 * half + (r & 3);
+            o_rows[static_cast<int64_t>(d) * ld + query] = o[r] * inverse;
         }
+    }
+    // rows 32 .. D - 1: lane l holds rows 32 + 4 (l / 16) + i of queries l % 16 and 16 + l % 16
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int mine = q0 + 16 * q + (lane & 15);
+        if (mine >= queries) continue;
+        const float inverse = length > 0 ? 1.f / (q == 0 ? total_low : total_high) : NAN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = 32 + 4 * (lane >> 4) + i;
+            if (d < D) o_rows[static_cast<int64_t>(d) * ld + mine] = o_tail[q][i] * inverse;
+        }
+    }
 }
 
 }  // namespace emph

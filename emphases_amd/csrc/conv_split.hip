@@ -53,16 +53,24 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// (tools/micro/corun_split.hip builds a 128-position variant - four MFMA waves, 111 KB of
+// LDS - to put a front-end workgroup beside it on a CU; the product is 256)
+#ifndef CONV_SPLIT_WIDTH
+#define CONV_SPLIT_WIDTH 256
+#endif
+
 constexpr int kSplitChannels = 80;
-constexpr int kSplitWidth = 256;                    // computed positions
+constexpr int kSplitWidth = CONV_SPLIT_WIDTH;       // computed positions
+constexpr int kSplitMfmaWaves = kSplitWidth / 32;   // one 32-position column tile each
+constexpr int kSplitMfmaThreads = 64 * kSplitMfmaWaves;
 constexpr int kSplitRows = kSplitWidth + 2;         // + the columns beside them
 constexpr int kSplitRowBytes = 176;                 // 88 bf16
-constexpr int kSplitImageBytes = 264 * kSplitRowBytes;            // one piece
+constexpr int kSplitImageBytes = (kSplitWidth + 8) * kSplitRowBytes;         // one piece
 constexpr int kSplitMTiles = 3;                     // 96 rows, 80 used
 constexpr int kSplitBlocks = kSplitChannels / 16;   // k-steps per tap
 constexpr int kSplitChunkBytes = kSplitBlocks * kSplitMTiles * 2 * 1024;     // one tap
 constexpr int kSplitLayerBytes = 3 * kSplitChunkBytes;
-constexpr int kSplitThreads = 768;                  // 8 MFMA waves + 4 loader waves
+constexpr int kSplitThreads = kSplitMfmaThreads + 256;      // 8 MFMA waves + 4 loader waves
 constexpr int kSplitMaxLayers = 5;
 constexpr int kSplitLdsBytes = 2 * kSplitImageBytes + 2 * kSplitChunkBytes +
                                kSplitMaxLayers * kSplitChannels * 4;
@@ -104,7 +112,7 @@ __global__ __launch_bounds__(kSplitThreads) void conv1d_split_kernel(
     float* bias_lds = reinterpret_cast<float*>(ring + 2 * kSplitChunkBytes);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool loader = wave >= 8;
+    const bool loader = wave >= kSplitMfmaWaves;
 
     const int4 span_a = reinterpret_cast<const int4*>(spans)[2 * blockIdx.x];
     const int4 span_b = reinterpret_cast<const int4*>(spans)[2 * blockIdx.x + 1];
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(kSplitThreads) void conv1d_split_kernel(
         unsigned char* target = ring + (g & 1) * kSplitChunkBytes;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int from = min((wave - 8) + 4 * k, kSplitChunkBytes / 1024 - 1) * 1024;
+            const int from = min((wave - kSplitMfmaWaves) + 4 * k, kSplitChunkBytes / 1024 - 1) * 1024;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(source + from + 16 * lane),
                 (__attribute__((address_space(3))) void*)(target + from), 16, 0, 0);
@@ -147,15 +155,16 @@ __global__ __launch_bounds__(kSplitThreads) void conv1d_split_kernel(
     // positions outside the segment become zeros.
     {
         const int tid = threadIdx.x;                   // 0 .. 511
-        if (tid < layers * kSplitChannels) bias_lds[tid] = biases[tid];
+        for (int i = tid; i < layers * kSplitChannels; i += kSplitMfmaThreads)
+            bias_lds[i] = biases[i];
         // (every load of the thread is in flight before the first is used: a load is
         // 1-2 us away when the whole chip starts a launch)
         constexpr int kTasks = (kSplitChannels / 4) * kSplitRows;
-        constexpr int kRounds = (kTasks + 511) / 512;
+        constexpr int kRounds = (kTasks + kSplitMfmaThreads - 1) / kSplitMfmaThreads;
         float raw[kRounds][4];
 #pragma unroll
         for (int round = 0; round < kRounds; ++round) {
-            const int task = min(tid + 512 * round, kTasks - 1);
+            const int task = min(tid + kSplitMfmaThreads * round, kTasks - 1);
             const int quad = task / kSplitRows, row = task - quad * kSplitRows;
             const float* source = x + static_cast<int64_t>(4 * quad) * ldx + column +
                                   min(max(c0 - 1 + row, 0), count - 1);
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(kSplitThreads) void conv1d_split_kernel(
         }
 #pragma unroll
         for (int round = 0; round < kRounds; ++round) {
-            const int task = tid + 512 * round;
+            const int task = tid + kSplitMfmaThreads * round;
             if (task >= kTasks) break;
             const int quad = task / kSplitRows, row = task - quad * kSplitRows;
             const int p = c0 - 1 + row;

@@ -15,6 +15,7 @@ keeps its model on function attributes of `infer` (`core.py:298-315`); here the
 cache is an explicit object.
 """
 import contextlib
+import functools
 import os
 import ctypes
 import threading
@@ -142,6 +143,12 @@ class Engine:
         # host threads hold this lock from pack_audio() until they have cloned
         # the scores (core.from_alignments_and_audios does)
         self.lock = threading.RLock()
+        # positions per wave of the split position-wise kernels: 16
+        # (csrc/block_split16.hip: two waves a SIMD, block + next projections in
+        # one launch) or 32 (csrc/block_split.hip, one wave a SIMD)
+        self.split_tile = int(os.environ.get('EMPHASES_SPLIT_TILE', 16))
+        if self.split_tile not in (16, 32):
+            raise ValueError('EMPHASES_SPLIT_TILE must be 16 or 32')
         state = weights_module.load(state, config)
         self.state = state
         dev = self.device
@@ -358,15 +365,17 @@ class Engine:
             block_split = qkv_split = None
             if self.linear_pieces and channels == 80 and block is not None:
                 pieces = self.linear_pieces
+                pack = functools.partial(
+                    runtime.linear_split_pack, pieces=pieces,
+                    tile=self.split_tile)
                 block_split = (
                     to(np.concatenate([
-                        runtime.linear_split_pack(state[p + name], pieces)
+                        pack(state[p + name])
                         for name in ('self_attn.out_proj.weight',
                                      'linear1.weight', 'linear2.weight')])),
                     block[1])
                 qkv_split = (to(np.concatenate([
-                    runtime.linear_split_pack(
-                        in_w[part * channels:(part + 1) * channels], pieces)
+                    pack(in_w[part * channels:(part + 1) * channels])
                     for part in range(3)])), qkv[1])
             layers.append(dict(
                 block=block, qkv=qkv, block_split=block_split,
@@ -496,6 +505,8 @@ class Engine:
                          (runtime.AXIS_FRAMES, ATTENTION_BLOCK) + SHORT,
                          (runtime.AXIS_FRAMES, ATTENTION_GROUP) + LONG,
                          (runtime.AXIS_FRAMES, 32)]
+            if self.linear_pieces:
+                requests += [(runtime.AXIS_FRAMES, self.split_tile)]
             if not nested:
                 requests += [(runtime.AXIS_WORDS, ATTENTION_BLOCK)]
                 if self.word_transformer is not None:
@@ -821,9 +832,28 @@ class Engine:
                     channels, config.heads, tiles.data_ptr(), count, tile_n,
                     counts_pointer, runtime.stream()), 'emph_attention')
 
-        split_tiles = None
-        if ('tiles', axis, 32) + select in meta:
-            split_tiles = meta[('tiles', axis, 32) + select]
+        split_tiles, wide = None, self.split_tile
+        if axis == runtime.AXIS_FRAMES and ('tiles', axis, wide) + select in meta:
+            split_tiles = meta[('tiles', axis, wide) + select]
+
+        def position_wise(layer, following):
+            """emph_position_wise_split: this layer's block (layer given) and / or
+            the projections of the next (following given), tiles of 16."""
+            tiles, size = split_tiles
+            block_packs, vectors = layer['block_split'] if layer else (None, None)
+            next_packs, next_bias = following['qkv_split'] if following \
+                else (None, None)
+            pointer = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+            runtime.check(self.lib.emph_position_wise_split(
+                attended.data_ptr() if layer else None, x.data_ptr(), ld,
+                channels, config.heads, pointer(block_packs), pointer(vectors),
+                pointer(next_packs), pointer(next_bias), self.linear_pieces,
+                self.attention_pieces, config.layer_norm_eps,
+                runtime.ACTIVATIONS['relu'], tiles.data_ptr(),
+                size // runtime.TILE_FIELDS, 16, qk.data_ptr(), v.data_ptr(),
+                split_images.data_ptr() if projected_images and following
+                else None, runtime.stream()), 'emph_position_wise_split')
+
         projected_ahead = False     # this layer's Q, K, V came out of the last block
         images_ahead = False        # ... its K and V as the attention's split images
         for index, layer in enumerate(layers):
@@ -837,7 +867,10 @@ class Engine:
                 tiles, size = split_tiles
                 with self._timed(f'qkv_projection_split_{tag}', 6. * channels *
                                  channels * meta['positions'][axis]):
-                    if projected_images:
+                    if wide == 16:
+                        position_wise(None, layer)
+                        images_written = projected_images
+                    elif projected_images:
                         runtime.check(self.lib.emph_qkv_projection_split_images(
                             x.data_ptr(), ld, qk.data_ptr(),
                             split_images.data_ptr(), channels, config.heads,
@@ -882,16 +915,19 @@ class Engine:
                 tiles, size = split_tiles
                 with self._timed(f'transformer_block_qkv_split_{tag}', 12. *
                                  channels * channels * meta['positions'][axis]):
-                    runtime.check(self.lib.emph_transformer_block_qkv_split(
-                        attended.data_ptr(), x.data_ptr(), ld, channels,
-                        config.heads, packs.data_ptr(), next_packs.data_ptr(),
-                        self.linear_pieces, self.attention_pieces,
-                        vectors.data_ptr(), next_bias.data_ptr(),
-                        config.layer_norm_eps, runtime.ACTIVATIONS['relu'],
-                        tiles.data_ptr(), size // runtime.TILE_FIELDS, 32,
-                        qk.data_ptr(), v.data_ptr(),
-                        split_images.data_ptr() if projected_images else None,
-                        runtime.stream()), 'emph_transformer_block_qkv_split')
+                    if wide == 16:
+                        position_wise(layer, following)
+                    else:
+                        runtime.check(self.lib.emph_transformer_block_qkv_split(
+                            attended.data_ptr(), x.data_ptr(), ld, channels,
+                            config.heads, packs.data_ptr(), next_packs.data_ptr(),
+                            self.linear_pieces, self.attention_pieces,
+                            vectors.data_ptr(), next_bias.data_ptr(),
+                            config.layer_norm_eps, runtime.ACTIVATIONS['relu'],
+                            tiles.data_ptr(), size // runtime.TILE_FIELDS, 32,
+                            qk.data_ptr(), v.data_ptr(),
+                            split_images.data_ptr() if projected_images else None,
+                            runtime.stream()), 'emph_transformer_block_qkv_split')
                 projected_ahead, images_ahead = True, projected_images
                 continue
             if split:
@@ -899,12 +935,15 @@ class Engine:
                 tiles, size = split_tiles
                 with self._timed(f'transformer_block_split_{tag}', 6. * channels *
                                  channels * meta['positions'][axis]):
-                    runtime.check(self.lib.emph_transformer_block_split(
-                        attended.data_ptr(), x.data_ptr(), ld, channels,
-                        packs.data_ptr(), self.linear_pieces, vectors.data_ptr(),
-                        config.layer_norm_eps, runtime.ACTIVATIONS['relu'],
-                        tiles.data_ptr(), size // runtime.TILE_FIELDS, 32,
-                        runtime.stream()), 'emph_transformer_block_split')
+                    if wide == 16:
+                        position_wise(layer, None)
+                    else:
+                        runtime.check(self.lib.emph_transformer_block_split(
+                            attended.data_ptr(), x.data_ptr(), ld, channels,
+                            packs.data_ptr(), self.linear_pieces, vectors.data_ptr(),
+                            config.layer_norm_eps, runtime.ACTIVATIONS['relu'],
+                            tiles.data_ptr(), size // runtime.TILE_FIELDS, 32,
+                            runtime.stream()), 'emph_transformer_block_split')
                 continue
             if layer['block_qkv'] is not None and block <= 32 and self.fuse_qkv:
                 # (attention has consumed qk / v: the next layer's go there)

@@ -13,7 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBRARY_PATH = os.path.join(HERE, 'libemphases_hip.so')
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 # include/emphases_hip.h
 SEG_FIELDS = 8
@@ -117,6 +117,11 @@ SIGNATURES = {
     'emph_transformer_block_split': (_c.c_int, [
         _ptr, _ptr, _i64, _i32, _ptr, _i32, _ptr, _c.c_float, _i32, _ptr, _i32,
         _i32, _ptr]),
+    'emph_linear_split_pack16_size': (_i64, [_i32]),
+    'emph_linear_split_pack16': (_c.c_int, [_ptr, _i32, _ptr]),
+    'emph_position_wise_split': (_c.c_int, [
+        _ptr, _ptr, _i64, _i32, _i32, _ptr, _ptr, _ptr, _ptr, _i32, _i32,
+        _c.c_float, _i32, _ptr, _i32, _i32, _ptr, _ptr, _ptr, _ptr]),
     'emph_transformer_block_qkv_split': (_c.c_int, [
         _ptr, _ptr, _i64, _i32, _i32, _ptr, _ptr, _i32, _i32, _ptr, _ptr,
         _c.c_float, _i32, _ptr, _i32, _i32, _ptr, _ptr, _ptr, _ptr]),
@@ -401,15 +406,18 @@ def conv_split_pack(weight):
     return pack
 
 
-def linear_split_pack(weight, pieces=2):
-    """Pack of `pieces` bf16 pieces per weight (`emph_linear_split_pack`) of a
-    [80, 80] Linear weight (host, numpy uint8)."""
+def linear_split_pack(weight, pieces=2, tile=32):
+    """Pack of `pieces` bf16 pieces per weight of a [80, 80] Linear weight
+    (host, numpy uint8): `emph_linear_split_pack` for the kernels that own 32
+    positions per wave, `emph_linear_split_pack16` for those that own 16."""
     lib = library()
     weight = np.ascontiguousarray(weight, dtype=np.float32)
-    assert weight.shape == (80, 80)
-    pack = np.zeros(lib.emph_linear_split_pack_size(pieces), dtype=np.uint8)
-    check(lib.emph_linear_split_pack(weight.ctypes.data, pieces,
-                                     pack.ctypes.data),
+    assert weight.shape == (80, 80) and tile in (16, 32)
+    size, fill = (lib.emph_linear_split_pack_size, lib.emph_linear_split_pack) \
+        if tile == 32 else \
+        (lib.emph_linear_split_pack16_size, lib.emph_linear_split_pack16)
+    pack = np.zeros(size(pieces), dtype=np.uint8)
+    check(fill(weight.ctypes.data, pieces, pack.ctypes.data),
           'emph_linear_split_pack')
     return pack
 

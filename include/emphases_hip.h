@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define EMPH_ABI_VERSION 29
+#define EMPH_ABI_VERSION 30
 
 /* Segment-table fields */
 enum {
@@ -767,6 +767,30 @@ int emph_transformer_block_qkv_split(const float* attended, float* x, int64_t ld
                                      const int32_t* tiles, int32_t n_tiles,
                                      int32_t tile_n, float* qk, float* v,
                                      void* images, void* stream);
+/* The same three operations on tiles of SIXTEEN positions (csrc/block_split16.hip:
+ * v_mfma_f32_16x16x32_bf16, 230 registers a wave, two waves a SIMD - one tile's
+ * vector work under the other's MFMAs; eight waves share the packs in LDS): what the
+ * engine's opt-in precisions run.  One entry point, three shapes:
+ *   attended != NULL, qkv_packs == NULL   emph_transformer_block_split
+ *   attended == NULL, qkv_packs != NULL   emph_qkv_projection_split (images == NULL)
+ *                                         / _images (images != NULL) of x
+ *   both                                  emph_transformer_block_qkv_split: one launch,
+ *                                         the six packs streamed through three LDS
+ *                                         slots; bit for bit the two launches
+ * Packs: emph_linear_split_pack16 (k-step j, group g, element e = input channel
+ * 32 j + 16 (e / 4) + 4 g + e % 4: the order in which a GEMM's result lies in the
+ * registers of the next); `tiles`: blocks of 16 (`tile_n` = 16); vectors, bias, qk, v,
+ * images as above.  emphases/model/layers/transformer.py:18-30. */
+int64_t emph_linear_split_pack16_size(int32_t pieces);
+int emph_linear_split_pack16(const float* host_weight /* [80][80] */, int32_t pieces,
+                             void* host_pack);
+int emph_position_wise_split(const float* attended, float* x, int64_t ld,
+                             int32_t channels, int32_t heads, const void* block_packs,
+                             const float* vectors, const void* qkv_packs,
+                             const float* qkv_bias, int32_t pieces,
+                             int32_t attention_pieces, float eps, int32_t activation,
+                             const int32_t* tiles, int32_t n_tiles, int32_t tile_n,
+                             float* qk, float* v, void* images, void* stream);
 /* ... with K and V written straight as the images emph_attention_split stages
  * (what emph_split_kv would make of qk / v: no fp32 K and V, no second pass): Q
  * into qk's first 80 rows (the K rows are left alone), `images` sized by

@@ -1224,6 +1224,166 @@ def test_transformer_block_qkv_split(pieces, attention_pieces):
         qk_few.data_ptr(), v_few.data_ptr(), None, None) == 0
 
 
+@pytest.mark.parametrize('pieces,attention_pieces,block_budget,qkv_budget', [
+    (3, 32, 5e-6, 5e-6), (2, 32, 8e-5, 8e-5), (3, 3, 5e-6, 5e-6),
+    (2, 2, 8e-5, 8e-5)])
+def test_position_wise_split(pieces, attention_pieces, block_budget, qkv_budget):
+    """emph_position_wise_split (tiles of 16 positions, csrc/block_split16.hip) in
+    its three shapes on a ragged axis with NaN between the segments and more tiles
+    than one round of the grid's waves: the block against a float64 reference; the
+    projections of its output against float64 and, as split images, against what
+    emph_split_kv makes of the fp32 ones; block + projections as ONE launch bit for
+    bit the two."""
+    lib = runtime.library()
+    channels, heads, tile = 80, 2, 16
+    plan = ragged_plan([200, 1, 17, 33, 700, 64, 32, 96, 321, 15, 16, 48, 49] +
+                       [1000] * 40)
+    axis = runtime.AXIS_FRAMES
+    meta = Meta(plan, [(axis, tile), (axis, 64)])
+    ld = plan.ld_frames
+    x = random_packed(channels, plan, axis, 21)
+    attended = random_packed(channels, plan, axis, 22)
+    padding = torch.ones(ld, dtype=torch.bool)
+    for off, count in spans(plan, axis):
+        padding[off:off + count] = False
+    live = ~padding
+    x[:, padding] = float('nan')
+    names = ['out', 'l1', 'l2']
+    weight = {n: torch.from_numpy(synth.weights(30 + i, (channels, channels), 0.3))
+              for i, n in enumerate(names)}
+    order = ['b_o', 'g1', 'be1', 'b_1', 'b_2', 'g2', 'be2']
+    vector = {n: torch.from_numpy(synth.weights(40 + i, (channels,), 0.5))
+              for i, n in enumerate(order)}
+    vector['g1'] += 1.
+    vector['g2'] += 1.
+    block_packs = torch.from_numpy(np.concatenate([
+        runtime.linear_split_pack(weight[n].numpy(), pieces, 16)
+        for n in names])).to(DEVICE)
+    vectors = torch.cat([vector[n] for n in order]).to(DEVICE)
+    in_proj = torch.from_numpy(synth.weights(6, (3 * channels, channels), 0.3))
+    bias = torch.from_numpy(synth.weights(7, (3 * channels,), 0.5))
+    bias_dev = bias.to(DEVICE)
+    qkv_packs = torch.from_numpy(np.concatenate([
+        runtime.linear_split_pack(
+            in_proj[part * channels:(part + 1) * channels].numpy(), pieces, 16)
+        for part in range(3)])).to(DEVICE)
+    tiles, size = meta.view(('tiles', axis, tile))
+    stage_tiles, stage_size = meta.view(('tiles', axis, 64))
+    attended_dev = attended.to(DEVICE)
+    image_bytes = lib.emph_split_kv_bytes(
+        ld, len(plan.segments), channels, heads, attention_pieces)
+
+    def call(do_block, do_qkv, x_dev, qk, v, images, n_tiles=size // 4):
+        runtime.check(lib.emph_position_wise_split(
+            attended_dev.data_ptr() if do_block else None, x_dev.data_ptr(), ld,
+            channels, heads, block_packs.data_ptr() if do_block else None,
+            vectors.data_ptr() if do_block else None,
+            qkv_packs.data_ptr() if do_qkv else None,
+            bias_dev.data_ptr() if do_qkv else None, pieces, attention_pieces,
+            1e-5, 1, tiles.data_ptr(), n_tiles, tile,
+            None if qk is None else qk.data_ptr(),
+            None if v is None else v.data_ptr(),
+            None if images is None else images.data_ptr(), None),
+            'emph_position_wise_split')
+
+    def outputs():
+        return (torch.full((2 * channels, ld), 7.0, device=DEVICE),
+                torch.full((ld, channels), 7.0, device=DEVICE),
+                torch.full((image_bytes // 2,), 0x5555, dtype=torch.int16,
+                           device=DEVICE))
+    # 1. the block alone
+    x_block = x.to(DEVICE)
+    call(True, False, x_block, None, None, None)
+    got = x_block.cpu()
+    norm = torch.nn.functional.layer_norm
+    wd = {n: w.double() for n, w in weight.items()}
+    vd = {n: w.double() for n, w in vector.items()}
+    worst = 0.
+    for off, count in spans(plan, axis):
+        xs = x[:, off:off + count].T.double()
+        a = attended[:, off:off + count].T.double()
+        y = norm(xs + a @ wd['out'].T + vd['b_o'], (channels,),
+                 vd['g1'], vd['be1'], 1e-5)
+        h = torch.relu(y @ wd['l1'].T + vd['b_1'])
+        want = norm(y + h @ wd['l2'].T + vd['b_2'], (channels,),
+                    vd['g2'], vd['be2'], 1e-5).T
+        worst = max(worst, float((got[:, off:off + count] - want).abs().max()))
+    print(f'block16, {pieces} pieces: {worst:.2e}')
+    assert worst < block_budget
+    assert torch.isnan(got[:, padding]).all()            # padding untouched
+    # 2. the projections of that x alone, as fp32 rows
+    qk_rows, v_rows, _ = outputs()
+    call(False, True, x_block, qk_rows, v_rows, None)
+    qk_host, v_host = qk_rows.cpu(), v_rows.cpu()
+    worst = 0.
+    for off, count in spans(plan, axis):
+        want = in_proj.double() @ got[:, off:off + count].double() + \
+            bias.double()[:, None]
+        worst = max(worst,
+                    float((qk_host[:, off:off + count] -
+                           want[:2 * channels]).abs().max()),
+                    float((v_host[off:off + count].T -
+                           want[2 * channels:]).abs().max()))
+    print(f'qkv16, {pieces} pieces: {worst:.2e}')
+    assert worst < qkv_budget
+    assert float(qk_host[:, padding].min()) == 7.0
+    assert float(v_host[padding].min()) == 7.0
+    # 3. ... as Q + split images: what emph_split_kv makes of the fp32 K and V
+    want_images = torch.full((image_bytes // 2,), 0x5555, dtype=torch.int16,
+                             device=DEVICE)
+    runtime.check(lib.emph_split_kv(
+        qk_rows.data_ptr(), v_rows.data_ptr(), ld, channels, heads,
+        stage_tiles.data_ptr(), stage_size // 4, 64, attention_pieces,
+        want_images.data_ptr(), None), 'emph_split_kv')
+    q_only, v_unused, got_images = outputs()
+    call(False, True, x_block, q_only, None, got_images)
+    assert torch.equal(q_only[:channels], qk_rows[:channels])
+    assert float(q_only[channels:].min()) == 7.0           # K's rows: not touched
+    same = torch.equal(got_images, want_images)
+    print('images16 bit for bit:', same)
+    if not same:
+        pk, pv = {2: (2, 2), 3: (3, 3), 32: (3, 2)}[attention_pieces]
+        key_halfs, value_halfs = 6 * 64 * 8, 8 * 42 * 8
+
+        def decode(images):
+            bits = images.cpu().numpy().view(np.uint16).astype(np.uint32) << 16
+            stage = bits.view(np.float32).astype(np.float64).reshape(
+                -1, pk * key_halfs + pv * value_halfs)
+            keys = stage[:, :pk * key_halfs].reshape(-1, pk, key_halfs).sum(1)
+            values = stage[:, pk * key_halfs:].reshape(
+                -1, pv, value_halfs).sum(1)
+            return keys, values
+        for a, b in zip(decode(got_images), decode(want_images)):
+            assert np.abs(a - b).max() < 2e-6
+    # 4. block + projections in ONE launch: bit for bit the two
+    for with_images in (False, True):
+        x_one = x.to(DEVICE)
+        qk_one, v_one, images_one = outputs()
+        call(True, True, x_one, qk_one, None if with_images else v_one,
+             images_one if with_images else None)
+        torch.cuda.synchronize()
+        assert torch.equal(x_one.cpu()[:, live], got[:, live])
+        assert torch.isnan(x_one.cpu()[:, padding]).all()
+        if with_images:
+            assert torch.equal(qk_one, q_only)
+            assert torch.equal(images_one, got_images)
+        else:
+            assert torch.equal(qk_one, qk_rows)
+            assert torch.equal(v_one, v_rows)
+    # a handful of tiles (fewer than the waves of one workgroup) and none at all
+    x_few = x.to(DEVICE)
+    qk_few, v_few, _ = outputs()
+    call(True, True, x_few, qk_few, v_few, None, n_tiles=3)
+    first = plan.frame_off[0]
+    assert torch.equal(x_few[:, first:first + 48], x_block[:, first:first + 48])
+    assert torch.equal(qk_few[:, first:first + 48], qk_rows[:, first:first + 48])
+    call(True, True, x_few, qk_few, v_few, None, n_tiles=0)
+    assert lib.emph_position_wise_split(
+        None, x_few.data_ptr(), ld, channels, heads, None, None, None, None,
+        pieces, attention_pieces, 1e-5, 1, tiles.data_ptr(), 3, tile, None, None,
+        None, None) == -1
+
+
 ###############################################################################
 # feature rows
 ###############################################################################

@@ -2,7 +2,7 @@
 # Runs on the GPU box: matrix-pipe / vector / LDS utilisation counters of the round's
 # kernels (one rocprofv3 --pmc pass each; counters of a pass must fit together).
 # usage: tools/pmc_round.sh <tag>   -> gpurun_out/<tag>_pmc_utilisation.txt
-tag=${1:-r5}
+tag=${1:-r6}
 repo=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$repo/gpurun_out/${tag}_pmc_utilisation.txt
 mkdir -p $repo/gpurun_out
