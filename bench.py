@@ -432,18 +432,30 @@ class Runner:
         engine.timers = []
         # (one untimed pass: every pass below finds its buffers in place)
         engine.forward(self.packed, self.plan, self.meta)
-        # ... and the clocks where the timed regions had them: an idle chip runs
-        # the first passes 7 % slower (tools/timer_check.py: eager passes right
-        # behind 300 replays agree with rocprofv3's trace of the replays to 1-2 %)
-        begin = time.perf_counter()
-        for count in range(300):
-            self.step()
-            if count >= 20 and count % 10 == 0:
-                torch.cuda.synchronize()
-                if time.perf_counter() - begin > 0.3:
-                    break
-        torch.cuda.synchronize()
-        with runtime.LaunchTimer(1 << 16) as exact:
+        per_pass = len(engine.timers)
+        graph = self.lanes[0][2] is not None
+
+        def hot():
+            """The clocks where the timed regions had them: an idle chip runs the
+            first passes 7 % slower (tools/timer_check.py: eager passes right behind
+            300 replays agree with rocprofv3's trace of the replays to 1-2 %)."""
+            begin = time.perf_counter()
+            for count in range(300):
+                self.step()
+                if count >= 20 and count % 10 == 0:
+                    torch.cuda.synchronize()
+                    if time.perf_counter() - begin > 0.3:
+                        break
+            torch.cuda.synchronize()
+        # creating the timer's events takes a moment: before the pre-roll, so that
+        # nothing but the passes follows it (replays are not launches of the
+        # library; without graphs the pre-roll would use the timer up)
+        capacity = 8 * (passes * max(per_pass, 1) + 4 * passes) + 64
+        if not graph:
+            hot()
+        with runtime.LaunchTimer(capacity) as exact:
+            if graph:
+                hot()
             engine.timers = []
             for _ in range(passes):
                 engine.forward(self.packed, self.plan, self.meta)
@@ -454,15 +466,22 @@ class Runner:
                         engine.lib.emph_launch_probe(runtime.stream()),
                         'emph_launch_probe')
             torch.cuda.synchronize()
-        assert exact.launches <= exact.capacity, exact.launches
-        kernels = {}
-        for name, flops, begin, end, first, last in engine.timers:
+        assert exact.launches <= exact.capacity, (exact.launches, capacity)
+        kernels, samples = {}, {}
+        for position, (name, flops, begin, end, first, last) in \
+                enumerate(engine.timers):
             entry = kernels.setdefault(name, [0, 0., 0., 0., 0])
             entry[0] += 1
             entry[1] += begin.elapsed_time(end) * 1e-3
             entry[2] += flops
-            entry[3] += float(exact.microseconds[first:last].sum()) * 1e-6
             entry[4] += last - first
+            # the k-th region of a pass, over the passes: their MEDIAN counts (a
+            # region that met a clock step or another process's burst does not)
+            slot = position % per_pass if name != 'launch_probe' else 0
+            samples.setdefault((name, slot), []).append(
+                float(exact.microseconds[first:last].sum()) * 1e-6)
+        for (name, slot), values in samples.items():
+            kernels[name][3] += float(np.median(values)) * len(values)
         engine.timers = None
         return kernels, passes
 
@@ -647,14 +666,25 @@ def executed_matrix_flops(dominant, launches_per_step, committed, spans=None,
 
 
 PEAK_BF16_MFMA = 2500.        # TFLOP/s dense, same guide
-# flops of one v_mfma_f32_32x32x16_bf16
+# flops of one v_mfma_f32_32x32x16_bf16 (a v_mfma_f32_16x16x32_bf16 is half of it)
 SPLIT_MFMA_FLOPS = 2 * 32 * 32 * 16
-# Without a committed PMC count: 32 x 32 tiles of the split attention execute
-# (3 k-steps x terms of the scores + 4 x terms of the values) bf16 MFMAs (head
-# dimension 40 -> 48, value rows 41 -> 64) per 2 x 2 x 32 x 32 x 40 flops
-SPLIT_EXECUTED = {'bf16x3': (3 * 6 + 4 * 3) * 32768 / 163840.,
-                  'bf16x3_fast': (3 * 6 + 4 * 3) * 32768 / 163840.,
-                  'bf16x6': 7 * 6 * 32768 / 163840.}
+# (products of the scores, of the values) per term of each opt-in precision's attention
+SPLIT_TERMS = {'bf16x3': (6, 3), 'bf16x3_fast': (6, 3), 'bf16x6': (6, 6)}
+
+
+def split_attention_flops_per_instruction(precision):
+    """attention_split_kernel per 32 x 32 scores: 3 T_K + 2 T_V instructions of 32 x 32 x
+    16 (S^T over a head dimension of 40 -> 48; rows 0 .. 31 of O^T) and 2 T_V of 16 x 16
+    x 32 (rows 32 .. 47): the mean flops of an instruction SQ_INSTS_MFMA counts."""
+    scores, values = SPLIT_TERMS[precision]
+    long_ones, short_ones = 3 * scores + 2 * values, 2 * values
+    return SPLIT_MFMA_FLOPS * (long_ones + .5 * short_ones) / (long_ones + short_ones)
+
+
+# Without a committed PMC count: executed over algorithmic flops of the split attention,
+# (3 T_K + 3 T_V) MFMA-equivalents of 32768 flops per 2 x 2 x 32 x 32 x 40
+SPLIT_EXECUTED = {name: (3 * scores + 3 * values) * 32768 / 163840.
+                  for name, (scores, values) in SPLIT_TERMS.items()}
 
 # What the fields of `roofline` are (kept out of the line: the side-records
 # file carries this once).
@@ -712,15 +742,18 @@ def roofline(kernels, passes, ms_per_step, config, spans=None, layers=None,
     if split:
         executed = {}
         if counted:
-            executed = {'flops': counted * SPLIT_MFMA_FLOPS,
+            per_instruction = split_attention_flops_per_instruction(precision) \
+                if dominant.startswith('attention') else SPLIT_MFMA_FLOPS
+            executed = {'flops': counted * per_instruction,
                         'mfma_instructions_per_launch': counted,
                         'mfma_instructions_source':
                             committed.get('mfma_pipe_busy_file')}
         elif dominant.startswith('attention'):
             executed = {'flops': algorithmic_flops * SPLIT_EXECUTED[precision],
                         'mfma_instructions_source':
-                            'formula (no committed PMC pass): 30 / 42 MFMAs '
-                            'per 32 x 32 scores, tile edges not counted'}
+                            'formula (no committed PMC pass): 27 / 36 MFMA-'
+                            'equivalents per 32 x 32 scores, tile edges not '
+                            'counted'}
         else:
             # direct form, three products per term, 96 rows for 80 channels,
             # 256 computed positions per 250 owned

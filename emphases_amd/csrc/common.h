@@ -37,7 +37,9 @@ struct LaunchTimer {
     int capacity;
     int count;        // launches seen (those beyond `capacity` are not timed)
 };
-extern thread_local LaunchTimer* t_launch_timer;    // host.hip
+// (one per thread, one definition for the library and for the micro-benchmarks that
+// include a kernel's source: a C++17 inline variable)
+inline thread_local LaunchTimer* t_launch_timer = nullptr;
 
 #define EMPH_LAUNCH(kernel, grid, block, lds, stream, ...)                               \
     do {                                                                                 \

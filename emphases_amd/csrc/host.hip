@@ -168,10 +168,6 @@ const int g_atfork = pthread_atfork(nullptr, nullptr, forget_pool_in_child);
 
 }  // namespace
 
-namespace emph {
-thread_local LaunchTimer* t_launch_timer = nullptr;
-}  // namespace emph
-
 namespace {
 void release_timer(emph::LaunchTimer* timer) {
     for (int i = 0; i < timer->capacity; ++i) {

@@ -1444,6 +1444,43 @@ def test_linear_split_pack_pieces_in_chain_order():
                               leading[32 * m + lane % 32, channels])
 
 
+def test_linear_split_pack16_pieces_in_chain_order():
+    """emph_linear_split_pack16 (host; the kernels on tiles of 16 positions):
+    [k-step j][m-tile m][piece][lane][8] with lane = (output channel 16 m + lane % 16;
+    input channels 32 j + 16 (e / 4) + 4 (lane / 16) + e % 4 - the order in which a
+    16 x 16 result lies in the registers of the next GEMM); five m-tiles (no padded
+    rows), three k-steps whose input channels 80 .. 95 are zeros."""
+    from emphases_amd import runtime
+    lib = runtime.library()
+    weight = synth.weights(78, (80, 80), 0.3)
+    assert lib.emph_linear_split_pack16_size(4) == 0
+    e = np.arange(8)
+    for pieces in (2, 3):
+        pack = runtime.linear_split_pack(weight, pieces, 16)
+        assert pack.nbytes == lib.emph_linear_split_pack16_size(pieces) == \
+            3 * 5 * pieces * 1024
+        halves = pack.view(np.uint16).reshape(3, 5, pieces, 64, 8)
+        values = (halves.astype(np.uint32) << 16).view(np.float32)
+        rebuilt = np.zeros((80, 96), dtype=np.float64)
+        seen = np.zeros((80, 96), dtype=np.int64)
+        for j in range(3):
+            for m in range(5):
+                for lane in range(64):
+                    channels = 32 * j + 16 * (e // 4) + 4 * (lane // 16) + e % 4
+                    rebuilt[16 * m + lane % 16, channels] = \
+                        values[j, m, :, lane].astype(np.float64).sum(0)
+                    seen[16 * m + lane % 16, channels] += 1
+        assert np.all(seen == 1)                    # every (row, channel) exactly once
+        assert np.all(rebuilt[:, 80:] == 0.)
+        error = np.abs(rebuilt[:, :80] - weight) / np.maximum(np.abs(weight), 1e-30)
+        if pieces == 3:
+            assert float(error.max()) == 0.         # 8 + 8 + 8 bits: all of fp32's
+        else:
+            assert float(error.max()) < 2.0 ** -16
+    with pytest.raises(AssertionError):
+        runtime.linear_split_pack(weight, 2, 64)
+
+
 def test_split_kv_scratch_sizes_and_piece_codes():
     from emphases_amd import runtime
     lib = runtime.library()

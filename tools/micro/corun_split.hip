@@ -20,10 +20,7 @@
 
 #include "conv_split.hip"
 #include "frontend.hip"
-namespace emph {
-// (frontend.hip defines set_error for the library)
-thread_local LaunchTimer* t_launch_timer = nullptr;
-}  // namespace emph
+// (frontend.hip defines emph::set_error for the library)
 
 #ifndef LAYERS
 #define LAYERS 4

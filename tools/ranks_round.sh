@@ -2,7 +2,7 @@
 # Runs on the GPU box: the N > 1 and strong-scaling bench lines rehearsed on the one GPU
 # (two gloo ranks sharing it; one nccl = RCCL rank), each with `roofline` and `cpu_baseline`.
 # usage: tools/ranks_round.sh <tag>   -> gpurun_out/<tag>_bench_2ranks_gloo_1gpu.json, <tag>_strong_*.json
-tag=${1:-r5}
+tag=${1:-r6}
 repo=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$repo/gpurun_out
 mkdir -p $out
