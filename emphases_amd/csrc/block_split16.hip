@@ -51,18 +51,30 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f3
                                                    __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// A lane's column of channel-major rows: the row's address is wave-uniform, what varies
-// with the lane - its column and its group's four channels - is ONE 32-bit offset (the
-// entry point keeps 13 ld below 2^32).
-__device__ __forceinline__ uint32_t p16_lane_offset(int64_t ld, int64_t column, int group) {
-    return static_cast<uint32_t>(column) + static_cast<uint32_t>(4 * group) * static_cast<uint32_t>(ld);
+// Channel-major rows through BUFFER instructions: the array is one buffer resource (four
+// scalar registers), a lane's column and its group's four channels ONE 32-bit byte offset in
+// a vector register, the row of an access a scalar offset (channel x ld x 4, scalar
+// arithmetic) - no vector instruction per access.  With plain pointers every one of a tile's
+// 150 accesses cost a 64-bit vector add and the 80 row addresses spilled scalar registers
+// into vector lanes (v_writelane / v_readlane): 350 of the kernel's 1 840 vector
+// instructions per tile, in a kernel bound by vector issue.  (The entry point keeps every
+// byte offset below 2^32.)
+typedef __amdgpu_buffer_rsrc_t p16_rows;
+__device__ __forceinline__ p16_rows p16_buffer(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
 }
-__device__ __forceinline__ const float& p16_at(const float* base, int64_t ld, int channel,
-                                               uint32_t lane_offset) {
-    return (base + static_cast<int64_t>(channel) * ld)[lane_offset];
+__device__ __forceinline__ uint32_t p16_lane_offset(uint32_t ld4, int64_t column, int group) {
+    return 4u * static_cast<uint32_t>(column) + static_cast<uint32_t>(4 * group) * ld4;
 }
-__device__ __forceinline__ float& p16_at(float* base, int64_t ld, int channel, uint32_t lane_offset) {
-    return (base + static_cast<int64_t>(channel) * ld)[lane_offset];
+__device__ __forceinline__ float p16_load(p16_rows rows, uint32_t ld4, int channel,
+                                          uint32_t lane_offset) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+        rows, lane_offset, static_cast<uint32_t>(channel) * ld4, 0));
+}
+__device__ __forceinline__ void p16_store(p16_rows rows, uint32_t ld4, int channel,
+                                          uint32_t lane_offset, float value) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(value), rows, lane_offset,
+                                          static_cast<uint32_t>(channel) * ld4, 0);
 }
 
 // acc[m] += W (pack, in LDS) x B.  `fragment(j, b)`: the B operand of k-step j, split.
@@ -226,23 +238,27 @@ __global__ __launch_bounds__(kP16Threads) void position_wise16_kernel(
     // a tile's inputs: the first GEMM's operand in operand order (the attention's output,
     // or x itself without the block), the residual stream in the accumulator layout
     // (columns beyond the segment read its last one)
-    const float* operand_rows = BLOCK ? attended : x;
+    const uint32_t ld4 = 4u * static_cast<uint32_t>(ld);
+    const p16_rows operand_rows = p16_buffer(BLOCK ? attended : x);
+    const p16_rows x_rows = p16_buffer(x);
+    const p16_rows qk_rows = p16_buffer(qk);
+    const p16_rows v_rows = p16_buffer(v);
     auto request = [&](int tile, float (&operand)[kP16Steps][8], f32x4 (&residual)[kP16MTiles]) {
         const Tile span = load_tile(tiles, tile);
         const uint32_t at =
-            p16_lane_offset(ld, span.offset + min(span.first + p, span.count - 1), group);
+            p16_lane_offset(ld4, span.offset + min(span.first + p, span.count - 1), group);
 #pragma unroll
         for (int j = 0; j < kP16Steps; ++j)
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 operand[j][e] = 32 * j + 16 * (e >> 2) < C
-                                    ? p16_at(operand_rows, ld, 32 * j + 16 * (e >> 2) + (e & 3), at)
+                                    ? p16_load(operand_rows, ld4, 32 * j + 16 * (e >> 2) + (e & 3), at)
                                     : 0.f;
         if (BLOCK) {
 #pragma unroll
             for (int m = 0; m < kP16MTiles; ++m)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) residual[m][i] = p16_at(x, ld, 16 * m + i, at);
+                for (int i = 0; i < 4; ++i) residual[m][i] = p16_load(x_rows, ld4, 16 * m + i, at);
         }
     };
     auto bias_of = [&](const float* bias, int m) {
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(kP16Threads) void position_wise16_kernel(
         const Tile span = load_tile(tiles, tile);
         const bool live = span.first + p < span.count;
         const int64_t column = span.offset + min(span.first + p, span.count - 1);
-        const uint32_t at = p16_lane_offset(ld, column, group);
+        const uint32_t at = p16_lane_offset(ld4, column, group);
         // this tile's inputs leave their registers (split) ...
         u32x4 b_frag[kP16Steps][P];
 #pragma unroll
@@ -313,7 +329,7 @@ __global__ __launch_bounds__(kP16Threads) void position_wise16_kernel(
 #pragma unroll
                 for (int m = 0; m < kP16MTiles; ++m)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) p16_at(x, ld, 16 * m + i, at) = y[m][i];
+                    for (int i = 0; i < 4; ++i) p16_store(x_rows, ld4, 16 * m + i, at, y[m][i]);
             }
             if (!QKV) continue;
             // the next layer's projections of what was just stored: its registers ARE
@@ -358,37 +374,55 @@ __global__ __launch_bounds__(kP16Threads) void position_wise16_kernel(
                     for (int m = 0; m < kP16MTiles; ++m)
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
-                            p16_at(qk, ld, part * C + 16 * m + i, at) = acc[m][i];
+                            p16_store(qk_rows, ld4, part * C + 16 * m + i, at, acc[m][i]);
                 } else if (live) {
 #pragma unroll
                     for (int m = 0; m < kP16MTiles; ++m)
-                        *reinterpret_cast<f32x4*>(v + column * C + 16 * m + 4 * group) = acc[m];
+                        __builtin_amdgcn_raw_buffer_store_b128(
+                            __builtin_bit_cast(u32x4, acc[m]), v_rows,
+                            4u * (static_cast<uint32_t>(column) * C + 4 * group), 64 * m, 0);
                 }
             } else if (part == 1) {
-                // K image: [d / 8][key][8 d]; the lane's four consecutive d are half an octet
+                // K image: [d / 8][key][8 d]; the lane's four consecutive d are half an
+                // octet.  (Buffer stores again: the stage is the resource, a lane's key and
+                // half one vector offset, the m-tile's (head, octet) - one of two constants
+                // by the lane's group - a select, the piece a scalar offset.)
+                const p16_rows stage_bytes = p16_buffer(stage);
+                const uint32_t lane_key = 16u * static_cast<uint32_t>(key0 + p) + 8u * (group & 1);
 #pragma unroll
                 for (int m = 0; m < kP16MTiles; ++m) {
                     constexpr int OCTETS = D / 8;
-                    const int index = 2 * m + (group >> 1);          // channel / 8
-                    const int head = index / OCTETS, octet = index % OCTETS;
+                    // channel / 8 = 2 m + group / 2
+                    const uint32_t even = (2 * m / OCTETS) * Images::kStageBytes +
+                                          (2 * m % OCTETS) * kSplitStage * 16;
+                    const uint32_t odd = ((2 * m + 1) / OCTETS) * Images::kStageBytes +
+                                         ((2 * m + 1) % OCTETS) * kSplitStage * 16;
+                    const uint32_t where = lane_key + ((group >> 1) ? odd : even);
                     uint32_t low[PK], high[PK];
                     split_pair<PK>(live ? acc[m][0] : 0.f, live ? acc[m][1] : 0.f, low);
                     split_pair<PK>(live ? acc[m][2] : 0.f, live ? acc[m][3] : 0.f, high);
 #pragma unroll
                     for (int piece = 0; piece < PK; ++piece)
-                        *reinterpret_cast<u32x2*>(stage + head * Images::kStageBytes +
-                                                  Images::key_piece(piece) +
-                                                  (octet * kSplitStage + key0 + p) * 16 +
-                                                  8 * (group & 1)) = u32x2{low[piece], high[piece]};
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{low[piece], high[piece]}, stage_bytes,
+                                                              where, Images::key_piece(piece), 0);
                 }
             } else {
                 // V image: [key / 8][d][8 keys], the keys of each 16 permuted (position
                 // 8 h + 4 a + i holds key 8 a + 4 h + i): the lane's keys 4 g + i are half
                 // of chunk g % 2, at offset 4 (g / 2)
+                const p16_rows stage_bytes = p16_buffer(stage);
+                const uint32_t lane_chunk =
+                    16u * static_cast<uint32_t>(((key0 >> 3) + (group & 1)) * Images::kRows) +
+                    8u * (group >> 1);
 #pragma unroll
                 for (int m = 0; m < kP16MTiles; ++m) {
+                    // channel 16 m + p = head x D + d (only the m-tile that holds channel D
+                    // straddles the heads)
                     const int c = 16 * m + p;
-                    const int head = c / D, d = c % D;
+                    const int head = c >= D ? 1 : 0;
+                    const int d = c - D * head;
+                    const uint32_t where =
+                        lane_chunk + 16u * static_cast<uint32_t>(d) + head * Images::kStageBytes;
                     float keys[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
@@ -398,10 +432,8 @@ __global__ __launch_bounds__(kP16Threads) void position_wise16_kernel(
                     split_pair<PV>(keys[2], keys[3], high);
 #pragma unroll
                     for (int piece = 0; piece < PV; ++piece)
-                        *reinterpret_cast<u32x2*>(
-                            stage + head * Images::kStageBytes + Images::value_piece(piece) +
-                            (((key0 >> 3) + (group & 1)) * Images::kRows + d) * 16 +
-                            8 * (group >> 1)) = u32x2{low[piece], high[piece]};
+                        __builtin_amdgcn_raw_buffer_store_b64(u32x2{low[piece], high[piece]}, stage_bytes,
+                                                              where, Images::value_piece(piece), 0);
                 }
             }
         }
@@ -545,8 +577,10 @@ int emph_position_wise_split(const float* attended, float* x, int64_t ld, int32_
                  "%s: %d channels, %d heads, tiles of %d (built for 80, 2 and 16)", what, channels,
                  heads, tile_n);
     EMPH_REQUIRE(pieces == 2 || pieces == 3, EMPH_ERANGE, "%s: %d pieces (2 or 3)", what, pieces);
-    EMPH_REQUIRE(ld > 0 && ld < (int64_t{1} << 28), EMPH_ERANGE,
-                 "%s: ld %lld outside the 32-bit lane offsets", what, static_cast<long long>(ld));
+    // (byte offsets of 32 bits: 160 rows of qk, v's ld x 80 floats)
+    EMPH_REQUIRE(ld > 0 && ld < (int64_t{1} << 22), EMPH_ERANGE,
+                 "%s: ld %lld outside the 32-bit byte offsets (2^22 columns: 11 hours of frames)",
+                 what, static_cast<long long>(ld));
     EMPH_REQUIRE(activation == EMPH_ACT_RELU || activation == EMPH_ACT_NONE, EMPH_ERANGE,
                  "%s: activation %d", what, activation);
     EMPH_REQUIRE(!images || attention_pieces == 2 || attention_pieces == 3 || attention_pieces == 32,

@@ -11,7 +11,7 @@ repo=$(cd "$(dirname "$0")/.." && pwd)
 scratch=${TMPDIR:-/tmp}/emphases_asan
 rm -rf $scratch && mkdir -p $scratch/build
 cp -r $repo/emphases_amd $repo/tests $repo/oracle $repo/include $repo/tools $scratch/
-cp $repo/BASELINE.json $scratch/ 2>/dev/null || true
+cp $repo/BASELINE.json $repo/bench.py $scratch/ 2>/dev/null || true
 for source in $repo/emphases_amd/csrc/*.hip; do
     name=$(basename $source .hip)
     /opt/rocm/bin/hipcc -O1 -g --offload-arch=gfx950 -fPIC -std=c++17 -Xarch_host -fsanitize=$sanitizers -Xarch_host -fno-sanitize=vptr,function \
