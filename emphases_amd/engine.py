@@ -833,7 +833,11 @@ class Engine:
                     counts_pointer, runtime.stream()), 'emph_attention')
 
         split_tiles, wide = None, self.split_tile
-        if axis == runtime.AXIS_FRAMES and ('tiles', axis, wide) + select in meta:
+        # (the 16-position kernels address rows with 32-bit byte offsets: a packed
+        # axis of 2^22 columns or more - 11 hours of frames in ONE batch - takes the
+        # fp32 position-wise kernels)
+        if axis == runtime.AXIS_FRAMES and ld < (1 << 22 if wide == 16 else 1 << 29) \
+                and ('tiles', axis, wide) + select in meta:
             split_tiles = meta[('tiles', axis, wide) + select]
 
         def position_wise(layer, following):
