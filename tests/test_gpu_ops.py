@@ -1382,6 +1382,14 @@ def test_position_wise_split(pieces, attention_pieces, block_budget, qkv_budget)
         None, x_few.data_ptr(), ld, channels, heads, None, None, None, None,
         pieces, attention_pieces, 1e-5, 1, tiles.data_ptr(), 3, tile, None, None,
         None, None) == -1
+    # rows are addressed with 32-bit byte offsets: a packed axis of 2^22 columns is
+    # refused (EMPH_ERANGE; the engine hands such a batch to the fp32 kernels)
+    assert lib.emph_position_wise_split(
+        attended_dev.data_ptr(), x_few.data_ptr(), 1 << 22, channels, heads,
+        block_packs.data_ptr(), vectors.data_ptr(), None, None, pieces,
+        attention_pieces, 1e-5, 1, tiles.data_ptr(), 3, tile, None, None, None,
+        None) == -2
+    assert b'2^22' in lib.emph_last_error()
 
 
 ###############################################################################
