@@ -1,12 +1,13 @@
 // The position-wise kernels of block_split.hip - the block of a post-LN Transformer
 // encoder layer, the Q / K / V projections in front of the attention, or both in one
 // launch - rebuilt around tiles of SIXTEEN positions on v_mfma_f32_16x16x32_bf16, so that
-// a wave needs 230 registers instead of 450 and TWO waves share a SIMD: the chain of a
-// tile (GEMM, LayerNorm, split, GEMM ...) is serial by construction, and at one wave per
-// SIMD the matrix pipe idled through every vector phase, every LDS fragment read and every
-// trip to memory (block_split.hip's kernels: pipe 29-37 % busy, 51 us per layer whether
-// as one launch or two).  With two waves a SIMD one tile's vector work runs beside the
-// other's MFMAs (free on the bf16 pipe, profiles/r5_coexec.txt).
+// a wave needs 160-230 registers instead of 450 and TWO waves share a SIMD.  The chain of a
+// tile (GEMM, LayerNorm, split, GEMM ...) is serial by construction: at one wave per SIMD
+// the matrix pipe idled through every vector phase, every LDS fragment read and every trip
+// to memory (block_split.hip's kernels: pipe 29-37 % busy, 51 us per layer whether as one
+// launch or two); the second wave fills part of that (42.7 us per layer for block + next
+// projections in ONE launch, profiles/r6_transformer_bf16x3_kernel_stats_1stream.csv; what
+// still bounds it is the chain, EXPERIMENTS.md round 6).
 //   emph_position_wise_split     y = LayerNorm1(x + W_o a + b_o)
 //                                x <- LayerNorm2(y + W_2 relu(W_1 y + b_1) + b_2)
 //                                and / or  Q | K | V of the NEXT layer, as fp32 rows or
