@@ -1341,20 +1341,7 @@ def test_position_wise_split(pieces, attention_pieces, block_budget, qkv_budget)
     assert float(q_only[channels:].min()) == 7.0           # K's rows: not touched
     same = torch.equal(got_images, want_images)
     print('images16 bit for bit:', same)
-    if not same:
-        pk, pv = {2: (2, 2), 3: (3, 3), 32: (3, 2)}[attention_pieces]
-        key_halfs, value_halfs = 6 * 64 * 8, 8 * 42 * 8
-
-        def decode(images):
-            bits = images.cpu().numpy().view(np.uint16).astype(np.uint32) << 16
-            stage = bits.view(np.float32).astype(np.float64).reshape(
-                -1, pk * key_halfs + pv * value_halfs)
-            keys = stage[:, :pk * key_halfs].reshape(-1, pk, key_halfs).sum(1)
-            values = stage[:, pk * key_halfs:].reshape(
-                -1, pv, value_halfs).sum(1)
-            return keys, values
-        for a, b in zip(decode(got_images), decode(want_images)):
-            assert np.abs(a - b).max() < 2e-6
+    assert same
     # 4. block + projections in ONE launch: bit for bit the two
     for with_images in (False, True):
         x_one = x.to(DEVICE)
