@@ -1036,9 +1036,11 @@ def single_utterance_api(audios, alignments, host=None, rounds=300):
     return result
 
 
-def replay_time(engine, packed, alignments, lengths, batch_size, least=0.25):
-    """(seconds per pass, words, frames, checksum) of one ragged batch with
-    its audio resident, replayed as a graph."""
+def replay_time(engine, packed, alignments, lengths, batch_size, least=0.25,
+                keep=None):
+    """(seconds per pass, words, frames, checksum, laps) of one ragged batch
+    with its audio resident, replayed as a graph.  `keep`: a list that receives
+    the batch's scores (a copy)."""
     plan = batch.plan_batch(alignments, lengths, batch_size)
     meta = engine.upload(plan)
     replay, scores, _ = engine.capture(packed, plan, meta)
@@ -1057,6 +1059,8 @@ def replay_time(engine, packed, alignments, lengths, batch_size, least=0.25):
     columns = torch.as_tensor(plan.word_columns(), device=scores.device)
     values = scores[columns]
     assert bool(torch.isfinite(values).all())
+    if keep is not None:
+        keep.append(values.clone())
     return (float(np.median(laps)), plan.total_words, plan.total_frames,
             float(values.double().sum()), len(laps))
 
@@ -1084,6 +1088,25 @@ def rates(count, frames, words, seconds):
         'mfma_frac': (frames * FLOPS_PER_FRAME + words * FLOPS_PER_WORD)
         / seconds / (PEAK_FP32_MFMA * 1e12),
         'hbm_frac_compulsory': frames * BYTES_PER_FRAME / seconds / PEAK_HBM}
+
+
+def split_entry(device, packed, alignments, lengths, batch_size, count,
+                baseline, precision='bf16x3'):
+    """The same resident batch through an engine of the opt-in precision:
+    rates, and the worst score difference to the f32 engine's scores."""
+    engine = emphases_amd.engine.Engine(
+        cfg.DEFAULT, None, device, precision=precision)
+    kept = []
+    seconds, words, total, checksum, laps = replay_time(
+        engine, packed, alignments, lengths, batch_size, keep=kept)
+    entry = rates(count, total, words, seconds)
+    entry.update({
+        'precision': precision, 'checksum': checksum, 'laps': laps,
+        'max_abs_dscore_vs_f32': float((kept[0] - baseline).abs().max()),
+        'words_compared': int(kept[0].numel()),
+        'what': 'device-only graph replay, audio resident, opt-in precision'})
+    del engine
+    return entry
 
 
 def side_corpus(device):
@@ -1118,13 +1141,17 @@ def side_corpus(device):
                           for i, n in zip(indices, lengths)]), lengths
 
     packed, lengths = packed_of(own)
+    kept = []
     seconds, words, total, checksum, laps = replay_time(
-        engine, packed, [alignments[i] for i in own], lengths, None)
+        engine, packed, [alignments[i] for i in own], lengths, None, keep=kept)
     entry = rates(len(own), total, words, seconds)
     entry.update({'utterances': len(own), 'frames': total, 'words': words,
                   'checksum': checksum, 'laps': laps,
                   'what': 'device-only graph replay, audio resident'})
     result['rank0_of_8_device_only'] = entry
+    result['rank0_of_8_device_only_bf16x3'] = guarded(
+        split_entry, device, packed, [alignments[i] for i in own], lengths,
+        None, len(own), kept[0])
     audios = [host[picks[i]][:, :int(frames[i]) * cfg.HOPSIZE] for i in own]
     seconds, api_sum = api_time([alignments[i] for i in own], audios, None)
     entry = rates(len(own), total, words, seconds)
@@ -1159,8 +1186,9 @@ def side_longform(device):
         synth.word_frames(9000 + i, 30000)) for i in range(count)]
     lengths = [int(a.shape[1]) for a in host]
     packed = torch.cat([a.reshape(-1) for a in host]).to(device)
+    kept = []
     seconds, words, total, checksum, laps = replay_time(
-        engine, packed, alignments, lengths, 3000)
+        engine, packed, alignments, lengths, 3000, keep=kept)
     result = {'workload': (
         '8 synthetic 5-minute utterances (one GPU\'s share of 64 per node), '
         'conv config, chunked at batch_size = 3000 frames '
@@ -1171,6 +1199,8 @@ def side_longform(device):
                       alignments, lengths, 3000)),
                   'what': 'device-only graph replay, audio resident'})
     result['device_only'] = entry
+    result['device_only_bf16x3'] = guarded(
+        split_entry, device, packed, alignments, lengths, 3000, count, kept[0])
     seconds, api_sum = api_time(alignments, host, 3000)
     entry = rates(count, total, words, seconds)
     entry.update({'checksum': api_sum, 'what': (
@@ -1598,8 +1628,19 @@ def compact_line(result):
         'configs_3_whole_corpus_utterances_per_s':
             ('configs_3_corpus', 'whole_corpus_device_only',
              'utterances_per_s'),
+        'configs_3_shard_bf16x3_frames_per_s':
+            ('configs_3_corpus', 'rank0_of_8_device_only_bf16x3',
+             'frames_per_s'),
+        'configs_3_shard_bf16x3_max_abs_dscore':
+            ('configs_3_corpus', 'rank0_of_8_device_only_bf16x3',
+             'max_abs_dscore_vs_f32'),
         'configs_4_frames_per_s':
             ('configs_4_longform', 'device_only', 'frames_per_s'),
+        'configs_4_bf16x3_frames_per_s':
+            ('configs_4_longform', 'device_only_bf16x3', 'frames_per_s'),
+        'configs_4_bf16x3_max_abs_dscore':
+            ('configs_4_longform', 'device_only_bf16x3',
+             'max_abs_dscore_vs_f32'),
         'configs_4_api_pcm16_frames_per_s':
             ('configs_4_longform', 'api_pcm16', 'frames_per_s'),
         # ... strong-scaled over the ranks (N > 1)
